@@ -1,0 +1,766 @@
+/*
+ * oz2_oracle.c -- CPU restatement of the Ozaki-scheme-II GEMM emulation (TEST INFRASTRUCTURE).
+ *
+ * This file is the parity oracle for the HIP library in gemmul8_amd/csrc.  It is NOT part of the
+ * product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ * It restates, in plain scalar C, the algorithm of the reference (paths relative to
+ * /root/reference/GEMMul8):
+ *
+ *   phase                         reference
+ *   ----------------------------  -----------------------------------------------------------
+ *   extract (7-bit upper bounds)  src/scaling_accu_real.hpp:23-136, src/scaling.hpp:3-94,
+ *                                 src/scaling_accu_complex.hpp:6-126
+ *   bound GEMM + row/col max      src/scaling_accu_real.hpp:415-432, src/find_max.hpp:67-251,
+ *                                 src/scaling_accu_complex.hpp:441-460
+ *   accurate-mode shift           src/scaling_accu_real.hpp:6-18,142-226
+ *   fast-mode shift               src/scaling_fast_real.hpp:6-49, src/find_max.hpp:258-341
+ *   quantise + residues           src/scaling_fast_real.hpp:54-137, src/scaling.hpp:99-280,
+ *                                 src/mod.hpp:8-98,194-355
+ *   INT8 GEMM + requantise        src/gemmul8_real.hpp:144-191, src/conv_hi2mid_real.hpp:9-25,
+ *                                 src/conv_hi2mid_complex.hpp:9-127
+ *   CRT accumulate + unscale      src/inverse_scaling_real.hpp:8-187,
+ *                                 src/inverse_scaling_complex.hpp:8-231,
+ *                                 src/template_math.hpp:61-75
+ *   FP8 residue splitting         src/mod.hpp:106-189, src/gemmul8_real.hpp:159-181
+ *
+ * Conventions: column-major BLAS operands; "rows" of an operand are the m rows of op(A) or the
+ * n columns of op(B); an operand is K-MAJOR when element (r,kk) sits at X[r*ld+kk] (A with op T/C,
+ * B with op N) and ROW-STRIDED when it sits at X[kk*ld+r] (A with op N, B with op T/C).
+ * Intermediate planes are returned UNPADDED: lo[part][t][r][kk], C_mid[t][j][i] (complex:
+ * interleaved re,im), shifts as the NEGATED int16 the reference stores.
+ *
+ * Where the reference's behaviour is undefined (all-zero row/column in accurate mode gives
+ * log2(0) = -inf -> saturated cast, scaling_accu_real.hpp:9-10) the oracle defines f(0) = 0.
+ * log2f here is the host libm's; the device uses v_log_f32 -- shifts can differ at rare integer
+ * boundaries (see DESIGN.md "parity policy"); everything downstream is exact given the shifts.
+ */
+#include <fenv.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "tables.inc"
+
+#define OZ_F32 0
+#define OZ_F64 1
+#define OZ_C32 2
+#define OZ_C64 3
+#define OZ_INT8 0
+#define OZ_FP8 1
+
+static inline int is_cplx(int dtype) { return dtype >= 2; }
+static inline int is_f32(int dtype) { return dtype == OZ_F32 || dtype == OZ_C32; }
+static inline size_t pad256(size_t x) { return (x + 255) / 256 * 256; }
+
+/* ---------------- table access ---------------- */
+static const int *moduli_of(int backend) { return backend == OZ_INT8 ? GEMMUL8_MODULI_INT8 : GEMMUL8_MODULI_FP8; }
+static float log2P_of(int backend, unsigned N) { return backend == OZ_INT8 ? GEMMUL8_LOG2P_INT8[N - 2] : GEMMUL8_LOG2P_FP8[N - 2]; }
+static int p_is_double(int backend) { return backend == OZ_INT8 ? 6 : 5; }
+static int max_ufp(int backend) { return backend == OZ_INT8 ? 5 : 7; }
+/* number of low-precision planes per modulus (table.hpp:69-75) */
+static int planes_of(int backend, int t) { return backend == OZ_INT8 ? 1 : (t < 6 ? 2 : 3); }
+unsigned oz2_num_mat(int backend, unsigned N) {
+    unsigned s = 0;
+    for (unsigned t = 0; t < N; ++t) s += planes_of(backend, t);
+    return s;
+}
+
+/* ---------------- directed rounding helpers ---------------- */
+static float fmaf_dir(float a, float b, float c, int mode) {
+    volatile float va = a, vb = b, vc = c, r;
+    fesetround(mode);
+    r = fmaf(va, vb, vc);
+    fesetround(FE_TONEAREST);
+    return r;
+}
+static float addf_dir(float a, float b, int mode) {
+    volatile float va = a, vb = b, r;
+    fesetround(mode);
+    r = va + vb;
+    fesetround(FE_TONEAREST);
+    return r;
+}
+static float mulf_dir(float a, float b, int mode) {
+    volatile float va = a, vb = b, r;
+    fesetround(mode);
+    r = va * vb;
+    fesetround(FE_TONEAREST);
+    return r;
+}
+static float d2f_ru(double a) {
+    volatile double va = a;
+    volatile float r;
+    fesetround(FE_UPWARD);
+    r = (float)va;
+    fesetround(FE_TONEAREST);
+    return r;
+}
+static int ilogb0(double x) { return x == 0.0 ? 0 : ilogb(x); }
+static int ilogb0f(float x) { return x == 0.0f ? 0 : ilogbf(x); }
+
+/* ---------------- element access ---------------- */
+static inline void load_elem(int dtype, const void *X, size_t idx, int conj, double *re, double *im) {
+    switch (dtype) {
+    case OZ_F32: *re = ((const float *)X)[idx]; *im = 0; break;
+    case OZ_F64: *re = ((const double *)X)[idx]; *im = 0; break;
+    case OZ_C32: *re = ((const float *)X)[2 * idx]; *im = ((const float *)X)[2 * idx + 1]; break;
+    default: *re = ((const double *)X)[2 * idx]; *im = ((const double *)X)[2 * idx + 1]; break;
+    }
+    if (conj) *im = -*im;
+}
+static inline size_t elem_index(int kmajor, size_t ld, size_t r, size_t kk) { return kmajor ? r * ld + kk : kk * ld + r; }
+
+/* ---------------- exact scaled truncation: trunc(|x| * 2^sft) = M * 2^E ---------------- */
+typedef struct {
+    int neg;
+    uint64_t M; /* < 2^53 */
+    int E;      /* >= 0 */
+} oz_int_t;
+
+static oz_int_t trunc_scale(double x, int sft) {
+    oz_int_t r = {0, 0, 0};
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    r.neg = (int)(bits >> 63);
+    int e = (int)((bits >> 52) & 0x7FF);
+    uint64_t frac = bits & 0xFFFFFFFFFFFFFull;
+    uint64_t mant;
+    if (e) {
+        mant = frac | (1ull << 52);
+    } else {
+        mant = frac;
+        e = 1;
+    }
+    if (mant == 0) return r;
+    int x2 = e - 1023 - 52 + sft; /* value = mant * 2^x2 */
+    if (x2 >= 0) {
+        r.M = mant;
+        r.E = x2;
+    } else {
+        r.M = (-x2 >= 64) ? 0 : (mant >> (-x2));
+        r.E = 0;
+    }
+    if (r.M == 0) r.neg = 0, r.E = 0;
+    return r;
+}
+
+/* ceil(|x| * 2^sft) as int8 (scaling.hpp:3-46): exact ceiling, tiny non-zero -> 1, 0 -> 0 */
+static int8_t upper_bound_i8(double x, int sft) {
+    uint64_t bits;
+    memcpy(&bits, &x, 8);
+    bits &= ~(1ull << 63);
+    if (bits == 0) return 0;
+    int e = (int)(bits >> 52);
+    uint64_t frac = bits & 0xFFFFFFFFFFFFFull;
+    uint64_t mant;
+    if (e) {
+        mant = frac | (1ull << 52);
+    } else {
+        mant = frac;
+        e = 1;
+    }
+    int x2 = e - 1023 - 52 + sft; /* |x|*2^sft = mant * 2^x2 */
+    if (x2 >= 0) return (int8_t)(mant << (x2 > 63 ? 63 : x2));
+    if (-x2 >= 64) return 1;
+    uint64_t fl = mant >> (-x2);
+    uint64_t has = (mant & ((1ull << (-x2)) - 1)) != 0;
+    return (int8_t)(fl + has);
+}
+
+/* symmetric residue of (+-M * 2^E) mod p, in (-p/2, p/2]  (mod.hpp:8-98) */
+static int sym_mod_big(oz_int_t v, int p) {
+    uint64_t r = v.M % (uint64_t)p;
+    uint64_t pw = 1;
+    uint64_t b = 2 % (uint64_t)p;
+    int e = v.E;
+    while (e) {
+        if (e & 1) pw = pw * b % p;
+        b = b * b % p;
+        e >>= 1;
+    }
+    r = r * pw % p; /* in [0,p) */
+    int s = (int)r;
+    if (v.neg) s = (p - s) % p;
+    if (s > p / 2) s -= p;
+    return s;
+}
+static int sym_mod_i64(int64_t a, int p) {
+    int64_t r = a % p;
+    if (r < 0) r += p;
+    if (r > p / 2) r -= p;
+    return (int)r;
+}
+/* wrapping (mod.hpp:8-12) */
+static int wrapping(int a, int p) {
+    int h = p / 2;
+    return (a > h) ? a - p : ((a < -h) ? a + p : a);
+}
+
+/* ---------------- OCP FP8 e4m3 encode of a small integer (exact) and round-up encode ------- */
+static uint8_t e4m3_from_double_rn(double a) { /* saturating RN-even conversion, finite inputs */
+    uint8_t sign = (a < 0 || (a == 0 && signbit(a))) ? 0x80 : 0;
+    double x = fabs(a);
+    if (x == 0) return sign;
+    if (x > 448.0) x = 448.0;
+    int e = ilogb(x);
+    if (e < -6) e = -6; /* subnormal range: step 2^-9 */
+    double step = ldexp(1.0, e - 3);
+    double q = nearbyint(x / step); /* RN-even (default rounding mode) */
+    double y = q * step;
+    if (y > 448.0) y = 448.0;
+    if (y == 0) return sign;
+    int ey = ilogb(y);
+    if (ey < -6) { /* subnormal */
+        int m = (int)(y / ldexp(1.0, -9));
+        return sign | (uint8_t)m;
+    }
+    int m = (int)(y / ldexp(1.0, ey - 3)) - 8;
+    return sign | (uint8_t)(((ey + 7) << 3) | m);
+}
+static double e4m3_to_double(uint8_t b) {
+    int s = b >> 7, e = (b >> 3) & 0xF, m = b & 7;
+    double v = e ? ldexp(1.0 + m / 8.0, e - 7) : ldexp(m / 8.0, -6);
+    return s ? -v : v;
+}
+/* fp8_e4m3_ru (scaling.hpp:48-54): RN conversion, then +1 encoding step if the result is below a */
+static uint8_t e4m3_ru(double a) {
+    uint8_t r = e4m3_from_double_rn(a);
+    double y = e4m3_to_double(r);
+    return (uint8_t)(r + (y < a));
+}
+
+/* ---------------- phase 1: accurate-mode extract ---------------- */
+/* out: lo planes [(1|3)][rows][k] (int8 or e4m3 bytes), sft0[rows] (NOT negated: maxUFP - ilogb(amax)) */
+void oz2_extract(int dtype, int backend, int kmajor, int conj, size_t rows, size_t k, const void *X, size_t ld,
+                 uint8_t *lo, int16_t *sft0) {
+    const int cplx = is_cplx(dtype);
+    const size_t plane = rows * k;
+    for (size_t r = 0; r < rows; ++r) {
+        double amax = 0;
+        for (size_t kk = 0; kk < k; ++kk) {
+            double re, im;
+            load_elem(dtype, X, elem_index(kmajor, ld, r, kk), 0, &re, &im);
+            amax = fmax(amax, fmax(fabs(re), fabs(im)));
+        }
+        const int s = max_ufp(backend) - (is_f32(dtype) ? ilogb0f((float)amax) : ilogb0(amax));
+        sft0[r] = (int16_t)s;
+        for (size_t kk = 0; kk < k; ++kk) {
+            double re, im;
+            load_elem(dtype, X, elem_index(kmajor, ld, r, kk), conj, &re, &im);
+            if (backend == OZ_INT8) {
+                int8_t a = upper_bound_i8(re, s), b = upper_bound_i8(im, s);
+                lo[r * k + kk] = (uint8_t)a;
+                if (cplx) {
+                    lo[plane + r * k + kk] = (uint8_t)b;
+                    lo[2 * plane + r * k + kk] = (uint8_t)(int8_t)(a - b);
+                }
+            } else {
+                /* scalbn(fabs(x), s) is exact unless it underflows; computed in the input type */
+                double sa = is_f32(dtype) ? (double)scalbnf(fabsf((float)re), s) : scalbn(fabs(re), s);
+                double sb = is_f32(dtype) ? (double)scalbnf(fabsf((float)im), s) : scalbn(fabs(im), s);
+                uint8_t a = e4m3_ru(sa), b = e4m3_ru(sb);
+                lo[r * k + kk] = a;
+                if (cplx) {
+                    lo[plane + r * k + kk] = b;
+                    /* sub_ru_8bit (scaling_accu_complex.hpp:7-10): half(a)-half(b) is exact here */
+                    lo[2 * plane + r * k + kk] = e4m3_ru(e4m3_to_double(a) - e4m3_to_double(b));
+                }
+            }
+        }
+    }
+}
+
+/* ---------------- phase 2: bound GEMM, row/col max, final accurate-mode shifts ------------- */
+static int accu_shift_from_max_i32(int32_t amax, float log2P) {
+    if (amax <= 0) return 0; /* oracle definition for the reference's undefined case */
+    float l = log2f((float)amax);
+    return (int)floorf(fmaf_dir(-0x1.000006p-1f, l, log2P, FE_DOWNWARD));
+}
+static int accu_shift_from_max_f32(float amax, float log2P) {
+    if (!(amax > 0)) return 0;
+    float l = log2f(amax);
+    return (int)floorf(fmaf_dir(-0x1.000006p-1f, l, log2P, FE_DOWNWARD));
+}
+
+/* sftA/sftB in: sft0 from oz2_extract; out: NEGATED final shifts. rmax/cmax optional outputs. */
+void oz2_bound_shifts(int backend, int cplx, unsigned N, size_t m, size_t n, size_t k, const uint8_t *Abar,
+                      const uint8_t *Bbar, int16_t *sftA, int16_t *sftB, int update_A, int update_B) {
+    const float log2P = log2P_of(backend, N);
+    const size_t pa = m * k, pb = n * k;
+    if (backend == OZ_INT8) {
+        int32_t *rmax = calloc(m, 4), *cmax = calloc(n, 4);
+        for (size_t j = 0; j < n; ++j)
+            for (size_t i = 0; i < m; ++i) {
+                int32_t v;
+                if (!cplx) {
+                    int32_t s = 0;
+                    const int8_t *a = (const int8_t *)Abar + i * k, *b = (const int8_t *)Bbar + j * k;
+                    for (size_t kk = 0; kk < k; ++kk) s += (int32_t)a[kk] * b[kk];
+                    v = s;
+                } else {
+                    /* C1 = Ar*Bi + Ai*Br ; C0 = (Ar-Ai)*(Br-Bi) ; bounds: max(C0+C1, C1) */
+                    const int8_t *ar = (const int8_t *)Abar + i * k, *ai = ar + pa, *ad = ai + pa;
+                    const int8_t *br = (const int8_t *)Bbar + j * k, *bi = br + pb, *bd = bi + pb;
+                    int32_t c0 = 0, c1 = 0;
+                    for (size_t kk = 0; kk < k; ++kk) {
+                        c1 += (int32_t)ar[kk] * bi[kk] + (int32_t)ai[kk] * br[kk];
+                        c0 += (int32_t)ad[kk] * bd[kk];
+                    }
+                    int32_t t3 = c0 + c1;
+                    v = t3 > c1 ? t3 : c1;
+                }
+                if (v > rmax[i]) rmax[i] = v;
+                if (v > cmax[j]) cmax[j] = v;
+            }
+        if (update_A)
+            for (size_t i = 0; i < m; ++i) sftA[i] = (int16_t)(-(sftA[i] + accu_shift_from_max_i32(rmax[i], log2P)));
+        if (update_B)
+            for (size_t j = 0; j < n; ++j) sftB[j] = (int16_t)(-(sftB[j] + accu_shift_from_max_i32(cmax[j], log2P)));
+        free(rmax);
+        free(cmax);
+    } else {
+        /* FP8: products of e4m3 values accumulated in fp32 (exact integers here are not guaranteed:
+           bound entries go up to 256 with 3-bit mantissas; the reference inflates by (k+1)*2^-24,
+           find_max.hpp:82-96).  Accumulate in double (exact) and round to float once per entry,
+           which is what an exact-product / fp32-accumulate engine returns when no rounding occurs;
+           the inflation covers the engine's rounding either way. */
+        float *rmax = calloc(m, 4), *cmax = calloc(n, 4);
+        const float ku = (float)(k + 1) * 0x1.0p-24f;
+        for (size_t j = 0; j < n; ++j)
+            for (size_t i = 0; i < m; ++i) {
+                float v;
+                if (!cplx) {
+                    double s = 0;
+                    for (size_t kk = 0; kk < k; ++kk) s += e4m3_to_double(Abar[i * k + kk]) * e4m3_to_double(Bbar[j * k + kk]);
+                    float t = (float)s;
+                    v = fmaf_dir(ku, t, t, FE_UPWARD);
+                } else {
+                    const uint8_t *ar = Abar + i * k, *ai = ar + pa, *ad = ai + pa;
+                    const uint8_t *br = Bbar + j * k, *bi = br + pb, *bd = bi + pb;
+                    double c0 = 0, c1 = 0, c2 = 0;
+                    for (size_t kk = 0; kk < k; ++kk) {
+                        c1 += e4m3_to_double(ar[kk]) * e4m3_to_double(bi[kk]);
+                        c2 += e4m3_to_double(ai[kk]) * e4m3_to_double(br[kk]);
+                        c0 += e4m3_to_double(ad[kk]) * e4m3_to_double(bd[kk]);
+                    }
+                    float ArBi = (float)c1, AiBr = (float)c2, AriBri = (float)c0;
+                    float ArBi_up = fmaf_dir(ku, ArBi, ArBi, FE_UPWARD);
+                    float AiBr_up = fmaf_dir(ku, AiBr, AiBr, FE_UPWARD);
+                    float s12 = addf_dir(ArBi_up, AiBr_up, FE_UPWARD);
+                    float AriBri_up = fmaf_dir(ku, AriBri, AriBri, FE_UPWARD);
+                    float s0 = addf_dir(AriBri_up, s12, FE_UPWARD);
+                    v = s0 > s12 ? s0 : s12;
+                }
+                if (v > rmax[i]) rmax[i] = v;
+                if (v > cmax[j]) cmax[j] = v;
+            }
+        if (update_A)
+            for (size_t i = 0; i < m; ++i) sftA[i] = (int16_t)(-(sftA[i] + accu_shift_from_max_f32(rmax[i], log2P)));
+        if (update_B)
+            for (size_t j = 0; j < n; ++j) sftB[j] = (int16_t)(-(sftB[j] + accu_shift_from_max_f32(cmax[j], log2P)));
+        free(rmax);
+        free(cmax);
+    }
+}
+
+/* ---------------- fast-mode shifts (order-faithful round-up reductions) ---------------- */
+static double fma_ru_d(double a, double b, double c) {
+    volatile double va = a, vb = b, vc = c, r;
+    fesetround(FE_UPWARD);
+    r = fma(va, vb, vc);
+    fesetround(FE_TONEAREST);
+    return r;
+}
+static double add_ru_d(double a, double b) {
+    volatile double va = a, vb = b, r;
+    fesetround(FE_UPWARD);
+    r = va + vb;
+    fesetround(FE_TONEAREST);
+    return r;
+}
+static int fast_shift(int f32, int backend, unsigned N, double amax, double vecnrm) {
+    const float log2P = log2P_of(backend, N);
+    float log2vsum;
+    if (f32) {
+        log2vsum = log2f((float)vecnrm);
+    } else {
+        const int exponent = ilogb0(vecnrm);
+        const float vf = d2f_ru(scalbn(vecnrm, -exponent));
+        log2vsum = addf_dir(log2f(vf), (float)exponent, FE_UPWARD);
+    }
+    const float log2vnrm = mulf_dir(0x1.000006p-1f, log2vsum, FE_UPWARD);
+    const float e0 = addf_dir(log2P, -1.5f, FE_DOWNWARD);
+    const float exp1 = addf_dir(e0, -fmaxf(1.0f, log2vnrm), FE_DOWNWARD);
+    return (int)floorf(exp1) - ilogb0f((float)amax);
+}
+/* lanes: number of partial accumulators (256 for the K-major kernel = 8 groups of 32; 32 for the
+ * row-strided tile kernel); element kk goes to lane kk % lanes; then width-32 shuffle trees
+ * (find_max.hpp:258-341, template_math.hpp:179-212). */
+static void fast_norm(int dtype, int kmajor, int conj, size_t r, size_t k, const void *X, size_t ld, double *amax_out,
+                      double *nrm_out) {
+    const int f32 = is_f32(dtype);
+    const int lanes = kmajor ? 256 : 32;
+    double sum[256];
+    double amax = 0;
+    for (int l = 0; l < lanes; ++l) sum[l] = 0;
+    for (size_t kk = 0; kk < k; ++kk) {
+        double re, im;
+        load_elem(dtype, X, elem_index(kmajor, ld, r, kk), conj, &re, &im);
+        re = fabs(re);
+        im = fabs(im);
+        amax = fmax(amax, fmax(re, im));
+        const int l = (int)(kk % lanes);
+        if (f32) {
+            float s = (float)sum[l];
+            s = fmaf_dir((float)re, (float)re, s, FE_UPWARD);
+            if (is_cplx(dtype)) s = fmaf_dir((float)im, (float)im, s, FE_UPWARD);
+            sum[l] = s;
+        } else {
+            double s = sum[l];
+            s = fma_ru_d(re, re, s);
+            if (is_cplx(dtype)) s = fma_ru_d(im, im, s);
+            sum[l] = s;
+        }
+    }
+    /* width-32 trees inside each group of 32 lanes */
+    const int groups = lanes / 32;
+    double g[8];
+    for (int w = 0; w < groups; ++w) {
+        double *v = sum + 32 * w;
+        for (int off = 16; off > 0; off >>= 1)
+            for (int l = 0; l < off; ++l) v[l] = f32 ? (double)addf_dir((float)v[l], (float)v[l + off], FE_UPWARD) : add_ru_d(v[l], v[l + off]);
+        g[w] = v[0];
+    }
+    double tot = g[0];
+    if (groups > 1) {
+        double v[32];
+        for (int l = 0; l < 32; ++l) v[l] = l < groups ? g[l] : 0.0;
+        for (int off = 16; off > 0; off >>= 1)
+            for (int l = 0; l < off; ++l) v[l] = f32 ? (double)addf_dir((float)v[l], (float)v[l + off], FE_UPWARD) : add_ru_d(v[l], v[l + off]);
+        tot = v[0];
+    }
+    *amax_out = amax;
+    *nrm_out = tot;
+}
+void oz2_fast_shifts(int dtype, int backend, unsigned N, int kmajor, size_t rows, size_t k, const void *X, size_t ld,
+                     int16_t *sft) {
+    for (size_t r = 0; r < rows; ++r) {
+        double amax, nrm;
+        fast_norm(dtype, kmajor, 0, r, k, X, ld, &amax, &nrm);
+        sft[r] = (int16_t)(-fast_shift(is_f32(dtype), backend, N, amax, nrm));
+    }
+}
+
+/* ---------------- phase 3: quantise + residues ---------------- */
+/* FP8 splitting of a residue (mod.hpp:159-189): square moduli a = s*hi + lo, else a = 16*hi + lo, third = hi+lo */
+static void fp8_split(int a, int t, uint8_t *out, size_t stride) {
+    if (t < 6) {
+        const int s = GEMMUL8_SQRT_MODULI_FP8[t];
+        const float af = (float)a;
+        const float q = af * (1.0f / (float)s);
+        const float hx = rintf(q);
+        const float ly = fmaf(-(float)s, hx, af);
+        out[0] = e4m3_from_double_rn(hx);
+        out[stride] = e4m3_from_double_rn(ly);
+    } else {
+        const unsigned absu = (unsigned)(a < 0 ? -a : a);
+        const int q = (int)((absu + 15u) >> 4);
+        const int bx = a < 0 ? -q : q;
+        const int by = a - 16 * bx;
+        out[0] = e4m3_from_double_rn(bx);
+        out[stride] = e4m3_from_double_rn(by);
+        out[2 * stride] = e4m3_from_double_rn(bx + by);
+    }
+}
+
+/* sft: NEGATED shifts (as stored).  lo layout: [part(1|3)][num_mat planes][rows][k] */
+void oz2_quantise(int dtype, int backend, unsigned N, int kmajor, int conj, size_t rows, size_t k, const void *X,
+                  size_t ld, const int16_t *sft, uint8_t *lo) {
+    const int cplx = is_cplx(dtype);
+    const int *p = moduli_of(backend);
+    const size_t plane = rows * k;
+    const size_t part_stride = plane * oz2_num_mat(backend, N);
+    for (size_t r = 0; r < rows; ++r) {
+        const int s = -(int)sft[r];
+        for (size_t kk = 0; kk < k; ++kk) {
+            double re, im;
+            load_elem(dtype, X, elem_index(kmajor, ld, r, kk), conj, &re, &im);
+            const oz_int_t vr = trunc_scale(re, s), vi = trunc_scale(im, s);
+            size_t pl = 0;
+            for (unsigned t = 0; t < N; ++t) {
+                const int rr = sym_mod_big(vr, p[t]);
+                const size_t off = pl * plane + r * k + kk;
+                if (backend == OZ_INT8) {
+                    lo[off] = (uint8_t)(int8_t)rr;
+                    if (cplx) {
+                        const int ri = sym_mod_big(vi, p[t]);
+                        lo[part_stride + off] = (uint8_t)(int8_t)ri;
+                        /* third plane from the int8-cast values (mod.hpp:321-325) */
+                        lo[2 * part_stride + off] = (uint8_t)(int8_t)wrapping((int)(int8_t)rr + (int)(int8_t)ri, p[t]);
+                    }
+                } else {
+                    fp8_split(rr, (int)t, lo + off, plane);
+                    if (cplx) {
+                        const int ri = sym_mod_big(vi, p[t]);
+                        fp8_split(ri, (int)t, lo + part_stride + off, plane);
+                        fp8_split(wrapping(rr + ri, p[t]), (int)t, lo + 2 * part_stride + off, plane);
+                    }
+                }
+                pl += planes_of(backend, (int)t);
+            }
+        }
+    }
+}
+
+/* ---------------- phase 4: low-precision GEMMs + requantise ---------------- */
+static int64_t dot_i8(const int8_t *a, const int8_t *b, size_t k) {
+    int32_t s = 0;
+    for (size_t kk = 0; kk < k; ++kk) s += (int32_t)a[kk] * (int32_t)b[kk];
+    return s;
+}
+static int64_t dot_f8(const uint8_t *a, const uint8_t *b, size_t k) {
+    /* all stored values are integers of magnitude <= 16: products and sums are exact in fp32 for
+       k <= 65536; accumulate in int64 and let the caller reduce (any exact engine agrees). */
+    int64_t s = 0;
+    for (size_t kk = 0; kk < k; ++kk) s += (int64_t)e4m3_to_double(a[kk]) * (int64_t)e4m3_to_double(b[kk]);
+    return s;
+}
+/* residue of one (part-plane set) product, before the final symmetric wrap */
+static int64_t modprod(int backend, int t, const uint8_t *a, const uint8_t *b, size_t k, size_t pa, size_t pb) {
+    if (backend == OZ_INT8) return dot_i8((const int8_t *)a, (const int8_t *)b, k);
+    const int p = GEMMUL8_MODULI_FP8[t];
+    if (t < 6) {
+        /* C0 = Ahi*Blo, C1 = Alo*Bhi, C2 = Alo*Blo ; value = s*(C0+C1)+C2 (mod.hpp:117-123) */
+        const int s = GEMMUL8_SQRT_MODULI_FP8[t];
+        int64_t c0 = dot_f8(a, b + pb, k), c1 = dot_f8(a + pa, b, k), c2 = dot_f8(a + pa, b + pb, k);
+        return (int64_t)s * (sym_mod_i64(c0, p) + sym_mod_i64(c1, p)) + sym_mod_i64(c2, p);
+    }
+    /* Karatsuba: C0 = hi*hi', C1 = lo*lo', C2 = (hi+lo)(hi'+lo') ; 256*C0 + 16*(C2-C0-C1) + C1 */
+    int64_t c0 = dot_f8(a, b, k), c1 = dot_f8(a + pa, b + pb, k), c2 = dot_f8(a + 2 * pa, b + 2 * pb, k);
+    int64_t r0 = sym_mod_i64(c0, p), r1 = sym_mod_i64(c1, p), r2 = sym_mod_i64(c2, p);
+    return 256 * r0 + 16 * (r2 - r0 - r1) + r1;
+}
+/* C_mid: real int8|int16 [N][n][m] ; complex interleaved [N][n][m][2] */
+void oz2_gemm_mod(int backend, int cplx, unsigned N, size_t m, size_t n, size_t k, const uint8_t *A_lo,
+                  const uint8_t *B_lo, void *C_mid, unsigned t_begin, unsigned t_end) {
+    const int *p = moduli_of(backend);
+    const size_t pa = m * k, pb = n * k;
+    const size_t nm = oz2_num_mat(backend, N);
+    const size_t partA = pa * nm, partB = pb * nm;
+    size_t pl = 0;
+    for (unsigned t = 0; t < N; ++t) {
+        if (t >= t_begin && t < t_end) {
+            for (size_t j = 0; j < n; ++j)
+                for (size_t i = 0; i < m; ++i) {
+                    const uint8_t *a = A_lo + pl * pa + i * k, *b = B_lo + pl * pb + j * k;
+                    const size_t o = (size_t)t * m * n + j * m + i;
+                    if (!cplx) {
+                        const int r = sym_mod_i64(modprod(backend, (int)t, a, b, k, pa, pb), p[t]);
+                        if (backend == OZ_INT8) ((int8_t *)C_mid)[o] = (int8_t)r;
+                        else ((int16_t *)C_mid)[o] = (int16_t)r;
+                    } else {
+                        /* X = ArBr, Y = AiBi, Z = AriBri ; Cr = X-Y, Ci = Z-X-Y (conv_hi2mid_complex.hpp:9-26) */
+                        int64_t X = modprod(backend, (int)t, a, b, k, pa, pb);
+                        int64_t Y = modprod(backend, (int)t, a + partA, b + partB, k, pa, pb);
+                        int64_t Z = modprod(backend, (int)t, a + 2 * partA, b + 2 * partB, k, pa, pb);
+                        const int cr = sym_mod_i64(X - Y, p[t]), ci = sym_mod_i64(Z - X - Y, p[t]);
+                        if (backend == OZ_INT8) {
+                            ((int8_t *)C_mid)[2 * o] = (int8_t)cr;
+                            ((int8_t *)C_mid)[2 * o + 1] = (int8_t)ci;
+                        } else {
+                            ((int16_t *)C_mid)[2 * o] = (int16_t)cr;
+                            ((int16_t *)C_mid)[2 * o + 1] = (int16_t)ci;
+                        }
+                    }
+                }
+        }
+        pl += planes_of(backend, (int)t);
+    }
+}
+
+/* ---------------- phase 5: CRT accumulation, mod P, unscale, axpby ---------------- */
+static double crt_one(int backend, int use_dd, unsigned N, const void *C_mid, int mid16, size_t stride, size_t idx) {
+    const double(*q1)[20] = backend == OZ_INT8 ? GEMMUL8_QPI1_INT8 : GEMMUL8_QPI1_FP8;
+    const double(*qh)[20] = backend == OZ_INT8 ? GEMMUL8_QPI2_HI_INT8 : GEMMUL8_QPI2_HI_FP8;
+    const double(*ql)[20] = backend == OZ_INT8 ? GEMMUL8_QPI2_LO_INT8 : GEMMUL8_QPI2_LO_FP8;
+    const double Phi = (backend == OZ_INT8 ? GEMMUL8_PNEG_HI_INT8 : GEMMUL8_PNEG_HI_FP8)[N - 2];
+    const double Plo = (backend == OZ_INT8 ? GEMMUL8_PNEG_LO_INT8 : GEMMUL8_PNEG_LO_FP8)[N - 2];
+    const double invP = (backend == OZ_INT8 ? GEMMUL8_INVP_INT8 : GEMMUL8_INVP_FP8)[N - 2];
+    if (!use_dd) {
+        double S = 0;
+        for (unsigned t = 0; t < N; ++t) {
+            const double c = mid16 ? (double)((const int16_t *)C_mid)[t * stride + idx] : (double)((const int8_t *)C_mid)[t * stride + idx];
+            S = fma(q1[N - 2][t], c, S);
+        }
+        const double quot = rint(invP * S);
+        return fma(Phi, quot, S);
+    }
+    double Sh = 0, Sl = 0;
+    for (unsigned t = 0; t < N; ++t) {
+        const double c = mid16 ? (double)((const int16_t *)C_mid)[t * stride + idx] : (double)((const int8_t *)C_mid)[t * stride + idx];
+        Sh = fma(qh[N - 2][t], c, Sh);
+        Sl = fma(ql[N - 2][t], c, Sl);
+    }
+    const double quot = rint(invP * Sh);
+    volatile double inner = fma(Phi, quot, Sh) + Sl;
+    return fma(Plo, quot, inner);
+}
+
+/* scalar_mode: 0 = host scalars (special cases for alpha=+-1, beta in {0,1}; inverse_scaling_real.hpp:218-236),
+ *              1 = device-pointer scalars: always the general fma form (:120-144, :215) */
+void oz2_invscal(int dtype, int backend, unsigned N, size_t m, size_t n, const void *C_mid, const int16_t *sftA,
+                 const int16_t *sftB, const void *alpha, const void *beta, void *C, size_t ldc, int scalar_mode) {
+    const int cplx = is_cplx(dtype), f32 = is_f32(dtype);
+    const int use_dd = !(f32 || (int)N <= p_is_double(backend));
+    const int mid16 = backend == OZ_FP8;
+    const size_t comps = cplx ? 2 : 1;
+    const size_t stride = m * n * comps;
+    double ar, ai, br, bi;
+    load_elem(dtype, alpha, 0, 0, &ar, &ai);
+    load_elem(dtype, beta, 0, 0, &br, &bi);
+    int special = 0; /* 1: C=AB  2: C+=AB  3: C=-AB  4: C-=AB */
+    if (!scalar_mode && ai == 0 && bi == 0) {
+        if (ar == 1 && br == 0) special = 1;
+        else if (ar == 1 && br == 1) special = 2;
+        else if (ar == -1 && br == 0) special = 3;
+        else if (ar == -1 && br == 1) special = 4;
+    }
+    for (size_t j = 0; j < n; ++j)
+        for (size_t i = 0; i < m; ++i) {
+            const int sft = (int)sftA[i] + (int)sftB[j];
+            double ab[2] = {0, 0};
+            for (size_t c = 0; c < comps; ++c) {
+                const double R = crt_one(backend, use_dd, N, C_mid, mid16, stride, (j * m + i) * comps + c);
+                ab[c] = f32 ? (double)scalbnf((float)R, sft) : scalbn(R, sft);
+            }
+            const size_t o = j * ldc + i;
+            if (!cplx) {
+                if (f32) {
+                    float *Cf = (float *)C;
+                    const float AB = (float)ab[0];
+                    switch (special) {
+                    case 1: Cf[o] = AB; break;
+                    case 2: Cf[o] += AB; break;
+                    case 3: Cf[o] = -AB; break;
+                    case 4: Cf[o] -= AB; break;
+                    default: {
+                        volatile float ax = (float)ar * AB;
+                        Cf[o] = fmaf((float)br, Cf[o], ax);
+                    }
+                    }
+                } else {
+                    double *Cd = (double *)C;
+                    const double AB = ab[0];
+                    switch (special) {
+                    case 1: Cd[o] = AB; break;
+                    case 2: Cd[o] += AB; break;
+                    case 3: Cd[o] = -AB; break;
+                    case 4: Cd[o] -= AB; break;
+                    default: {
+                        volatile double ax = ar * AB;
+                        Cd[o] = fma(br, Cd[o], ax);
+                    }
+                    }
+                }
+            } else if (f32) {
+                float *Cf = (float *)C + 2 * o;
+                const float x = (float)ab[0], y = (float)ab[1];
+                switch (special) {
+                case 1: Cf[0] = x, Cf[1] = y; break;
+                case 2: Cf[0] += x, Cf[1] += y; break;
+                case 3: Cf[0] = -x, Cf[1] = -y; break;
+                case 4: Cf[0] -= x, Cf[1] -= y; break;
+                default: {
+                    const float a_x = (float)ar, a_y = (float)ai, b_x = (float)br, b_y = (float)bi, cx = Cf[0], cy = Cf[1];
+                    volatile float t0 = a_x * x, t1 = a_x * y;
+                    Cf[0] = fmaf(-b_y, cy, fmaf(b_x, cx, fmaf(-a_y, y, t0)));
+                    Cf[1] = fmaf(b_y, cx, fmaf(b_x, cy, fmaf(a_y, x, t1)));
+                }
+                }
+            } else {
+                double *Cd = (double *)C + 2 * o;
+                const double x = ab[0], y = ab[1];
+                switch (special) {
+                case 1: Cd[0] = x, Cd[1] = y; break;
+                case 2: Cd[0] += x, Cd[1] += y; break;
+                case 3: Cd[0] = -x, Cd[1] = -y; break;
+                case 4: Cd[0] -= x, Cd[1] -= y; break;
+                default: {
+                    const double cx = Cd[0], cy = Cd[1];
+                    volatile double t0 = ar * x, t1 = ar * y;
+                    Cd[0] = fma(-bi, cy, fma(br, cx, fma(-ai, y, t0)));
+                    Cd[1] = fma(bi, cx, fma(br, cy, fma(ai, x, t1)));
+                }
+                }
+            }
+        }
+}
+
+/* ---------------- full pipeline ---------------- */
+/* op: 0 = N, 1 = T, 2 = C.  Optional outputs may be NULL.  If sftA_in/sftB_in are given (negated
+ * shifts, e.g. read back from the device) they replace the computed ones (parity policy). */
+int oz2_gemm(int dtype, int backend, int opA, int opB, size_t m, size_t n, size_t k, const void *alpha, const void *A,
+             size_t lda, const void *B, size_t ldb, const void *beta, void *C, size_t ldc, unsigned N, int fastmode,
+             int scalar_mode, const int16_t *sftA_in, const int16_t *sftB_in, int16_t *sftA_out, int16_t *sftB_out,
+             uint8_t *A_lo_out, uint8_t *B_lo_out, void *C_mid_out) {
+    if (N < 2 || N > 20) return 1;
+    const int cplx = is_cplx(dtype);
+    const int parts = cplx ? 3 : 1;
+    const int kmajA = opA != 0, kmajB = opB == 0;
+    const int conjA = cplx && opA == 2, conjB = cplx && opB == 2;
+    const size_t nm = oz2_num_mat(backend, N);
+    int16_t *sftA = malloc(2 * m), *sftB = malloc(2 * n);
+    uint8_t *A_lo = malloc(parts * nm * m * k), *B_lo = malloc(parts * nm * n * k);
+    const size_t midsz = (backend == OZ_INT8 ? 1 : 2) * (cplx ? 2 : 1) * m * n * N;
+    void *C_mid = malloc(midsz);
+    if (fastmode) {
+        oz2_fast_shifts(dtype, backend, N, kmajA, m, k, A, lda, sftA);
+        oz2_fast_shifts(dtype, backend, N, kmajB, n, k, B, ldb, sftB);
+    } else {
+        uint8_t *Ab = malloc(parts * m * k), *Bb = malloc(parts * n * k);
+        oz2_extract(dtype, backend, kmajA, conjA, m, k, A, lda, Ab, sftA);
+        oz2_extract(dtype, backend, kmajB, conjB, n, k, B, ldb, Bb, sftB);
+        oz2_bound_shifts(backend, cplx, N, m, n, k, Ab, Bb, sftA, sftB, 1, 1);
+        free(Ab);
+        free(Bb);
+    }
+    if (sftA_in) memcpy(sftA, sftA_in, 2 * m);
+    if (sftB_in) memcpy(sftB, sftB_in, 2 * n);
+    oz2_quantise(dtype, backend, N, kmajA, conjA, m, k, A, lda, sftA, A_lo);
+    oz2_quantise(dtype, backend, N, kmajB, conjB, n, k, B, ldb, sftB, B_lo);
+    oz2_gemm_mod(backend, cplx, N, m, n, k, A_lo, B_lo, C_mid, 0, N);
+    oz2_invscal(dtype, backend, N, m, n, C_mid, sftA, sftB, alpha, beta, C, ldc, scalar_mode);
+    if (sftA_out) memcpy(sftA_out, sftA, 2 * m);
+    if (sftB_out) memcpy(sftB_out, sftB, 2 * n);
+    if (A_lo_out) memcpy(A_lo_out, A_lo, parts * nm * m * k);
+    if (B_lo_out) memcpy(B_lo_out, B_lo, parts * nm * n * k);
+    if (C_mid_out) memcpy(C_mid_out, C_mid, midsz);
+    free(sftA);
+    free(sftB);
+    free(A_lo);
+    free(B_lo);
+    free(C_mid);
+    return 0;
+}
+
+/* workSize restatement (gemmul8_real.hpp:8-47, gemmul8_complex.hpp:8-47) */
+size_t oz2_work_size(int cplx, int backend, size_t m, size_t n, size_t k, unsigned N, int enA, int enB, size_t *wA,
+                     size_t *wB) {
+    const size_t kp = pad256(k), mp = pad256(m);
+    const size_t sizeA = kp * mp, sizeB = kp * n, sizeC = mp * n;
+    const size_t nm = oz2_num_mat(backend, N);
+    const size_t lowsz = 1, midsz = (backend == OZ_INT8 ? 1 : 2) * (cplx ? 2 : 1), hisz = 4;
+    const size_t nhi = backend == OZ_INT8 ? 1 : 3;
+    const size_t parts = cplx ? 3 : 1;
+    const size_t lwork = (size_t)1 << 25;
+    size_t tA = 255, tB = 255, tC = 255;
+    tA += lowsz * sizeA * (nm + (enA ? 1 : 0)) * parts + 2 * mp;
+    tB += lowsz * sizeB * (nm + (enB ? 1 : 0)) * parts + 2 * pad256(n);
+    const size_t one_mid = midsz * sizeC;
+    tC += midsz * sizeC * (N - 1) + (lwork > one_mid ? lwork : one_mid);
+    tC += hisz * sizeC * nhi * parts;
+    if (wA) *wA = tA;
+    if (wB) *wB = tB;
+    return tA + tB + tC;
+}

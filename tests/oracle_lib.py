@@ -1,0 +1,106 @@
+"""ctypes front-end for the CPU oracle (oracle/liboz2_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(ROOT, "oracle", "liboz2_oracle.so")
+
+DT = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.complex64): 2, np.dtype(np.complex128): 3}
+INT8, FP8 = 0, 1
+OPS = {"N": 0, "T": 1, "C": 2}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+        _lib = C.CDLL(_SO)
+        _lib.oz2_num_mat.restype = C.c_uint
+        _lib.oz2_work_size.restype = C.c_size_t
+        _lib.oz2_work_size.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.c_int, C.c_int,
+                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        _lib.oz2_gemm.restype = C.c_int
+        _lib.oz2_gemm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
+                                  C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                  C.c_uint, C.c_int, C.c_int] + [C.c_void_p] * 7
+        _lib.oz2_gemm_mod.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_uint, C.c_uint]
+        _lib.oz2_invscal.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _lib.oz2_quantise.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p,
+                                      C.c_size_t, C.c_void_p, C.c_void_p]
+        _lib.oz2_extract.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                     C.c_void_p, C.c_void_p]
+        _lib.oz2_bound_shifts.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        _lib.oz2_fast_shifts.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p,
+                                         C.c_size_t, C.c_void_p]
+    return _lib
+
+
+def num_mat(backend, N):
+    return lib().oz2_num_mat(backend, N)
+
+
+def work_size(cplx, backend, m, n, k, N, enA=False, enB=False):
+    wa, wb = C.c_size_t(0), C.c_size_t(0)
+    tot = lib().oz2_work_size(int(cplx), backend, m, n, k, N, int(enA), int(enB), C.byref(wa), C.byref(wb))
+    return tot, wa.value, wb.value
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def op_dims(op, rows, k):
+    """Stored shape (column-major, as a Fortran-ordered numpy array) of an operand whose op() is rows x k."""
+    return (rows, k) if op == "N" else (k, rows)
+
+
+def gemm(A, B, N, fastmode=False, backend=INT8, opA="N", opB="N", alpha=1.0, beta=0.0, C0=None, scalar_mode=0,
+         sftA_in=None, sftB_in=None, want_intermediates=False):
+    """Run the oracle pipeline.  A, B: Fortran-ordered 2-D arrays as stored (before op).  Returns C (m x n, F-order)
+    and, if requested, a dict with sftA, sftB, A_lo, B_lo, C_mid."""
+    A = np.asfortranarray(A)
+    B = np.asfortranarray(B)
+    dt = A.dtype
+    assert B.dtype == dt
+    m, k = (A.shape if opA == "N" else A.shape[::-1])
+    kb, n = (B.shape if opB == "N" else B.shape[::-1])
+    assert k == kb
+    cplx = dt.kind == "c"
+    parts = 3 if cplx else 1
+    nm = num_mat(backend, N)
+    Cout = np.zeros((m, n), dtype=dt, order="F") if C0 is None else np.asfortranarray(C0).copy(order="F")
+    al = np.array([alpha], dtype=dt)
+    be = np.array([beta], dtype=dt)
+    inter = {}
+    sA = sB = Alo = Blo = Cmid = None
+    if want_intermediates:
+        sA = np.zeros(m, np.int16)
+        sB = np.zeros(n, np.int16)
+        Alo = np.zeros((parts, nm, m, k), np.uint8)
+        Blo = np.zeros((parts, nm, n, k), np.uint8)
+        mid_dt = np.int8 if backend == INT8 else np.int16
+        Cmid = np.zeros((N, n, m, 2) if cplx else (N, n, m), mid_dt)
+    if sftA_in is not None:
+        sftA_in = np.ascontiguousarray(sftA_in, np.int16)
+    if sftB_in is not None:
+        sftB_in = np.ascontiguousarray(sftB_in, np.int16)
+    rc = lib().oz2_gemm(DT[dt], backend, OPS[opA], OPS[opB], m, n, k, _p(al), _p(A), A.shape[0], _p(B), B.shape[0],
+                        _p(be), _p(Cout), Cout.shape[0], N, int(fastmode), scalar_mode, _p(sftA_in), _p(sftB_in),
+                        _p(sA), _p(sB), _p(Alo), _p(Blo), _p(Cmid))
+    assert rc == 0
+    if want_intermediates:
+        inter = dict(sftA=sA, sftB=sB, A_lo=Alo, B_lo=Blo, C_mid=Cmid)
+        return Cout, inter
+    return Cout

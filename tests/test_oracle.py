@@ -1,0 +1,173 @@
+"""CPU tests (no GPU): pin the oracle against (i) the reference's known-answer sample, (ii) exact
+big-integer identities, (iii) OpenBLAS (BASELINE config 1: SGEMM 256^3, moduli=2), (iv) the
+reference's workSize formula values quoted in SURVEY.md section 8."""
+import json
+import os
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+import bigint_ref as bi
+import oracle_lib as ol
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def kat():
+    d = json.load(open(os.path.join(GOLD, "kat_dgemm_4x5x3.json")))
+    A = np.array([float.fromhex(x) for x in d["A"]]).reshape((d["m"], d["k"]), order="F")
+    B = np.array([float.fromhex(x) for x in d["B"]]).reshape((d["k"], d["n"]), order="F")
+    Cx = np.array([float.fromhex(x) for x in d["C_exact"]]).reshape((d["m"], d["n"]), order="F")
+    return A, B, Cx
+
+
+@pytest.mark.parametrize("backend,N", [(ol.INT8, 15), (ol.FP8, 13)])
+@pytest.mark.parametrize("fast", [False, True])
+def test_kat_sample(backend, N, fast):
+    """sample/dgemm_cuBLAS_int8.cu (N=15) and dgemm_cuBLASLt_fp8.cu (N=13): Frobenius error vs hC_exact."""
+    A, B, Cx = kat()
+    C = ol.gemm(A, B, N, fastmode=fast, backend=backend)
+    err = np.sqrt(((C - Cx) ** 2).sum())
+    assert err < 4e-15, err  # native DGEMM gives ~1e-15 here; the emulation is at least as good
+    # the exact product from rationals agrees with the reference's hC_exact to the last bit
+    for i in range(4):
+        for j in range(3):
+            ex = sum(Fraction(A[i, l]) * Fraction(B[l, j]) for l in range(5))
+            assert float(ex) == Cx[i, j]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("N,fast", [(2, True), (5, False), (8, True), (14, False), (16, False), (20, True)])
+def test_bigint_identities_real(dtype, N, fast):
+    if dtype == np.float32 and N > 13:
+        pytest.skip("float path documented for N<=13")
+    rng = np.random.default_rng(1000 + N)
+    m, n, k = 7, 5, 19
+    A = ((rng.random((m, k)) - 0.5) * np.exp(2 * rng.standard_normal((m, k)))).astype(dtype)
+    B = ((rng.random((k, n)) - 0.5) * np.exp(2 * rng.standard_normal((k, n)))).astype(dtype)
+    A[2, 3] = 0.0
+    C, it = ol.gemm(A, B, N, fastmode=fast, want_intermediates=True)
+    mods = bi.MODULI_INT8[:N]
+    Ai = bi.int_matrix(A, it["sftA"])
+    Bi = bi.int_matrix(B.T, it["sftB"])
+    # residues of the truncated integers, as int8
+    for t, p in enumerate(mods):
+        for i in range(m):
+            for kk in range(k):
+                assert np.int8(it["A_lo"][0, t, i, kk].view(np.int8)) == bi.as_int8(bi.sym(Ai[i][kk], p))
+        for j in range(n):
+            for kk in range(k):
+                assert np.int8(it["B_lo"][0, t, j, kk].view(np.int8)) == bi.as_int8(bi.sym(Bi[j][kk], p))
+    # exact integer product, residues, CRT uniqueness, final value
+    P = 1
+    for p in mods:
+        P *= p
+    for i in range(m):
+        for j in range(n):
+            ex = sum(Ai[i][kk] * Bi[j][kk] for kk in range(k))
+            assert 2 * abs(ex) < P, "shift selection must keep |A'B'| < P/2"
+            for t, p in enumerate(mods):
+                assert int(it["C_mid"][t, j, i]) == bi.as_int8(bi.sym(ex, p))
+            val = Fraction(ex) * Fraction(2) ** (int(it["sftA"][i]) + int(it["sftB"][j]))
+            got = Fraction(float(C[i, j]))
+            if val == 0:
+                assert got == 0
+            else:
+                tol = Fraction(1, 2 ** 51) if dtype == np.float64 else Fraction(1, 2 ** 23)
+                assert abs(got - val) <= tol * abs(val)
+
+
+@pytest.mark.parametrize("N,fast", [(3, False), (9, True), (20, False)])
+def test_bigint_identities_complex(N, fast):
+    rng = np.random.default_rng(7 + N)
+    m, n, k = 4, 3, 11
+    A = (rng.standard_normal((m, k)) + 1j * rng.standard_normal((m, k))).astype(np.complex128)
+    B = (rng.standard_normal((k, n)) + 1j * rng.standard_normal((k, n))).astype(np.complex128)
+    C, it = ol.gemm(A, B, N, fastmode=fast, want_intermediates=True)
+    mods = bi.MODULI_INT8[:N]
+    Ar, Ai_ = bi.int_matrix(A.real, it["sftA"]), bi.int_matrix(A.imag, it["sftA"])
+    Br, Bi_ = bi.int_matrix(B.real.T, it["sftB"]), bi.int_matrix(B.imag.T, it["sftB"])
+    P = 1
+    for p in mods:
+        P *= p
+    for i in range(m):
+        for j in range(n):
+            cr = sum(Ar[i][l] * Br[j][l] - Ai_[i][l] * Bi_[j][l] for l in range(k))
+            ci = sum(Ar[i][l] * Bi_[j][l] + Ai_[i][l] * Br[j][l] for l in range(k))
+            assert 2 * max(abs(cr), abs(ci)) < P
+            for t, p in enumerate(mods):
+                assert int(it["C_mid"][t, j, i, 0]) == bi.as_int8(bi.sym(cr, p))
+                assert int(it["C_mid"][t, j, i, 1]) == bi.as_int8(bi.sym(ci, p))
+            sc = Fraction(2) ** (int(it["sftA"][i]) + int(it["sftB"][j]))
+            for val, got in ((cr * sc, C[i, j].real), (ci * sc, C[i, j].imag)):
+                assert abs(Fraction(float(got)) - val) <= Fraction(1, 2 ** 50) * max(abs(val), abs(Fraction(float(abs(C[i, j])))) / 2 ** 3)
+    # third plane = wrap(re + im) of the int8-cast residues
+    for t, p in enumerate(mods):
+        re = it["A_lo"][0, t].view(np.int8).astype(int)
+        im = it["A_lo"][1, t].view(np.int8).astype(int)
+        s = re + im
+        h = p // 2
+        w = np.where(s > h, s - p, np.where(s < -h, s + p, s))
+        assert np.array_equal(it["A_lo"][2, t].view(np.int8), w.astype(np.int8))
+
+
+def test_ops_and_axpby():
+    """op(N/T/C) x alpha/beta variants (debug/test.cu:106-141) against numpy in high precision."""
+    rng = np.random.default_rng(3)
+    m, n, k = 33, 34, 47
+    for dtype, N, tol in ((np.float64, 14, 1e-13), (np.complex128, 15, 1e-13), (np.float32, 8, 3e-6)):
+        for opA in "NTC":
+            for opB in "NTC":
+                if dtype != np.complex128 and "C" in (opA, opB):
+                    continue
+                sa = (m, k) if opA == "N" else (k, m)
+                sb = (k, n) if opB == "N" else (n, k)
+                A = rng.standard_normal(sa).astype(dtype)
+                B = rng.standard_normal(sb).astype(dtype)
+                if dtype == np.complex128:
+                    A = A + 1j * rng.standard_normal(sa)
+                    B = B + 1j * rng.standard_normal(sb)
+                C0 = rng.standard_normal((m, n)).astype(dtype)
+                f = {"N": lambda x: x, "T": lambda x: x.T, "C": lambda x: x.conj().T}
+                for alpha, beta in ((1, 0), (1, 1), (-1, 0), (-1, 1), (-1.5, 1.5)):
+                    if dtype == np.complex128 and alpha == -1.5:
+                        alpha, beta = -1.5 + 1.2j, 1.5 + 1.2j
+                    C = ol.gemm(A, B, N, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0)
+                    hp = np.complex256 if dtype == np.complex128 else np.longdouble
+                    ref = alpha * (f[opA](A).astype(hp) @ f[opB](B).astype(hp)) + beta * C0.astype(hp)
+                    scale = np.abs(f[opA](A)).astype(hp) @ np.abs(f[opB](B)).astype(hp) + np.abs(C0)
+                    assert np.max(np.abs(C - ref) / scale) < tol
+
+
+def test_config1_sgemm_256_vs_openblas():
+    """BASELINE config 1: SGEMM 256x256x256, moduli=2, INT8 -- host plumbing check vs OpenBLAS (numpy).
+    With N=2, P = 65280: operands are quantised to ~4 bits, so the check is normwise."""
+    rng = np.random.default_rng(12345)
+    A = (rng.random((256, 256)) - 0.5).astype(np.float32)
+    B = (np.random.default_rng(54321).random((256, 256)) - 0.5).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    bound = np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64)
+    for fast in (True, False):
+        C, it = ol.gemm(A, B, 2, fastmode=fast, want_intermediates=True)
+        assert np.max(np.abs(C - ref) / bound) < 2.0 ** -3
+        # exact identity: CRT of the two residue planes reproduces A'^T B' exactly
+        Ai = np.array(bi.int_matrix(A, it["sftA"]), dtype=np.int64)
+        Bi = np.array(bi.int_matrix(B.T, it["sftB"]), dtype=np.int64)
+        ex = Ai @ Bi.T
+        assert np.all(2 * np.abs(ex) < 65280)
+        want = ex.astype(np.float64) * np.exp2(it["sftA"].astype(np.float64))[:, None] * np.exp2(it["sftB"].astype(np.float64))[None, :]
+        assert np.array_equal(C.astype(np.float64), want.astype(np.float32).astype(np.float64))
+
+
+def test_worksize_matches_survey_table():
+    """SURVEY.md section 8 table (from gemmul8_real.hpp:14-46, gemmul8_complex.hpp:14-46)."""
+    GiB = 2.0 ** 30
+    tot, _, _ = ol.work_size(False, ol.INT8, 8192, 8192, 8192, 14)
+    assert abs(tot / GiB - 2.875) < 0.001
+    tot, _, _ = ol.work_size(False, ol.FP8, 16384, 16384, 16384, 6)
+    assert abs(tot / GiB - 12.0) < 0.001
+    tot, _, _ = ol.work_size(False, ol.INT8, 16384, 16384, 16384, 16)
+    assert abs(tot / GiB - 13.0) < 0.001
+    tot, _, _ = ol.work_size(True, ol.INT8, 8192, 8192, 8192, 20)
+    assert abs(tot / GiB - 10.75) < 0.001
