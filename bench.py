@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- emulated DGEMM TFLOPS (N=8192, moduli=14) on N GPUs of one node (BASELINE.json metric).
+
+One "step" = one whole emulated DGEMM C = A*B (8192^3, FP64 in/out, 14 moduli, INT8 MFMA backend,
+accurate mode = the reference's default: 15 INT8 GEMMs) with A, B already resident in HBM.
+N>1: the moduli are sharded over the ranks (gemmul8_amd.dist), residue planes are exchanged over
+RCCL and every rank finishes the columns it owns ("strong" scaling: the problem is fixed).
+
+Prints ONE JSON line (rank 0) with the driver's contract keys plus `roofline` (dominant kernel =
+the batched INT8 MFMA GEMM, events recorded on the launch stream inside the timed region),
+`cpu_baseline` (the CPU oracle port on a bounded sample), `host_blas_dgemm` (numpy/OpenBLAS DGEMM on
+the box's cores, same shape) and `max_rel_err` (vs an 80-bit long-double product on a sampled block).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=8192)
+    ap.add_argument("--moduli", type=int, default=14)
+    ap.add_argument("--fast", action="store_true", help="fast mode (14 GEMMs) instead of accurate (15)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines (profiling runs)")
+    return ap.parse_args()
+
+
+def make_inputs(n, device):
+    """U(-0.5, 0.5) FP64, seeds 12345 (A) / 54321 (B) (testing/common.hpp:35-36), column-major."""
+    gA = torch.Generator(device=device).manual_seed(12345)
+    gB = torch.Generator(device=device).manual_seed(54321)
+    A = torch.rand((n, n), generator=gA, dtype=torch.float64, device=device) - 0.5
+    B = torch.rand((n, n), generator=gB, dtype=torch.float64, device=device) - 0.5
+    return A, B  # tensor (cols, rows) == column-major matrix
+
+
+def cpu_baseline_port(moduli, fast):
+    """Oracle (scalar C port of the reference algorithm) on a bounded sample: DGEMM 384^3."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    s = 384
+    rng = np.random.default_rng(1)
+    A = rng.random((s, s)) - 0.5
+    B = rng.random((s, s)) - 0.5
+    t0 = time.perf_counter()
+    ol.gemm(A, B, moduli, fastmode=fast)
+    dt = time.perf_counter() - t0
+    return {"value": 2.0 * s ** 3 / dt * 1e-12, "unit": "TFLOPS", "cores": 1, "kind": "port",
+            "sample": f"oracle/oz2_oracle.c full pipeline on DGEMM {s}^3, moduli={moduli}, {dt:.2f} s"}
+
+
+def host_blas(n):
+    A = np.random.default_rng(12345).random((n, n)) - 0.5
+    B = np.random.default_rng(54321).random((n, n)) - 0.5
+    A @ B[:, :256]  # warm-up
+    best = 1e30
+    for _ in range(2):
+        t0 = time.perf_counter()
+        A @ B
+        best = min(best, time.perf_counter() - t0)
+    try:
+        from threadpoolctl import threadpool_info
+        thr = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        thr = os.cpu_count()
+    return {"value": 2.0 * n ** 3 / best * 1e-12, "unit": "TFLOPS", "threads": thr, "cores": os.cpu_count(),
+            "lib": "numpy-bundled OpenBLAS DGEMM", "shape": f"{n}^3", "seconds": best}
+
+
+def sampled_error(A, B, C, n):
+    """max |C-Chat|/|Chat| on a 48x48 sampled block, Chat = long-double (80-bit) product."""
+    rows = np.arange(0, n, n // 48)[:48]
+    cols = np.arange(7, n, n // 48)[:48]
+    Ah = A[:, rows].cpu().numpy().T.astype(np.longdouble)   # (48, k): rows of the matrix
+    Bh = B[cols, :].cpu().numpy().T.astype(np.longdouble)   # (k, 48)
+    ref = Ah @ Bh
+    got = C[cols][:, rows].cpu().numpy().T
+    return float(np.max(np.abs((got - ref) / ref)))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    import ctypes as C
+    import gemmul8_amd as g
+
+    n, N = args.size, args.moduli
+    A, B = make_inputs(n, dev)
+    Cmat = torch.zeros((n, n), dtype=torch.float64, device=dev)
+    lib = g.lib()
+    stream = torch.cuda.current_stream(dev)
+    one = np.array([1.0])
+    zero = np.array([0.0])
+    gemm_events = []
+
+    if world == 1:
+        tot, _, _ = g.work_size(False, g.INT8, n, n, n, N)
+        work = torch.empty(tot, dtype=torch.uint8, device=dev)
+        L = g.Layout()
+        g.check(lib.gemmul8_get_layout(g.D, g.INT8, n, n, n, N, work.data_ptr(), None, None, 0, 0, C.byref(L)))
+
+        def step(record):
+            st = stream.cuda_stream
+            g.check(lib.gemmul8_scale(st, g.D, g.INT8, 0, 0, n, n, n, A.data_ptr(), n, B.data_ptr(), n, N, int(args.fast), 0, N,
+                                      C.byref(L), 0, 0))
+            if record:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            g.check(lib.gemmul8_lowprec_gemm(st, g.D, g.INT8, n, n, n, N, 0, N, C.byref(L)))
+            if record:
+                e1.record(stream)
+                gemm_events.append((e0, e1))
+            g.check(lib.gemmul8_crt(st, g.D, g.INT8, N, n, n, L.C_mid, L.mp, L.sizeC, L.sftA, L.sftB, one.ctypes.data,
+                                    zero.ctypes.data, Cmat.data_ptr(), n))
+        parallelism = "single-gpu"
+    else:
+        from gemmul8_amd import dist as gd
+        plan = gd.ShardedGemm(g.D, g.INT8, n, n, n, N, fastmode=args.fast, device=dev)
+
+        def step(record):
+            ev = plan.run(A, B, Cmat, record_gemm_events=record)
+            if record and ev is not None:
+                gemm_events.append(ev)
+        parallelism = f"moduli-sharded x{world} (residue all-to-all over RCCL, column-block CRT)"
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        Cfull = plan.gather_result(Cmat)
+    else:
+        Cfull = Cmat
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        flops = 2.0 * n ** 3
+        value = flops / (ms * 1e-3) * 1e-12
+        planes_here = N if world == 1 else plan.my_planes
+        gemm_ms = float(np.mean([a.elapsed_time(b) for a, b in gemm_events])) if gemm_events else None
+        ops = planes_here * 2.0 * n ** 3
+        peak = 5000.0  # dense INT8 MFMA TOPS (MI355X_MICROARCH.md: ~5 PF-class dense FP8/INT8)
+        roof = None
+        if gemm_ms:
+            ach = ops / (gemm_ms * 1e-3) * 1e-12
+            roof = {"bound": "mfma", "kernel": "oz2::gemm_i8_kernel<EPI_MOD> (batched over moduli)", "achieved": ach, "peak": peak,
+                    "unit": "TOP/s", "frac": ach / peak, "traffic": None, "launch_ms": gemm_ms, "ops_per_launch": ops}
+        out = {
+            "metric": "emulated DGEMM TFLOPS (N=8192, moduli=14)", "value": value, "unit": "TFLOPS", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "int8 MFMA (i32 accumulate) + f64 CRT", "data": "synthetic U(-0.5,0.5), seeds 12345/54321",
+            "config": {"workload": f"DGEMM {n}x{n}x{n}, moduli={N}, INT8 backend, {'fast' if args.fast else 'accurate'} mode "
+                                   f"({N + (0 if args.fast else 1)} INT8 GEMMs), op N/N, alpha=1, beta=0, inputs resident in HBM",
+                       "parallelism": parallelism},
+            "roofline": roof,
+        }
+        out["max_rel_err"] = sampled_error(A, B, Cfull, n)
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline_port(N, args.fast)
+            out["host_blas_dgemm"] = host_blas(n)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

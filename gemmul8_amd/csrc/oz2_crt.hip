@@ -1,0 +1,205 @@
+// CRT accumulation + inverse scaling + axpby (HBM-bound: N int8 planes in, one FP matrix out).
+//
+// Replaces GEMMul8/src/inverse_scaling_real.hpp:8-278 and inverse_scaling_complex.hpp:8-326:
+//   S  = sum_{t=0}^{N-1} fma(qPi_t, double(C_mid[t]), S)            fixed order t = 0..N-1
+//   TP = double  (float outputs, or N <= 6 [INT8] / 5 [FP8]):  R = fma(Pneg, rint(invP*S), S)
+//   TP = double2 (otherwise): hi sum error-free, lo sum rounded;
+//        R = fma(Pneg_lo, q, fma(Pneg_hi, q, Sh) + Sl),  q = rint(invP*Sh)
+//   AB = scalbn((T)R, sftA[i] + sftB[j])   (shift arrays hold the NEGATED exponents)
+//   C  = AB | C+AB | -AB | C-AB  for host scalars alpha=+-1, beta in {0,1};
+//        otherwise fma(beta, C, alpha*AB) (complex: nested fma order of template_math.hpp:61-75);
+//   device-pointer scalars always take the general form (inverse_scaling_real.hpp:211-216).
+// Each thread handles 4 consecutive rows of one column: one dword load per residue plane.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "oz2_kernels.h"
+
+namespace oz2 {
+
+struct CrtArgs {
+    const void* Cmid;
+    size_t ld_mid;        // elements (int8 or char2 or int16...) between columns
+    size_t plane_stride;  // elements between residue planes
+    size_t m, n;
+    const int16_t* sftA;
+    const int16_t* sftB;
+    void* C;
+    size_t ldc;
+    unsigned N;
+    int use_dd;
+    int mode;  // 0 general(host scalars) 1: C=AB 2: C+=AB 3: C=-AB 4: C-=AB 5: general(device scalars)
+    double alpha[2], beta[2];
+    const void* alpha_dev;
+    const void* beta_dev;
+    double Phi, Plo, invP;
+    double q1[20], qh[20], ql[20];
+};
+
+template <typename U> __device__ __forceinline__ U scalb(U x, int s);
+template <> __device__ __forceinline__ float scalb<float>(float x, int s) { return scalbnf(x, s); }
+template <> __device__ __forceinline__ double scalb<double>(double x, int s) { return scalbn(x, s); }
+template <typename U> __device__ __forceinline__ U fmaU(U a, U b, U c);
+template <> __device__ __forceinline__ float fmaU<float>(float a, float b, float c) { return fmaf(a, b, c); }
+template <> __device__ __forceinline__ double fmaU<double>(double a, double b, double c) { return fma(a, b, c); }
+
+__device__ __forceinline__ double crt_reduce(const CrtArgs& a, double Sh, double Sl) {
+    const double q = rint(a.invP * Sh);
+    if (!a.use_dd) return fma(a.Phi, q, Sh);
+    return fma(a.Plo, q, fma(a.Phi, q, Sh) + Sl);
+}
+
+// U = float|double ; CPLX ; MID = int8_t|int16_t
+template <typename U, bool CPLX, typename MID>
+__global__ void __launch_bounds__(256) crt_kernel(const CrtArgs a) {
+    constexpr int COMPS = CPLX ? 2 : 1;
+    const size_t row_groups = (a.m + 3) / 4;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= row_groups * a.n) return;
+    const size_t col = gid / row_groups;
+    const size_t i0 = (gid - col * row_groups) * 4;
+
+    double Sh[4 * COMPS], Sl[4 * COMPS];
+#pragma unroll
+    for (int e = 0; e < 4 * COMPS; ++e) Sh[e] = 0.0, Sl[e] = 0.0;
+
+    const MID* base = (const MID*)a.Cmid + (col * a.ld_mid + i0) * COMPS;
+    for (unsigned t = 0; t < a.N; ++t) {
+        MID c[4 * COMPS];
+        // 4 consecutive rows: one 4*COMPS*sizeof(MID)-byte vector load (planes are padded to 256 rows)
+        __builtin_memcpy(c, base + (size_t)t * a.plane_stride * COMPS, sizeof(c));
+        if (a.use_dd) {
+            const double qh = a.qh[t], ql = a.ql[t];
+#pragma unroll
+            for (int e = 0; e < 4 * COMPS; ++e) {
+                const double cd = (double)c[e];
+                Sh[e] = fma(qh, cd, Sh[e]);
+                Sl[e] = fma(ql, cd, Sl[e]);
+            }
+        } else {
+            const double q1 = a.q1[t];
+#pragma unroll
+            for (int e = 0; e < 4 * COMPS; ++e) Sh[e] = fma(q1, (double)c[e], Sh[e]);
+        }
+    }
+
+    U al[2] = {(U)a.alpha[0], (U)a.alpha[1]}, be[2] = {(U)a.beta[0], (U)a.beta[1]};
+    int mode = a.mode;
+    if (mode == 5) {
+        al[0] = ((const U*)a.alpha_dev)[0];
+        be[0] = ((const U*)a.beta_dev)[0];
+        if (CPLX) {
+            al[1] = ((const U*)a.alpha_dev)[1];
+            be[1] = ((const U*)a.beta_dev)[1];
+        }
+        mode = 0;
+    }
+    const int sB = (int)a.sftB[col];
+    U* Cc = (U*)a.C + (col * a.ldc) * COMPS;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const size_t row = i0 + e;
+        if (row >= a.m) break;
+        const int sft = (int)a.sftA[row] + sB;
+        U* cp = Cc + row * COMPS;
+        if constexpr (!CPLX) {
+            const U AB = scalb<U>((U)crt_reduce(a, Sh[e], Sl[e]), sft);
+            switch (mode) {
+            case 1: cp[0] = AB; break;
+            case 2: cp[0] = cp[0] + AB; break;
+            case 3: cp[0] = -AB; break;
+            case 4: cp[0] = cp[0] - AB; break;
+            default: cp[0] = fmaU<U>(be[0], cp[0], al[0] * AB); break;
+            }
+        } else {
+            const U x = scalb<U>((U)crt_reduce(a, Sh[2 * e], Sl[2 * e]), sft);
+            const U y = scalb<U>((U)crt_reduce(a, Sh[2 * e + 1], Sl[2 * e + 1]), sft);
+            switch (mode) {
+            case 1: cp[0] = x, cp[1] = y; break;
+            case 2: cp[0] = cp[0] + x, cp[1] = cp[1] + y; break;
+            case 3: cp[0] = -x, cp[1] = -y; break;
+            case 4: cp[0] = cp[0] - x, cp[1] = cp[1] - y; break;
+            default: {
+                const U cx = cp[0], cy = cp[1];
+                cp[0] = fmaU<U>(-be[1], cy, fmaU<U>(be[0], cx, fmaU<U>(-al[1], y, al[0] * x)));
+                cp[1] = fmaU<U>(be[1], cx, fmaU<U>(be[0], cy, fmaU<U>(al[1], x, al[0] * y)));
+            } break;
+            }
+        }
+    }
+}
+
+hipError_t launch_crt(hipStream_t stream, int dtype, int backend, unsigned N, size_t m, size_t n, const void* Cmid, size_t ld_mid,
+                      size_t plane_stride, const int16_t* sftA, const int16_t* sftB, const void* alpha, const void* beta,
+                      bool scalars_on_device, void* C, size_t ldc) {
+    if (m == 0 || n == 0) return hipSuccess;
+    CrtArgs a{};
+    a.Cmid = Cmid;
+    a.ld_mid = ld_mid;
+    a.plane_stride = plane_stride;
+    a.m = m;
+    a.n = n;
+    a.sftA = sftA;
+    a.sftB = sftB;
+    a.C = C;
+    a.ldc = ldc;
+    a.N = N;
+    const bool f32 = is_f32(dtype), cplx = is_complex(dtype);
+    const int pdbl = backend == kINT8 ? 6 : 5;
+    a.use_dd = !(f32 || (int)N <= pdbl);
+    const bool i8 = backend == kINT8;
+    a.Phi = (i8 ? GEMMUL8_PNEG_HI_INT8 : GEMMUL8_PNEG_HI_FP8)[N - 2];
+    a.Plo = (i8 ? GEMMUL8_PNEG_LO_INT8 : GEMMUL8_PNEG_LO_FP8)[N - 2];
+    a.invP = (i8 ? GEMMUL8_INVP_INT8 : GEMMUL8_INVP_FP8)[N - 2];
+    for (unsigned t = 0; t < N; ++t) {
+        a.q1[t] = (i8 ? GEMMUL8_QPI1_INT8 : GEMMUL8_QPI1_FP8)[N - 2][t];
+        a.qh[t] = (i8 ? GEMMUL8_QPI2_HI_INT8 : GEMMUL8_QPI2_HI_FP8)[N - 2][t];
+        a.ql[t] = (i8 ? GEMMUL8_QPI2_LO_INT8 : GEMMUL8_QPI2_LO_FP8)[N - 2][t];
+    }
+    if (scalars_on_device) {
+        a.mode = 5;
+        a.alpha_dev = alpha;
+        a.beta_dev = beta;
+    } else {
+        double ar, ai = 0, br, bi = 0;
+        if (f32) {
+            ar = ((const float*)alpha)[0];
+            br = ((const float*)beta)[0];
+            if (cplx) ai = ((const float*)alpha)[1], bi = ((const float*)beta)[1];
+        } else {
+            ar = ((const double*)alpha)[0];
+            br = ((const double*)beta)[0];
+            if (cplx) ai = ((const double*)alpha)[1], bi = ((const double*)beta)[1];
+        }
+        a.alpha[0] = ar, a.alpha[1] = ai, a.beta[0] = br, a.beta[1] = bi;
+        a.mode = 0;
+        if (ai == 0 && bi == 0) {
+            if (ar == 1 && br == 0) a.mode = 1;
+            else if (ar == 1 && br == 1) a.mode = 2;
+            else if (ar == -1 && br == 0) a.mode = 3;
+            else if (ar == -1 && br == 1) a.mode = 4;
+        }
+    }
+    const size_t threads = ((m + 3) / 4) * n;
+    dim3 grid((unsigned)((threads + 255) / 256));
+#define OZ2_CRT(U, CP, MID) hipLaunchKernelGGL((crt_kernel<U, CP, MID>), grid, dim3(256), 0, stream, a)
+    if (i8) {
+        switch (dtype) {
+        case kF32: OZ2_CRT(float, false, int8_t); break;
+        case kF64: OZ2_CRT(double, false, int8_t); break;
+        case kC32: OZ2_CRT(float, true, int8_t); break;
+        case kC64: OZ2_CRT(double, true, int8_t); break;
+        }
+    } else {
+        switch (dtype) {
+        case kF32: OZ2_CRT(float, false, int16_t); break;
+        case kF64: OZ2_CRT(double, false, int16_t); break;
+        case kC32: OZ2_CRT(float, true, int16_t); break;
+        case kC64: OZ2_CRT(double, true, int16_t); break;
+        }
+    }
+#undef OZ2_CRT
+    return hipGetLastError();
+}
+
+}  // namespace oz2

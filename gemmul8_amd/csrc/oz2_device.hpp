@@ -1,0 +1,118 @@
+// Device-side helpers shared by the HIP kernels of the Ozaki-II emulation (gfx950 only).
+//
+// What the reference does with compile-time unrolled templates over num_moduli
+// (GEMMul8/src/mod.hpp:638-877, scaling.hpp:237-280) is done here with ONE exact integer
+// representation of trunc(x*2^s) = +-M*2^E (M < 2^53, E >= 0) and a limb-wise residue that runs at
+// full VALU rate (24-bit multiplies + an fp32 reciprocal); num_moduli stays a run-time loop bound.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tables.inc"
+
+namespace oz2 {
+
+constexpr int kINT8 = 0;
+constexpr int kFP8 = 1;
+
+// per-modulus constants for the limb-wise residue (built on the host, passed by value in kernargs)
+struct ModConst {
+    int p;        // modulus
+    int c18;      // sym(2^18 mod p)
+    int c36;      // sym(2^36 mod p)
+    float invp;   // RN(1/p)
+};
+struct ModTable {
+    ModConst mc[20];
+};
+
+__device__ __forceinline__ int ilogb0(double x) { return x == 0.0 ? 0 : ilogb(x); }
+__device__ __forceinline__ int ilogb0(float x) { return x == 0.0f ? 0 : ilogbf(x); }
+
+// exact trunc(|x| * 2^sft) = M * 2^E  (restates scaling.hpp:99-235 as one representation)
+struct ScaledInt {
+    uint64_t M;
+    int E;
+    bool neg;
+};
+__device__ __forceinline__ ScaledInt trunc_scale(double x, int sft) {
+    const uint64_t bits = (uint64_t)__double_as_longlong(x);
+    ScaledInt r;
+    r.neg = (bits >> 63) != 0;
+    int e = (int)((bits >> 52) & 0x7FF);
+    uint64_t mant = bits & 0xFFFFFFFFFFFFFull;
+    if (e) mant |= (1ull << 52);
+    else e = 1;
+    const int x2 = e - 1075 + sft;  // value = mant * 2^x2
+    if (x2 >= 0) {
+        r.M = mant;
+        r.E = x2;
+    } else {
+        r.M = (-x2 >= 64) ? 0ull : (mant >> (-x2));
+        r.E = 0;
+    }
+    if (r.M == 0) r.neg = false, r.E = 0;
+    return r;
+}
+
+// ceil(|x| * 2^sft) as int8: exact ceiling, tiny non-zero -> 1 (scaling.hpp:3-46)
+__device__ __forceinline__ int upper_bound_i8(double x, int sft) {
+    const uint64_t bits = ((uint64_t)__double_as_longlong(x)) & ~(1ull << 63);
+    if (bits == 0) return 0;
+    int e = (int)(bits >> 52);
+    uint64_t mant = bits & 0xFFFFFFFFFFFFFull;
+    if (e) mant |= (1ull << 52);
+    else e = 1;
+    const int x2 = e - 1075 + sft;
+    if (x2 >= 0) return (int)(int8_t)(mant << (x2 > 63 ? 63 : x2));
+    if (-x2 >= 64) return 1;
+    const uint64_t fl = mant >> (-x2);
+    const uint64_t has = (mant & ((1ull << (-x2)) - 1)) != 0;
+    return (int)(int8_t)(fl + has);
+}
+
+// three 18-bit limbs of M (< 2^54)
+struct Limbs {
+    int l0, l1, l2;
+};
+__device__ __forceinline__ Limbs make_limbs(uint64_t M) {
+    Limbs L;
+    L.l0 = (int)(M & 0x3FFFF);
+    L.l1 = (int)((M >> 18) & 0x3FFFF);
+    L.l2 = (int)(M >> 36);
+    return L;
+}
+
+// s mod p for |s| < 2^29, result in [0, p)
+__device__ __forceinline__ int mod_small_pos(int s, int p, float invp) {
+    const float q = rintf((float)s * invp);
+    int r = s - __mul24((int)q, p);  // |r| <= 0.6 p
+    if (r < 0) r += p;
+    if (r >= p) r -= p;
+    return r;
+}
+
+// symmetric residue of +-M*2^E in (-p/2, p/2]; pow2row = GEMMUL8_POW2MOD[t] (only read when E > 0)
+__device__ __forceinline__ int residue_sym(const Limbs& L, int E, bool neg, const ModConst& mc, const short* pow2row) {
+    int s = L.l0 + __mul24(L.l1, mc.c18) + __mul24(L.l2, mc.c36);
+    int r = mod_small_pos(s, mc.p, mc.invp);
+    if (E > 0) r = mod_small_pos(__mul24(r, (int)pow2row[E < 63 ? E : 63]), mc.p, mc.invp);
+    if (neg && r != 0) r = mc.p - r;
+    if (r > (mc.p >> 1)) r -= mc.p;
+    return r;
+}
+
+// wrapping (mod.hpp:8-12)
+__device__ __forceinline__ int wrapping(int a, int p) {
+    const int h = p >> 1;
+    return (a > h) ? a - p : ((a < -h) ? a + p : a);
+}
+
+// symmetric residue of an int32 accumulator: the reference's mod_small (mod.hpp:15-21,58-60);
+// result in [-p/2, p/2] with the same representative (checked exhaustively in tests)
+__device__ __forceinline__ int mod_i32_sym(int a, int p, int pinv32) {
+    const int rem = a - p * __mulhi(a, pinv32);
+    return wrapping(rem, p);
+}
+
+}  // namespace oz2

@@ -1,0 +1,244 @@
+// Host orchestration + C ABI (include/gemmul8_c.h).
+//
+// Restates the reference's pipeline drivers (GEMMul8/src/gemmul8_real.hpp:8-211,
+// src/gemmul8_complex.hpp:8-226): workspace carving, phase order, skip-scaling semantics -- with
+// three differences that are the point of the MI355X build:
+//   * the low-precision GEMMs are our own MFMA kernels with the requantise / bound-max epilogues
+//     fused (no C_hi round trip, no vendor BLAS, no 32 MiB BLAS workspace use);
+//   * all moduli of a call go out in ONE batched launch;
+//   * no host synchronisation unless the caller asks for the 4 phase timers.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "../../include/gemmul8_c.h"
+#include "oz2_kernels.h"
+
+using namespace oz2;
+
+namespace {
+
+inline char* align256(void* p) {
+    uintptr_t x = reinterpret_cast<uintptr_t>(p);
+    x = (x + 255) & ~uintptr_t(255);
+    return reinterpret_cast<char*>(x);
+}
+inline int norm_op(int op) {
+    if (op >= 111 && op <= 113) return op - 111;  // hipblasOperation_t
+    return op;
+}
+inline size_t low_size(int) { return 1; }
+inline size_t mid_size(int backend, bool cplx) { return (backend == kINT8 ? 1 : 2) * (cplx ? 2 : 1); }
+
+#define OZ2_HIP(expr)                       \
+    do {                                    \
+        hipError_t e__ = (expr);            \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
+struct Timer {
+    hipEvent_t ev[5];
+    bool ok = false;
+    Timer() {
+        ok = true;
+        for (auto& e : ev)
+            if (hipEventCreate(&e) != hipSuccess) ok = false;
+    }
+};
+Timer& thread_timer() {
+    static thread_local Timer t;
+    return t;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gemmul8_version(void) { return "gemmul8-mi355x 0.1 (gfx950; INT8 MFMA_I32_32x32x32_I8, fused epilogues)"; }
+
+size_t gemmul8_work_size(int is_complex, int backend, size_t m, size_t n, size_t k, unsigned N, int enA, int enB, size_t* wA,
+                         size_t* wB) {
+    const size_t kp = padding256(k), mp = padding256(m);
+    const size_t sizeA = kp * mp, sizeB = kp * n, sizeC = mp * n;
+    const size_t nm = num_mat(backend, N);
+    const size_t parts = is_complex ? 3 : 1;
+    const size_t midsz = mid_size(backend, is_complex != 0);
+    const size_t nhi = (backend == kINT8 ? 1 : 3) * parts;
+    const size_t lwork = size_t(1) << 25;
+    size_t tA = 255, tB = 255, tC = 255;
+    tA += sizeA * (nm + (enA ? 1 : 0)) * parts + 2 * mp;
+    tB += sizeB * (nm + (enB ? 1 : 0)) * parts + 2 * padding256(n);
+    tC += midsz * sizeC * (N - 1) + std::max(lwork, midsz * sizeC);
+    tC += 4 * sizeC * nhi;
+    if (wA) *wA = tA;
+    if (wB) *wB = tB;
+    return tA + tB + tC;
+}
+
+int gemmul8_get_layout(int dtype, int backend, size_t m, size_t n, size_t k, unsigned N, void* work, void* workA, void* workB,
+                       int enA, int enB, gemmul8_layout* L) {
+    if (!L || !work) return GEMMUL8_E_ARG;
+    if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
+    const bool cplx = is_complex(dtype);
+    memset(L, 0, sizeof(*L));
+    L->kp = padding256(k);
+    L->mp = padding256(m);
+    L->num_mat = num_mat(backend, N);
+    L->parts = cplx ? 3 : 1;
+    L->sizeA = L->kp * L->mp;
+    L->sizeB = L->kp * n;
+    L->sizeC = L->mp * n;
+    const size_t offsetA = L->sizeA * L->num_mat, offsetB = L->sizeB * L->num_mat;
+    const size_t size_vecA = L->mp, size_vecB = padding256(n);
+    char* w = align256(work);
+    char* wa = workA ? align256(workA) : nullptr;
+    char* wb = workB ? align256(workB) : nullptr;
+    char* A_lo = wa ? wa : w;
+    char* sftA = A_lo + L->parts * offsetA + (enA ? L->parts * L->sizeA : 0);
+    char* B_lo = wb ? wb : (wa ? w : sftA + 2 * size_vecA);
+    char* sftB = B_lo + L->parts * offsetB + (enB ? L->parts * L->sizeB : 0);
+    char* C_mid = wb ? (wa ? w : sftA + 2 * size_vecA) : sftB + 2 * size_vecB;
+    const size_t midsz = mid_size(backend, cplx);
+    char* work_native = C_mid + (N - 1) * L->sizeC * midsz;
+    const size_t native_sz = std::max(size_t(1) << 25, midsz * L->sizeC);
+    char* C_hi = work_native + native_sz;
+    const size_t hi_bytes = 4 * L->sizeC * (backend == kINT8 ? 1 : 3) * L->parts;
+    L->A_lo = A_lo;
+    L->B_lo = B_lo;
+    L->part_strideA = offsetA;
+    L->part_strideB = offsetB;
+    L->A_bound = enA ? A_lo + L->parts * offsetA : A_lo;
+    L->B_bound = enB ? B_lo + L->parts * offsetB : B_lo;
+    L->sftA = reinterpret_cast<int16_t*>(sftA);
+    L->sftB = reinterpret_cast<int16_t*>(sftB);
+    L->C_mid = C_mid;
+    // scratch: the larger of the C_hi region and the unused tail of the 32 MiB BLAS-workspace block
+    const size_t tail = native_sz - midsz * L->sizeC;
+    if (hi_bytes >= tail) {
+        L->scratch = C_hi;
+        L->scratch_bytes = hi_bytes;
+    } else {
+        L->scratch = work_native + midsz * L->sizeC;
+        L->scratch_bytes = tail;
+    }
+    return GEMMUL8_OK;
+}
+
+int gemmul8_scale(void* stream_, int dtype, int backend, int op_A, int op_B, size_t m, size_t n, size_t k, const void* A, size_t lda,
+                  const void* B, size_t ldb, unsigned N, int fastmode, unsigned t_begin, unsigned t_end, const gemmul8_layout* L,
+                  int skipA, int skipB) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!L || !A || !B) return GEMMUL8_E_ARG;
+    if (N < 2 || N > 20 || t_end > N || t_begin > t_end) return GEMMUL8_E_NUM_MODULI;
+    if (backend != kINT8) return GEMMUL8_E_UNSUPPORTED;
+    if (is_complex(dtype)) return GEMMUL8_E_UNSUPPORTED;
+    op_A = norm_op(op_A);
+    op_B = norm_op(op_B);
+    if (op_A < 0 || op_A > 2 || op_B < 0 || op_B > 2) return GEMMUL8_E_ARG;
+    if (skipA && skipB) return GEMMUL8_OK;
+    const bool cplx = is_complex(dtype);
+    const bool kmajA = op_A != 0, kmajB = op_B == 0;
+    const bool conjA = cplx && op_A == 2, conjB = cplx && op_B == 2;
+    int8_t* A_lo = (int8_t*)L->A_lo;
+    int8_t* B_lo = (int8_t*)L->B_lo;
+
+    if (fastmode) {
+        if (!skipA) OZ2_HIP(launch_fast_shift(stream, dtype, backend, N, kmajA, m, k, A, lda, L->sftA));
+        if (!skipB) OZ2_HIP(launch_fast_shift(stream, dtype, backend, N, kmajB, n, k, B, ldb, L->sftB));
+    } else {
+        // scratch: rowmax int32[mp] | colmax int32[pad(n)] | amax bits
+        const size_t np = padding256(n);
+        const size_t need = 4 * L->mp + 4 * np + 8 * std::max(L->mp, np);
+        if (L->scratch_bytes < need) return GEMMUL8_E_ARG;
+        int* rowmax = (int*)L->scratch;
+        int* colmax = rowmax + L->mp;
+        void* amax = (void*)(colmax + np);
+        const size_t bstrideA = cplx ? L->sizeA : 0, bstrideB = cplx ? L->sizeB : 0;
+        if (!skipA) OZ2_HIP(launch_extract(stream, dtype, backend, kmajA, conjA, m, k, A, lda, (int8_t*)L->A_bound, bstrideA, L->kp, L->sftA, amax));
+        if (!skipB) OZ2_HIP(launch_extract(stream, dtype, backend, kmajB, conjB, n, k, B, ldb, (int8_t*)L->B_bound, bstrideB, L->kp, L->sftB, amax));
+        OZ2_HIP(hipMemsetAsync(rowmax, 0, 4 * (L->mp + np), stream));
+        OZ2_HIP(launch_gemm_i8_max(stream, (const int8_t*)L->A_bound, (const int8_t*)L->B_bound, L->kp, m, n, rowmax, colmax));
+        if (!skipA) OZ2_HIP(launch_shift_finalize(stream, backend, N, m, rowmax, L->sftA));
+        if (!skipB) OZ2_HIP(launch_shift_finalize(stream, backend, N, n, colmax, L->sftB));
+    }
+    if (!skipA)
+        OZ2_HIP(launch_quantise(stream, dtype, backend, N, (int)t_begin, (int)t_end, kmajA, conjA, m, k, A, lda, L->sftA, A_lo, L->sizeA,
+                                L->part_strideA, L->kp));
+    if (!skipB)
+        OZ2_HIP(launch_quantise(stream, dtype, backend, N, (int)t_begin, (int)t_end, kmajB, conjB, n, k, B, ldb, L->sftB, B_lo, L->sizeB,
+                                L->part_strideB, L->kp));
+    return GEMMUL8_OK;
+}
+
+int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t n, size_t k, unsigned N, unsigned t_begin,
+                         unsigned t_end, const gemmul8_layout* L) {
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)k;
+    if (!L) return GEMMUL8_E_ARG;
+    if (N < 2 || N > 20 || t_end > N || t_begin > t_end) return GEMMUL8_E_NUM_MODULI;
+    if (backend != kINT8 || is_complex(dtype)) return GEMMUL8_E_UNSUPPORTED;
+    OZ2_HIP(launch_gemm_i8_mod(stream, (const int8_t*)L->A_lo, (const int8_t*)L->B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)t_begin,
+                               (int)t_end, (int8_t*)L->C_mid, L->mp, L->sizeC));
+    return GEMMUL8_OK;
+}
+
+int gemmul8_crt(void* stream_, int dtype, int backend, unsigned N, size_t m, size_t n, const void* C_mid, size_t ld_mid,
+                size_t plane_stride, const int16_t* sftA, const int16_t* sftB, const void* alpha, const void* beta, void* C, size_t ldc) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!C_mid || !sftA || !sftB || !alpha || !beta || !C) return GEMMUL8_E_ARG;
+    if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
+    hipPointerAttribute_t attr{};
+    bool on_device = false;
+    if (hipPointerGetAttributes(&attr, alpha) == hipSuccess) {
+        on_device = (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged || attr.type == hipMemoryTypeArray);
+    } else {
+        (void)hipGetLastError();  // unregistered host pointer: clear the sticky error
+    }
+    OZ2_HIP(launch_crt(stream, dtype, backend, N, m, n, C_mid, ld_mid, plane_stride, sftA, sftB, alpha, beta, on_device, C, ldc));
+    return GEMMUL8_OK;
+}
+
+int gemmul8_gemm(void* stream_, int dtype, int backend, int op_A, int op_B, size_t m, size_t n, size_t k, const void* alpha,
+                 const void* A, size_t lda, const void* B, size_t ldb, const void* beta, void* C, size_t ldc, unsigned N, int fastmode,
+                 void* work, void* workA, void* workB, int enA, int enB, int skip_scalA, int skip_scalB, double* timers_ns) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (timers_ns) timers_ns[0] = timers_ns[1] = timers_ns[2] = timers_ns[3] = 0.0;
+    if (dtype < 0 || dtype > 3 || backend < 0 || backend > 1) return GEMMUL8_E_ARG;
+    if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
+    if (!alpha || !beta || !A || !B || !C || !work) return GEMMUL8_E_ARG;
+    if (k > (size_t(1) << 17)) return GEMMUL8_E_ARG;
+    if (m == 0 || n == 0) return GEMMUL8_OK;
+    gemmul8_layout L;
+    int rc = gemmul8_get_layout(dtype, backend, m, n, k, N, work, workA, workB, enA, enB, &L);
+    if (rc) return rc;
+    const bool skipA = skip_scalA && enA, skipB = skip_scalB && enB;
+    Timer* T = timers_ns ? &thread_timer() : nullptr;
+    if (T && !T->ok) T = nullptr;
+    if (T) OZ2_HIP(hipEventRecord(T->ev[0], stream));
+    rc = gemmul8_scale(stream, dtype, backend, op_A, op_B, m, n, k, A, lda, B, ldb, N, fastmode, 0, N, &L, skipA, skipB);
+    if (rc) return rc;
+    if (T) OZ2_HIP(hipEventRecord(T->ev[1], stream));
+    rc = gemmul8_lowprec_gemm(stream, dtype, backend, m, n, k, N, 0, N, &L);
+    if (rc) return rc;
+    if (T) OZ2_HIP(hipEventRecord(T->ev[2], stream));
+    rc = gemmul8_crt(stream, dtype, backend, N, m, n, L.C_mid, L.mp, L.sizeC, L.sftA, L.sftB, alpha, beta, C, ldc);
+    if (rc) return rc;
+    if (T) {
+        OZ2_HIP(hipEventRecord(T->ev[3], stream));
+        OZ2_HIP(hipEventSynchronize(T->ev[3]));
+        float ms;
+        OZ2_HIP(hipEventElapsedTime(&ms, T->ev[0], T->ev[1]));
+        timers_ns[0] = ms * 1e6;
+        OZ2_HIP(hipEventElapsedTime(&ms, T->ev[1], T->ev[2]));
+        timers_ns[1] = ms * 1e6;
+        timers_ns[2] = 0.0;
+        OZ2_HIP(hipEventElapsedTime(&ms, T->ev[2], T->ev[3]));
+        timers_ns[3] = ms * 1e6;
+    }
+    return GEMMUL8_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+// Internal launcher prototypes (host side) of the HIP kernels.  The public boundary is
+// include/gemmul8_c.h (C ABI) and include/gemmul8.hpp (C++ API); nothing here is exported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "oz2_device.hpp"
+
+namespace oz2 {
+
+enum DType { kF32 = 0, kF64 = 1, kC32 = 2, kC64 = 3 };
+inline bool is_complex(int dt) { return dt >= 2; }
+inline bool is_f32(int dt) { return dt == kF32 || dt == kC32; }
+inline size_t padding256(size_t x) { return (x + 255) / 256 * 256; }
+inline unsigned planes_of(int backend, int t) { return backend == kINT8 ? 1u : (t < 6 ? 2u : 3u); }
+inline unsigned num_mat(int backend, unsigned N) {
+    unsigned s = 0;
+    for (unsigned t = 0; t < N; ++t) s += planes_of(backend, (int)t);
+    return s;
+}
+ModTable make_mod_table(int backend);
+
+// ---- INT8 MFMA GEMM (oz2_gemm_i8.hip)
+hipError_t launch_gemm_i8_mod(hipStream_t stream, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp, size_t m,
+                              size_t n, int t_begin, int t_end, int8_t* Cmid, size_t ldc, size_t strideC);
+hipError_t launch_gemm_i8_max(hipStream_t stream, const int8_t* A, const int8_t* B, size_t kp, size_t m, size_t n, int* rowmax,
+                              int* colmax);
+
+// ---- scale / quantise (oz2_scale.hip).  An operand has `rows` logical rows (m for A, n for B) of
+// length k; K-major: element (r,kk) at X[r*ld+kk]; row-strided: X[kk*ld+r].  lo planes are
+// [rows_pad][kp] int8, zero-filled for kk in [k,kp).
+hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajor, bool conj, size_t rows, size_t k, const void* X,
+                          size_t ld, int8_t* lo, size_t part_stride, size_t kp, int16_t* sft0, void* scratch_amax);
+hipError_t launch_shift_finalize(hipStream_t stream, int backend, unsigned N, size_t rows, const int* maxv, int16_t* sft);
+hipError_t launch_fast_shift(hipStream_t stream, int dtype, int backend, unsigned N, bool kmajor, size_t rows, size_t k, const void* X,
+                             size_t ld, int16_t* sft);
+hipError_t launch_quantise(hipStream_t stream, int dtype, int backend, unsigned N, int t_begin, int t_end, bool kmajor, bool conj,
+                           size_t rows, size_t k, const void* X, size_t ld, const int16_t* sft, int8_t* lo, size_t plane_stride,
+                           size_t part_stride, size_t kp);
+
+// ---- CRT accumulation + inverse scaling (oz2_crt.hip)
+hipError_t launch_crt(hipStream_t stream, int dtype, int backend, unsigned N, size_t m, size_t n, const void* Cmid, size_t ld_mid,
+                      size_t plane_stride, const int16_t* sftA, const int16_t* sftB, const void* alpha, const void* beta,
+                      bool scalars_on_device, void* C, size_t ldc);
+
+}  // namespace oz2

@@ -1,0 +1,528 @@
+// Scale / quantise kernels of the Ozaki-II emulation for gfx950 (HBM-bound byte/integer work).
+//
+// Replaces (paths relative to /root/reference/GEMMul8/src):
+//   extract (accurate mode, 7-bit bounds) scaling_accu_real.hpp:23-136, scaling_accu_complex.hpp:6-126
+//   accurate-mode shift                   scaling_accu_real.hpp:6-18,142-226
+//   fast-mode shift                       scaling_fast_real.hpp:6-49, find_max.hpp:258-341
+//   quantise + all-moduli residues        scaling_fast_real.hpp:54-164, scaling_fast_complex.hpp:9-133,
+//                                         scaling.hpp:99-280, mod.hpp:8-98,194-355,638-877
+//
+// Layout in HBM: plane = [rows padded to 256][kp] bytes, row r contiguous in k, zero-filled for
+// k <= kk < kp.  A row-strided operand (A with op N, B with op T/C: element (r,kk) at X[kk*ld+r]) is
+// read with lanes along r (coalesced), staged RAW through LDS and re-read with lanes along k, so
+// that every store is 256 contiguous bytes per wave; a K-major operand needs no staging.  Each
+// thread owns 4 consecutive k and emits one dword per plane (the reference's char4 granularity),
+// num_moduli is a run-time loop bound (no per-N template instantiation).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "oz2_kernels.h"
+
+namespace oz2 {
+
+ModTable make_mod_table(int backend) {
+    ModTable T;
+    for (int t = 0; t < 20; ++t) {
+        const int p = backend == kINT8 ? GEMMUL8_MODULI_INT8[t] : GEMMUL8_MODULI_FP8[t];
+        auto sym = [p](long long r) {
+            r %= p;
+            if (r < 0) r += p;
+            return (int)(r > p / 2 ? r - p : r);
+        };
+        T.mc[t].p = p;
+        T.mc[t].c18 = sym(1ll << 18);
+        T.mc[t].c36 = sym(1ll << 36);
+        T.mc[t].invp = 1.0f / (float)p;
+    }
+    return T;
+}
+
+__constant__ short c_pow2mod_int8[20][64];
+__constant__ short c_pow2mod_fp8[20][64];
+static hipError_t upload_pow2_once() {
+    static bool done = false;
+    if (done) return hipSuccess;
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_pow2mod_int8), GEMMUL8_POW2MOD_INT8, sizeof(GEMMUL8_POW2MOD_INT8));
+    if (e != hipSuccess) return e;
+    e = hipMemcpyToSymbol(HIP_SYMBOL(c_pow2mod_fp8), GEMMUL8_POW2MOD_FP8, sizeof(GEMMUL8_POW2MOD_FP8));
+    if (e != hipSuccess) return e;
+    done = true;
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------ element traits
+template <typename T> struct ET;
+template <> struct ET<float> {
+    using U = float;
+    static constexpr bool cplx = false;
+    __device__ static double re(float v) { return (double)v; }
+    __device__ static double im(float) { return 0.0; }
+    __device__ static float zero() { return 0.f; }
+};
+template <> struct ET<double> {
+    using U = double;
+    static constexpr bool cplx = false;
+    __device__ static double re(double v) { return v; }
+    __device__ static double im(double) { return 0.0; }
+    __device__ static double zero() { return 0.0; }
+};
+template <> struct ET<float2> {
+    using U = float;
+    static constexpr bool cplx = true;
+    __device__ static double re(float2 v) { return (double)v.x; }
+    __device__ static double im(float2 v) { return (double)v.y; }
+    __device__ static float2 zero() { return make_float2(0.f, 0.f); }
+};
+template <> struct ET<double2> {
+    using U = double;
+    static constexpr bool cplx = true;
+    __device__ static double re(double2 v) { return v.x; }
+    __device__ static double im(double2 v) { return v.y; }
+    __device__ static double2 zero() { return make_double2(0.0, 0.0); }
+};
+
+template <typename U> __device__ __forceinline__ U wave_max(U v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const U o = __shfl_xor(v, off);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------ stage kernel (extract / quantise)
+enum { MODE_BOUND = 0, MODE_MOD = 1 };
+
+struct StageArgs {
+    const void* X;
+    size_t ld;
+    size_t rows, k, kp;
+    int8_t* lo;
+    size_t plane_stride;  // bytes between moduli planes (MODE_MOD)
+    size_t part_stride;   // bytes between Re / Im / Re+Im plane sets
+    const int16_t* sft;   // MODE_MOD: negated final shifts
+    int16_t* sft0;        // MODE_BOUND: written (maxUFP - ilogb(amax))
+    const void* amax;     // MODE_BOUND, strided: per-row amax bit patterns (U-sized unsigned)
+    int backend;
+    int conj;
+    int t_begin, t_end;
+    ModTable mt;
+};
+
+template <typename T, int MODE>
+__device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0, const T (&v)[4], int s) {
+    using E = ET<T>;
+    int8_t* out = a.lo + row * a.kp + k0;
+    if constexpr (MODE == MODE_BOUND) {
+        unsigned wr = 0, wi = 0, wd = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int br = upper_bound_i8(E::re(v[e]), s);
+            wr |= ((unsigned)br & 0xFFu) << (8 * e);
+            if constexpr (E::cplx) {
+                const int bi = upper_bound_i8(E::im(v[e]), s);
+                wi |= ((unsigned)bi & 0xFFu) << (8 * e);
+                wd |= ((unsigned)(br - bi) & 0xFFu) << (8 * e);
+            }
+        }
+        *(unsigned*)out = wr;
+        if constexpr (E::cplx) {
+            *(unsigned*)(out + a.part_stride) = wi;
+            *(unsigned*)(out + 2 * a.part_stride) = wd;
+        }
+    } else {
+        Limbs Lr[4], Li[4];
+        int Er[4], Ei[4];
+        bool nr[4], ni[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const ScaledInt x = trunc_scale(E::re(v[e]), s);
+            Lr[e] = make_limbs(x.M);
+            Er[e] = x.E;
+            nr[e] = x.neg;
+            if constexpr (E::cplx) {
+                const ScaledInt y = trunc_scale(E::im(v[e]), s);
+                Li[e] = make_limbs(y.M);
+                Ei[e] = y.E;
+                ni[e] = a.conj ? !y.neg : y.neg;
+            }
+        }
+        const short(*pow2)[64] = a.backend == kINT8 ? c_pow2mod_int8 : c_pow2mod_fp8;
+        for (int t = a.t_begin; t < a.t_end; ++t) {
+            const ModConst mc = a.mt.mc[t];
+            unsigned wr = 0, wi = 0, ws = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int rr = residue_sym(Lr[e], Er[e], nr[e], mc, pow2[t]);
+                wr |= ((unsigned)rr & 0xFFu) << (8 * e);
+                if constexpr (E::cplx) {
+                    const int ri = residue_sym(Li[e], Ei[e], ni[e], mc, pow2[t]);
+                    wi |= ((unsigned)ri & 0xFFu) << (8 * e);
+                    // third plane from the int8-cast residues (mod.hpp:321-325)
+                    const int rs = wrapping((int)(int8_t)rr + (int)(int8_t)ri, mc.p);
+                    ws |= ((unsigned)rs & 0xFFu) << (8 * e);
+                }
+            }
+            int8_t* o = out + (size_t)t * a.plane_stride;
+            *(unsigned*)o = wr;
+            if constexpr (E::cplx) {
+                *(unsigned*)(o + a.part_stride) = wi;
+                *(unsigned*)(o + 2 * a.part_stride) = ws;
+            }
+        }
+    }
+}
+
+// K-major operand: one 256-thread block per row; thread = 4 consecutive k per 1024-wide sweep
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) stage_kmajor_kernel(const StageArgs a) {
+    using E = ET<T>;
+    using U = typename E::U;
+    const size_t row = blockIdx.x;
+    const T* x = (const T*)a.X + row * a.ld;
+    int s;
+    if constexpr (MODE == MODE_BOUND) {
+        __shared__ U sm[4];
+        U am = 0;
+        for (size_t kk = threadIdx.x; kk < a.k; kk += 256) {
+            const T v = x[kk];
+            const U ar = (U)fabs(E::re(v)), ai = (U)fabs(E::im(v));
+            am = ar > am ? ar : am;
+            am = ai > am ? ai : am;
+        }
+        am = wave_max(am);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = am;
+        __syncthreads();
+        am = sm[0];
+        am = sm[1] > am ? sm[1] : am;
+        am = sm[2] > am ? sm[2] : am;
+        am = sm[3] > am ? sm[3] : am;
+        s = (a.backend == kINT8 ? 5 : 7) - ilogb0(am);
+        if (threadIdx.x == 0) a.sft0[row] = (int16_t)s;
+    } else {
+        s = -(int)a.sft[row];
+    }
+    for (size_t k0 = (size_t)threadIdx.x * 4; k0 < a.kp; k0 += 1024) {
+        T v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (k0 + e < a.k) ? x[k0 + e] : E::zero();
+        emit4<T, MODE>(a, row, k0, v, s);
+    }
+}
+
+// Row-strided operand: grid (ceil(kp/TK), ceil(rows/32)), 256 threads; tile 32 rows x TK k staged RAW in LDS
+template <typename T> struct StageTile {
+    static constexpr int TR = 32;
+    static constexpr int TK = sizeof(T) == 16 ? 64 : 128;
+};
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) stage_strided_kernel(const StageArgs a) {
+    using E = ET<T>;
+    using U = typename E::U;
+    constexpr int TR = StageTile<T>::TR, TK = StageTile<T>::TK;
+    constexpr int PITCH = TK + (sizeof(T) >= 16 ? 1 : 16 / sizeof(T));  // rows stay 16-B aligned
+    constexpr int CH = TK / 4;                                          // 4-wide k chunks per row
+    constexpr int RPP = 256 / CH;                                       // rows per pass
+    __shared__ __attribute__((aligned(16))) T tile[TR][PITCH];
+    const size_t r0 = (size_t)blockIdx.y * TR;
+    const size_t kb = (size_t)blockIdx.x * TK;
+    {
+        const int rx = threadIdx.x & 31, ky = threadIdx.x >> 5;
+        const size_t row = r0 + rx;
+        const T* x = (const T*)a.X + row;
+#pragma unroll 4
+        for (int it = 0; it < TK / 8; ++it) {
+            const int kk = ky + 8 * it;
+            const size_t kg = kb + kk;
+            tile[rx][kk] = (row < a.rows && kg < a.k) ? x[kg * a.ld] : E::zero();
+        }
+    }
+    __syncthreads();
+    const int c = threadIdx.x % CH;
+#pragma unroll 1
+    for (int pass = 0; pass < TR / RPP; ++pass) {
+        const int rl = pass * RPP + threadIdx.x / CH;
+        const size_t row = r0 + rl;
+        if (row >= a.rows) continue;
+        int s;
+        if constexpr (MODE == MODE_BOUND) {
+            using UB = typename std::conditional<sizeof(U) == 8, unsigned long long, unsigned>::type;
+            const UB bits = ((const UB*)a.amax)[row];
+            U am;
+            __builtin_memcpy(&am, &bits, sizeof(U));
+            s = (a.backend == kINT8 ? 5 : 7) - ilogb0(am);
+            if (blockIdx.x == 0 && c == 0) a.sft0[row] = (int16_t)s;
+        } else {
+            s = -(int)a.sft[row];
+        }
+        T v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tile[rl][c * 4 + e];
+        emit4<T, MODE>(a, row, kb + c * 4, v, s);
+    }
+}
+
+// per-row amax of a row-strided operand: grid (ceil(rows/64), ksplit), 256 threads = 64 rows x 4 k-lanes
+template <typename T> __global__ void __launch_bounds__(256) amax_strided_kernel(const T* X, size_t ld, size_t rows, size_t k, void* amax) {
+    using E = ET<T>;
+    using U = typename E::U;
+    using UB = typename std::conditional<sizeof(U) == 8, unsigned long long, unsigned>::type;
+    __shared__ U sm[4][64];
+    const int rx = threadIdx.x & 63, ky = threadIdx.x >> 6;
+    const size_t row = (size_t)blockIdx.x * 64 + rx;
+    const size_t kper = (k + gridDim.y - 1) / gridDim.y;
+    const size_t kbeg = (size_t)blockIdx.y * kper, kend = (kbeg + kper < k) ? kbeg + kper : k;
+    U am = 0;
+    if (row < rows) {
+        const T* x = X + row;
+        for (size_t kk = kbeg + ky; kk < kend; kk += 4) {
+            const T v = x[kk * ld];
+            const U ar = (U)fabs(E::re(v)), ai = (U)fabs(E::im(v));
+            am = ar > am ? ar : am;
+            am = ai > am ? ai : am;
+        }
+    }
+    sm[ky][rx] = am;
+    __syncthreads();
+    if (ky == 0 && row < rows) {
+        am = sm[1][rx] > am ? sm[1][rx] : am;
+        am = sm[2][rx] > am ? sm[2][rx] : am;
+        am = sm[3][rx] > am ? sm[3][rx] : am;
+        UB bits;
+        __builtin_memcpy(&bits, &am, sizeof(U));
+        if (bits) atomicMax((UB*)amax + row, bits);  // non-negative IEEE values order like unsigned integers
+    }
+}
+
+template <typename T, int MODE> static hipError_t launch_stage(hipStream_t stream, bool kmajor, const StageArgs& a) {
+    if (kmajor) {
+        dim3 grid((unsigned)a.rows);
+        hipLaunchKernelGGL((stage_kmajor_kernel<T, MODE>), grid, dim3(256), 0, stream, a);
+    } else {
+        dim3 grid((unsigned)(a.kp / StageTile<T>::TK), (unsigned)((a.rows + 31) / 32));
+        hipLaunchKernelGGL((stage_strided_kernel<T, MODE>), grid, dim3(256), 0, stream, a);
+    }
+    return hipGetLastError();
+}
+
+template <int MODE> static hipError_t dispatch_stage(hipStream_t stream, int dtype, bool kmajor, const StageArgs& a) {
+    switch (dtype) {
+    case kF32: return launch_stage<float, MODE>(stream, kmajor, a);
+    case kF64: return launch_stage<double, MODE>(stream, kmajor, a);
+    case kC32: return launch_stage<float2, MODE>(stream, kmajor, a);
+    case kC64: return launch_stage<double2, MODE>(stream, kmajor, a);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajor, bool conj, size_t rows, size_t k, const void* X,
+                          size_t ld, int8_t* lo, size_t part_stride, size_t kp, int16_t* sft0, void* scratch_amax) {
+    if (rows == 0) return hipSuccess;
+    StageArgs a{};
+    a.X = X;
+    a.ld = ld;
+    a.rows = rows;
+    a.k = k;
+    a.kp = kp;
+    a.lo = lo;
+    a.part_stride = part_stride;
+    a.sft0 = sft0;
+    a.amax = scratch_amax;
+    a.backend = backend;
+    a.conj = conj;
+    if (!kmajor) {
+        const size_t ub = is_f32(dtype) ? 4 : 8;
+        hipError_t e = hipMemsetAsync(scratch_amax, 0, ub * rows, stream);
+        if (e != hipSuccess) return e;
+        unsigned ksplit = (unsigned)((k + 511) / 512);
+        if (ksplit > 64) ksplit = 64;
+        if (ksplit < 1) ksplit = 1;
+        dim3 grid((unsigned)((rows + 63) / 64), ksplit);
+        switch (dtype) {
+        case kF32: hipLaunchKernelGGL(amax_strided_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, ld, rows, k, scratch_amax); break;
+        case kF64: hipLaunchKernelGGL(amax_strided_kernel<double>, grid, dim3(256), 0, stream, (const double*)X, ld, rows, k, scratch_amax); break;
+        case kC32: hipLaunchKernelGGL(amax_strided_kernel<float2>, grid, dim3(256), 0, stream, (const float2*)X, ld, rows, k, scratch_amax); break;
+        case kC64: hipLaunchKernelGGL(amax_strided_kernel<double2>, grid, dim3(256), 0, stream, (const double2*)X, ld, rows, k, scratch_amax); break;
+        }
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return dispatch_stage<MODE_BOUND>(stream, dtype, kmajor, a);
+}
+
+hipError_t launch_quantise(hipStream_t stream, int dtype, int backend, unsigned N, int t_begin, int t_end, bool kmajor, bool conj,
+                           size_t rows, size_t k, const void* X, size_t ld, const int16_t* sft, int8_t* lo, size_t plane_stride,
+                           size_t part_stride, size_t kp) {
+    if (rows == 0 || t_end <= t_begin) return hipSuccess;
+    hipError_t e = upload_pow2_once();
+    if (e != hipSuccess) return e;
+    StageArgs a{};
+    a.X = X;
+    a.ld = ld;
+    a.rows = rows;
+    a.k = k;
+    a.kp = kp;
+    a.lo = lo;
+    a.plane_stride = plane_stride;
+    a.part_stride = part_stride;
+    a.sft = sft;
+    a.backend = backend;
+    a.conj = conj;
+    a.t_begin = t_begin;
+    a.t_end = t_end;
+    a.mt = make_mod_table(backend);
+    (void)N;
+    return dispatch_stage<MODE_MOD>(stream, dtype, kmajor, a);
+}
+
+// ------------------------------------------------------------------ accurate-mode shift from the bound maxima
+__global__ void shift_finalize_kernel(size_t rows, const int* maxv, int16_t* sft, float log2P) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const int amax = maxv[r];
+    int f = 0;  // all-zero row/column: the reference is undefined here (log2(0)); any shift is valid
+    if (amax > 0) {
+        const float l = __log2f(__int2float_rn(amax));
+        f = __float2int_rd(__fmaf_rd(-0x1.000006p-1f, l, log2P));
+    }
+    sft[r] = (int16_t)(-((int)sft[r] + f));
+}
+hipError_t launch_shift_finalize(hipStream_t stream, int backend, unsigned N, size_t rows, const int* maxv, int16_t* sft) {
+    if (rows == 0) return hipSuccess;
+    const float log2P = backend == kINT8 ? GEMMUL8_LOG2P_INT8[N - 2] : GEMMUL8_LOG2P_FP8[N - 2];
+    hipLaunchKernelGGL(shift_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, rows, maxv, sft, log2P);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ fast-mode shifts
+// The round-up sums are order dependent; both kernels keep the reference's order so that the
+// shifts are the ones its HIP build would produce: per-lane strided chains, width-32 shuffle
+// trees, then a tree over the group sums (find_max.hpp:258-341, template_math.hpp:179-212).
+template <typename U> __device__ __forceinline__ U add_ru(U a, U b);
+template <> __device__ __forceinline__ float add_ru<float>(float a, float b) { return __fadd_ru(a, b); }
+template <> __device__ __forceinline__ double add_ru<double>(double a, double b) { return __dadd_ru(a, b); }
+template <typename U> __device__ __forceinline__ U sqr_add_ru(U x, U s);
+template <> __device__ __forceinline__ float sqr_add_ru<float>(float x, float s) { return __fmaf_ru(x, x, s); }
+template <> __device__ __forceinline__ double sqr_add_ru<double>(double x, double s) { return __fma_ru(x, x, s); }
+
+template <typename U> __device__ __forceinline__ U tree32_sum_ru(U v) {  // result valid in lane (l & 31) == 0
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v = add_ru<U>(v, __shfl_down(v, off, 32));
+    return v;
+}
+template <typename U> __device__ __forceinline__ U tree32_max(U v) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {
+        const U o = __shfl_down(v, off, 32);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int fast_sft(double amax, double vecnrm, float log2P) {
+    const int exponent = ilogb0(vecnrm);
+    const float vecnrmf = __double2float_ru(scalbn(vecnrm, -exponent));
+    const float log2vsum = __fadd_ru(__log2f(vecnrmf), (float)exponent);
+    const float log2vnrm = __fmul_ru(0x1.000006p-1f, log2vsum);
+    const float exp1 = __fsub_rd(__fsub_rd(log2P, 1.5f), fmaxf(1.0f, log2vnrm));
+    return __float2int_rd(exp1) - ilogb0((float)amax);
+}
+__device__ __forceinline__ int fast_sft(float amax, float vecnrm, float log2P) {
+    const float log2vsum = __log2f(vecnrm);
+    const float log2vnrm = __fmul_ru(0x1.000006p-1f, log2vsum);
+    const float exp1 = __fsub_rd(__fsub_rd(log2P, 1.5f), fmaxf(1.0f, log2vnrm));
+    return __float2int_rd(exp1) - ilogb0(amax);
+}
+
+// K-major: one 256-thread block per row (scaling_fast_real.hpp:142-164)
+template <typename T> __global__ void __launch_bounds__(256) fast_shift_kmajor_kernel(const T* X, size_t ld, size_t k, int16_t* sft, float log2P) {
+    using E = ET<T>;
+    using U = typename E::U;
+    __shared__ U samax[32], ssum[32];
+    const T* x = X + (size_t)blockIdx.x * ld;
+    U amax = 0, sum = 0;
+    for (size_t i = threadIdx.x; i < k; i += 256) {
+        const T v = x[i];
+        const U ar = (U)fabs(E::re(v));
+        amax = ar > amax ? ar : amax;
+        sum = sqr_add_ru<U>(ar, sum);
+        if constexpr (E::cplx) {
+            const U ai = (U)fabs(E::im(v));
+            amax = ai > amax ? ai : amax;
+            sum = sqr_add_ru<U>(ai, sum);
+        }
+    }
+    amax = tree32_max(amax);
+    sum = tree32_sum_ru(sum);
+    if ((threadIdx.x & 31) == 0) {
+        samax[threadIdx.x >> 5] = amax;
+        ssum[threadIdx.x >> 5] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        amax = threadIdx.x < 8 ? samax[threadIdx.x] : (U)0;
+        sum = threadIdx.x < 8 ? ssum[threadIdx.x] : (U)0;
+        amax = tree32_max(amax);
+        sum = tree32_sum_ru(sum);
+        if (threadIdx.x == 0) sft[blockIdx.x] = (int16_t)(-fast_sft(amax, sum, log2P));
+    }
+}
+
+// Row-strided: 32 rows x 32 k-lanes per block (scaling_fast_real.hpp:27-49)
+template <typename T> __global__ void __launch_bounds__(1024) fast_shift_strided_kernel(const T* X, size_t ld, size_t rows, size_t k, int16_t* sft, float log2P) {
+    using E = ET<T>;
+    using U = typename E::U;
+    __shared__ U samax[32][33], ssum[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    size_t row = (size_t)blockIdx.x * 32 + tx;
+    U amax = 0, sum = 0;
+    if (row < rows) {
+        const T* x = X + row;
+        for (size_t col = ty; col < k; col += 32) {
+            const T v = x[col * ld];
+            const U ar = (U)fabs(E::re(v));
+            amax = ar > amax ? ar : amax;
+            sum = sqr_add_ru<U>(ar, sum);
+            if constexpr (E::cplx) {
+                const U ai = (U)fabs(E::im(v));
+                amax = ai > amax ? ai : amax;
+                sum = sqr_add_ru<U>(ai, sum);
+            }
+        }
+    }
+    samax[ty][tx] = amax;
+    ssum[ty][tx] = sum;
+    __syncthreads();
+    sum = tree32_sum_ru(ssum[tx][ty]);
+    amax = tree32_max(samax[tx][ty]);
+    row = (size_t)blockIdx.x * 32 + ty;
+    if (row < rows && tx == 0) sft[row] = (int16_t)(-fast_sft(amax, sum, log2P));
+}
+
+hipError_t launch_fast_shift(hipStream_t stream, int dtype, int backend, unsigned N, bool kmajor, size_t rows, size_t k, const void* X,
+                             size_t ld, int16_t* sft) {
+    if (rows == 0) return hipSuccess;
+    const float log2P = backend == kINT8 ? GEMMUL8_LOG2P_INT8[N - 2] : GEMMUL8_LOG2P_FP8[N - 2];
+    if (kmajor) {
+        dim3 grid((unsigned)rows);
+        switch (dtype) {
+        case kF32: hipLaunchKernelGGL(fast_shift_kmajor_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, ld, k, sft, log2P); break;
+        case kF64: hipLaunchKernelGGL(fast_shift_kmajor_kernel<double>, grid, dim3(256), 0, stream, (const double*)X, ld, k, sft, log2P); break;
+        case kC32: hipLaunchKernelGGL(fast_shift_kmajor_kernel<float2>, grid, dim3(256), 0, stream, (const float2*)X, ld, k, sft, log2P); break;
+        case kC64: hipLaunchKernelGGL(fast_shift_kmajor_kernel<double2>, grid, dim3(256), 0, stream, (const double2*)X, ld, k, sft, log2P); break;
+        }
+    } else {
+        dim3 grid((unsigned)((rows + 31) / 32));
+        switch (dtype) {
+        case kF32: hipLaunchKernelGGL(fast_shift_strided_kernel<float>, grid, dim3(1024), 0, stream, (const float*)X, ld, rows, k, sft, log2P); break;
+        case kF64: hipLaunchKernelGGL(fast_shift_strided_kernel<double>, grid, dim3(1024), 0, stream, (const double*)X, ld, rows, k, sft, log2P); break;
+        case kC32: hipLaunchKernelGGL(fast_shift_strided_kernel<float2>, grid, dim3(1024), 0, stream, (const float2*)X, ld, rows, k, sft, log2P); break;
+        case kC64: hipLaunchKernelGGL(fast_shift_strided_kernel<double2>, grid, dim3(1024), 0, stream, (const double2*)X, ld, rows, k, sft, log2P); break;
+        }
+    }
+    return hipGetLastError();
+}
+
+}  // namespace oz2

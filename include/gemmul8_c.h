@@ -1,0 +1,103 @@
+/*
+ * gemmul8_c.h -- C ABI of the MI355X-native Ozaki-scheme-II GEMM emulator (libgemmul8.so).
+ *
+ * This is the drop-in boundary for the hot path of RIKEN-RCCS/GEMMul8: plain pointers and sizes,
+ * no C++ / torch types.  The C++ template API of include/gemmul8.hpp (gemmul8::workSize / gemm /
+ * gemmLt, reference GEMMul8/include/gemmul8.hpp:25-151) and the LD_PRELOAD hipBLAS hook
+ * (reference GEMMul8/src/hook.cu:846-1055) are thin layers over these entry points.
+ *
+ * Conventions: column-major BLAS semantics, all matrix pointers are DEVICE pointers, `stream` is a
+ * hipStream_t passed as void*.  Every function returns 0 on success, a negative GEMMUL8_E_* code
+ * on bad arguments, or a positive hipError_t if the HIP runtime failed.
+ */
+#ifndef GEMMUL8_C_H
+#define GEMMUL8_C_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element type of A, B, C (reference: template parameter T of gemmul8::gemm, gemmul8.hpp:98) */
+enum { GEMMUL8_S = 0, GEMMUL8_D = 1, GEMMUL8_C = 2, GEMMUL8_Z = 3 };
+/* low-precision engine (reference: enum class Backend, gemmul8.hpp:19-20) */
+enum { GEMMUL8_INT8 = 0, GEMMUL8_FP8 = 1 };
+/* op(X): 0/1/2, or the hipblasOperation_t values 111/112/113 (both accepted) */
+enum { GEMMUL8_OP_N = 0, GEMMUL8_OP_T = 1, GEMMUL8_OP_C = 2 };
+
+enum {
+    GEMMUL8_OK = 0,
+    GEMMUL8_E_NUM_MODULI = -1, /* num_moduli outside 2..20 */
+    GEMMUL8_E_ARG = -2,        /* null pointer / bad enum / k > 2^17 */
+    GEMMUL8_E_UNSUPPORTED = -3 /* combination not built */
+};
+
+/* Workspace bytes; same formula as the reference so callers' allocations stay valid.
+ * Replaces gemmul8::workSize<is_Complex,backend> (include/gemmul8.hpp:25-35,
+ * src/gemmul8_real.hpp:8-47, src/gemmul8_complex.hpp:8-47). */
+size_t gemmul8_work_size(int is_complex, int backend, size_t m, size_t n, size_t k, unsigned num_moduli,
+                         int enable_skip_scalA, int enable_skip_scalB, size_t *workSizeA, size_t *workSizeB);
+
+/* Whole emulated GEMM: C = alpha*op(A)*op(B) + beta*C.
+ * Replaces gemmul8::gemm<T,backend> / gemmLt<T,backend> (include/gemmul8.hpp:98-151,
+ * src/gemmul8_real.hpp:52-211, src/gemmul8_complex.hpp:52-226).
+ * alpha/beta may be host or device pointers (detected like inverse_scaling_real.hpp:211-213).
+ * timers_ns: NULL = fully asynchronous; else 4 doubles [scaling, low-prec GEMM, requantise (always
+ * 0: fused into the GEMM epilogue), inverse scaling] in ns, measured with events (one host sync). */
+int gemmul8_gemm(void *stream, int dtype, int backend, int op_A, int op_B, size_t m, size_t n, size_t k,
+                 const void *alpha, const void *A, size_t lda, const void *B, size_t ldb, const void *beta, void *C,
+                 size_t ldc, unsigned num_moduli, int fastmode, void *work, void *workA, void *workB,
+                 int enable_skip_scalA, int enable_skip_scalB, int skip_scalA, int skip_scalB, double *timers_ns);
+
+/* Where the intermediates of the last/next gemmul8_gemm call live inside the workspaces (device
+ * pointers; same carving as src/gemmul8_real.hpp:95-107).  Used by the parity tests and by the
+ * moduli-sharded multi-GPU driver. */
+typedef struct gemmul8_layout {
+    size_t kp, mp;             /* padded k and m (multiples of 256) */
+    size_t num_mat;            /* low-precision planes per part */
+    size_t parts;              /* 1 (real) or 3 (complex: Re, Im, Re+Im) */
+    size_t sizeA, sizeB, sizeC;/* elements per plane: kp*mp, kp*n, mp*n */
+    void *A_lo, *B_lo;         /* plane (part,q) at X_lo + (part*num_mat_total + q)*sizeX, num_mat_total = num_mat (+1 if skip enabled) ... see part_strideX */
+    size_t part_strideA, part_strideB; /* bytes between Re/Im/Re+Im plane sets */
+    void *A_bound, *B_bound;   /* accurate-mode 7-bit bound planes (alias plane 0 unless skip enabled) */
+    int16_t *sftA, *sftB;      /* negated shift exponents */
+    void *C_mid;               /* N residue planes [n][mp] (complex: interleaved re,im) */
+    void *scratch;             /* the reference's C_hi region (free for row/col maxima etc.) */
+    size_t scratch_bytes;
+} gemmul8_layout;
+
+int gemmul8_get_layout(int dtype, int backend, size_t m, size_t n, size_t k, unsigned num_moduli, void *work, void *workA,
+                       void *workB, int enable_skip_scalA, int enable_skip_scalB, gemmul8_layout *out);
+
+/* ---- phase-level entry points (one per kernel family) -------------------------------------- */
+
+/* Shifts + residue planes of both operands for moduli [t_begin, t_end).  fastmode=0 runs the
+ * accurate path (extract, bound GEMM with max epilogue, shift).  Replaces fast::scaling /
+ * accu::scaling (src/scaling_fast_real.hpp:222-268, src/scaling_accu_real.hpp:380-457 and the
+ * complex variants). */
+int gemmul8_scale(void *stream, int dtype, int backend, int op_A, int op_B, size_t m, size_t n, size_t k, const void *A,
+                  size_t lda, const void *B, size_t ldb, unsigned num_moduli, int fastmode, unsigned t_begin,
+                  unsigned t_end, const gemmul8_layout *L, int skipA, int skipB);
+
+/* Low-precision GEMMs of moduli [t_begin, t_end) with the requantise epilogue: fills C_mid planes.
+ * Replaces gemm_low_prec_* + conv_hi2mid (src/matmult.hpp:120-389, src/conv_hi2mid_real.hpp,
+ * src/conv_hi2mid_complex.hpp; loop at src/gemmul8_real.hpp:144-191). */
+int gemmul8_lowprec_gemm(void *stream, int dtype, int backend, size_t m, size_t n, size_t k, unsigned num_moduli,
+                         unsigned t_begin, unsigned t_end, const gemmul8_layout *L);
+
+/* CRT accumulation + inverse scaling + axpby on an arbitrary column block: C_mid planes given by
+ * pointer/stride so that a GPU can finish the columns it owns after an exchange of residue planes.
+ * Replaces inverse_scaling (src/inverse_scaling_real.hpp:242-278, inverse_scaling_complex.hpp). */
+int gemmul8_crt(void *stream, int dtype, int backend, unsigned num_moduli, size_t m, size_t n, const void *C_mid,
+                size_t ld_mid, size_t plane_stride, const int16_t *sftA, const int16_t *sftB, const void *alpha,
+                const void *beta, void *C, size_t ldc);
+
+/* Library identification (build arch, version) */
+const char *gemmul8_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

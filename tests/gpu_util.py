@@ -1,0 +1,103 @@
+"""Helpers for the -m gpu parity tests: run the HIP path through the C ABI and fetch intermediates."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+import gemmul8_amd as g
+import oracle_lib as ol
+
+NP2T = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+        np.dtype(np.complex64): torch.complex64, np.dtype(np.complex128): torch.complex128}
+
+
+def to_dev(M):
+    """numpy (rows x cols) matrix -> column-major device tensor of shape (cols, rows)."""
+    return torch.from_numpy(np.ascontiguousarray(M.T)).cuda()
+
+
+def from_dev(T):
+    return T.cpu().numpy().T
+
+
+def hip_gemm(A, B, N, fastmode=False, backend=g.INT8, opA="N", opB="N", alpha=1.0, beta=0.0, C0=None, want_intermediates=False,
+             timers=False):
+    """A, B: numpy arrays as stored (before op), like oracle_lib.gemm.  Returns C (numpy m x n) [, intermediates]."""
+    dA, dB = to_dev(A), to_dev(B)
+    dC = to_dev(C0.copy()) if C0 is not None else None
+    m, k = (A.shape if opA == "N" else A.shape[::-1])
+    n = B.shape[1] if opB == "N" else B.shape[0]
+    cplx = A.dtype.kind == "c"
+    tot, _, _ = g.work_size(cplx, backend, m, n, k, N)
+    work = torch.zeros(tot, dtype=torch.uint8, device="cuda")
+    Cd, tm, work = g.gemm(dA, dB, N, fastmode=fastmode, backend=backend, opA=opA, opB=opB, alpha=alpha, beta=beta, C_out=dC,
+                          work=work, timers=timers)
+    torch.cuda.synchronize()
+    Cn = from_dev(Cd)
+    if not want_intermediates:
+        return (Cn, tm) if timers else Cn
+    L = g.Layout()
+    g.check(g.lib().gemmul8_get_layout(g._dtype_code(dA.dtype), backend, m, n, k, N, work.data_ptr(), None, None, 0, 0, C.byref(L)))
+    w = work.cpu().numpy()
+    base = work.data_ptr()
+    parts, nm = L.parts, L.num_mat
+
+    def region(ptr, nbytes):
+        off = ptr - base
+        return w[off:off + nbytes]
+
+    sftA = region(L.sftA, 2 * m).view(np.int16).copy()
+    sftB = region(L.sftB, 2 * n).view(np.int16).copy()
+    A_lo = np.zeros((parts, nm, m, k), np.uint8)
+    B_lo = np.zeros((parts, nm, n, k), np.uint8)
+    for p in range(parts):
+        for q in range(nm):
+            pa = region(L.A_lo + p * L.part_strideA + q * L.sizeA, L.sizeA).reshape(L.mp, L.kp)
+            A_lo[p, q] = pa[:m, :k]
+            assert not pa[:m, k:].any(), "k-padding of A_lo must be zero"
+            pb = region(L.B_lo + p * L.part_strideB + q * L.sizeB, L.sizeB).reshape(n, L.kp)
+            B_lo[p, q] = pb[:, :k]
+            assert not pb[:, k:].any(), "k-padding of B_lo must be zero"
+    mid_dt = np.int8 if backend == g.INT8 else np.int16
+    comps = 2 if cplx else 1
+    isz = np.dtype(mid_dt).itemsize * comps
+    Cm = np.zeros((N, n, m, comps), mid_dt)
+    for t in range(N):
+        pc = region(L.C_mid + t * L.sizeC * isz, L.sizeC * isz).view(mid_dt).reshape(n, L.mp, comps)
+        Cm[t] = pc[:, :m, :]
+    if not cplx:
+        Cm = Cm[..., 0]
+    inter = dict(sftA=sftA, sftB=sftB, A_lo=A_lo, B_lo=B_lo, C_mid=Cm)
+    return (Cn, inter, tm) if timers else (Cn, inter)
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def shifts_close(dev, orc, what=""):
+    """Device vs oracle shifts: identical except for rare +-1 at floor boundaries of the log2 approximation."""
+    d = dev.astype(int) - orc.astype(int)
+    bad = np.abs(d) > 1
+    assert not bad.any(), f"{what}: shift differs by more than 1 at {np.nonzero(bad)[0][:5]}"
+    nd = int((d != 0).sum())
+    assert nd <= max(1, 0.02 * d.size), f"{what}: {nd}/{d.size} shifts differ from the oracle (log2 boundary cases should be rare)"
+    return nd
+
+
+def parity_case(A, B, N, fastmode, opA="N", opB="N", alpha=1.0, beta=0.0, C0=None, backend=g.INT8):
+    """Full bit-exact parity of one case: shifts (tolerant), planes, C_mid, C (exact given the device's shifts)."""
+    Cd, it = hip_gemm(A, B, N, fastmode=fastmode, backend=backend, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0, want_intermediates=True)
+    # oracle with its own shifts -> compare shifts
+    _, ito = ol.gemm(A, B, N, fastmode=fastmode, backend=backend, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0, want_intermediates=True)
+    nd = shifts_close(it["sftA"], ito["sftA"], "sftA") + shifts_close(it["sftB"], ito["sftB"], "sftB")
+    # oracle fed with the device's shifts -> everything downstream is bit-exact
+    Co, ito = ol.gemm(A, B, N, fastmode=fastmode, backend=backend, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0,
+                      sftA_in=it["sftA"], sftB_in=it["sftB"], want_intermediates=True)
+    assert np.array_equal(it["A_lo"], ito["A_lo"]), "A_lo planes differ"
+    assert np.array_equal(it["B_lo"], ito["B_lo"]), "B_lo planes differ"
+    assert np.array_equal(it["C_mid"], ito["C_mid"]), "C_mid planes differ"
+    assert bits_equal(Cd, Co), f"final C differs in {np.sum(Cd != Co)} elements"
+    return nd

@@ -1,0 +1,87 @@
+"""-m gpu parity tests: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+Policy: shifts may differ from the host oracle only at rare floor boundaries of
+the hardware log2 (|diff| <= 1, flagged and counted); with the DEVICE's shifts fed to the oracle,
+A_lo / B_lo / C_mid planes and the final C must be bit-identical."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rand(shape, dtype, rng, phi=1.0):
+    x = (rng.random(shape) - 0.5) * np.exp(phi * rng.standard_normal(shape))
+    if np.dtype(dtype).kind == "c":
+        x = x + 1j * (rng.random(shape) - 0.5) * np.exp(phi * rng.standard_normal(shape))
+    return x.astype(dtype)
+
+
+def test_library_loads_and_reports():
+    import gemmul8_amd as g
+    assert b"gfx950" in g.lib().gemmul8_version()
+
+
+def test_kat_sample_on_gpu():
+    """Reference sample vectors (sample/dgemm_cuBLAS_int8.cu:24-38), N=15 accurate, through the HIP path."""
+    import gpu_util as gu
+    d = json.load(open(os.path.join(GOLD, "kat_dgemm_4x5x3.json")))
+    A = np.array([float.fromhex(x) for x in d["A"]]).reshape((4, 5), order="F")
+    B = np.array([float.fromhex(x) for x in d["B"]]).reshape((5, 3), order="F")
+    Cx = np.array([float.fromhex(x) for x in d["C_exact"]]).reshape((4, 3), order="F")
+    for fast in (False, True):
+        C = gu.hip_gemm(A, B, 15, fastmode=fast)
+        assert np.sqrt(((C - Cx) ** 2).sum()) < 4e-15
+        gu.parity_case(A, B, 15, fast)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("fast", [False, True])
+@pytest.mark.parametrize("N", [2, 6, 7, 8, 14, 15, 16, 20])
+def test_parity_small_real(dtype, fast, N):
+    import gpu_util as gu
+    if dtype == np.float32 and N > 13:
+        pytest.skip("float documented for N<=13")
+    rng = np.random.default_rng(100 * N + fast)
+    m, n, k = 37, 41, 300
+    A, B = rand((m, k), dtype, rng), rand((k, n), dtype, rng)
+    A[5, :] = 0  # all-zero row
+    B[:, 7] = 0  # all-zero column
+    A[3, 4] = np.finfo(dtype).tiny / 4  # subnormal
+    gu.parity_case(A, B, N, fast)
+
+
+@pytest.mark.parametrize("opA,opB", [("N", "N"), ("T", "N"), ("N", "T"), ("T", "T")])
+@pytest.mark.parametrize("alpha,beta", [(1, 0), (1, 1), (-1, 0), (-1, 1), (-1.5, 1.5)])
+def test_parity_ops_axpby(opA, opB, alpha, beta):
+    """op x (alpha,beta) matrix of debug/test.cu:106-141 on odd sizes."""
+    import gpu_util as gu
+    rng = np.random.default_rng(5)
+    m, n, k = 45, 33, 47
+    A = rand((m, k) if opA == "N" else (k, m), np.float64, rng)
+    B = rand((k, n) if opB == "N" else (n, k), np.float64, rng)
+    C0 = rand((m, n), np.float64, rng)
+    for fast in (False, True):
+        gu.parity_case(A, B, 14, fast, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0)
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 256, 256), (300, 520, 700), (1, 1, 1), (513, 255, 1025), (128, 128, 4096)])
+def test_parity_shapes(m, n, k):
+    import gpu_util as gu
+    rng = np.random.default_rng(m + n + k)
+    A, B = rand((m, k), np.float64, rng), rand((k, n), np.float64, rng)
+    gu.parity_case(A, B, 14, False)
+    gu.parity_case(A, B, 9, True)
+
+
+def test_config1_sgemm_256_moduli2():
+    """BASELINE config 1 through the GPU path as well."""
+    import gpu_util as gu
+    A = (np.random.default_rng(12345).random((256, 256)) - 0.5).astype(np.float32)
+    B = (np.random.default_rng(54321).random((256, 256)) - 0.5).astype(np.float32)
+    for fast in (True, False):
+        gu.parity_case(A, B, 2, fast)
