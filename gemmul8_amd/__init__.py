@@ -36,6 +36,26 @@ EXPORTS = ["gemmul8_version", "gemmul8_work_size", "gemmul8_gemm", "gemmul8_get_
            "gemmul8_lowprec_gemm", "gemmul8_crt"]
 
 
+def _bind_hip_runtime():
+    """libgemmul8.so carries no DT_NEEDED on the HIP runtime: it must bind to the SAME libamdhip64 the
+    process already uses (PyTorch bundles its own copy; two runtimes do not share device pointers).
+    Promote the loaded copy to RTLD_GLOBAL, or load the system one if none is mapped yet."""
+    try:
+        import torch  # noqa: F401  (maps torch/lib/libamdhip64.so)
+    except Exception:
+        pass
+    path = None
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                path = line.split()[-1]
+                break
+    if path is None:
+        path = "/opt/rocm/lib/libamdhip64.so"
+    C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return path
+
+
 def lib():
     """Load libgemmul8.so (fails loudly if it has not been built: run __graft_entry__.build())."""
     global _lib
@@ -43,6 +63,7 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} not found: the HIP extension is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    _bind_hip_runtime()
     L = C.CDLL(LIB_PATH)
     L.gemmul8_version.restype = C.c_char_p
     L.gemmul8_work_size.restype = C.c_size_t
