@@ -1,0 +1,317 @@
+// LD_PRELOAD hipBLAS hook: hipblas{S,D,C,Z}gemm, hipblasGemmEx and hipblasDestroy are intercepted
+// and routed to the Ozaki-II emulation (C ABI, gemmul8_c.h) according to the GEMMUL8_* environment
+// variables; everything else -- and every call the environment does not select -- is passed to the
+// real library found with dlsym(RTLD_NEXT).
+//
+// Behavioural contract restated from the reference (GEMMul8/src/hook.cu, README.md:283-385):
+//   env (read on EVERY call unless noted)     hook.cu:170-227,284-310
+//     GEMMUL8_BACKEND          0|INT8 (default) / 1|FP8
+//     GEMMUL8_NUM_MOD_{D,S,Z,C} emulate when 2 <= N <= 20 (D,Z) / 13 (S,C); otherwise native
+//     GEMMUL8_FASTMODE_{D,S,Z,C} "1" = fast mode, default accurate
+//     GEMMUL8_SKIP_SCALE_{A,B}  "1" = keep quantised operand + shifts between calls (pointer identity)
+//     GEMMUL8_MAX_{M,N,K}, GEMMUL8_MAX_NUM_MOD, GEMMUL8_MAXWS_BACKEND (read once): workspace
+//       pre-sizing applied when a SKIP_SCALE switch is on                      hook.cu:232-281,656-662
+//   early outs: m|n|k <= 0 -> SUCCESS, null A/B/C -> INVALID_VALUE            hook.cu:616-617
+//   per-handle state under a mutex: three grow-only stream-ordered buffers (hipMallocAsync /
+//   hipFreeAsync), event hand-off when the handle's stream changes, skip-scaling cache
+//   (hook.cu:70-162,331-374,684-727); hipblasDestroy frees the state first (hook.cu:846-856).
+// This file has no kernels and calls no BLAS routine itself.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <hipblas/hipblas.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <unordered_map>
+
+#include "../../include/gemmul8_c.h"
+
+namespace {
+
+struct Cache {  // what the quantised planes in workA/workB currently hold
+    bool valid = false;
+    unsigned num_moduli = 0;
+    int op_A = 0, op_B = 0;
+    size_t m = 0, n = 0, k = 0, lda = 0, ldb = 0;
+    const void *A = nullptr, *B = nullptr;
+    void *workA = nullptr, *workB = nullptr;
+    int dtype = -1, backend = 0;
+    bool fastmode = false;
+};
+
+struct Buffer {
+    void* ptr = nullptr;
+    size_t size = 0;
+};
+
+struct HandleState {
+    std::mutex mtx;
+    Buffer wA, wB, wC;
+    Cache last;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t last_event = nullptr;
+    bool have_stream = false;
+};
+
+std::mutex g_map_mtx;
+std::unordered_map<hipblasHandle_t, std::shared_ptr<HandleState>> g_map;
+
+std::shared_ptr<HandleState> state_of(hipblasHandle_t h) {
+    std::lock_guard<std::mutex> g(g_map_mtx);
+    auto& p = g_map[h];
+    if (!p) p = std::make_shared<HandleState>();
+    return p;
+}
+
+bool env_one(const char* name) {
+    const char* s = std::getenv(name);
+    return s && std::strcmp(s, "1") == 0;
+}
+unsigned long long env_u64(const char* name, unsigned long long def) {
+    const char* s = std::getenv(name);
+    if (!s || !*s) return def;
+    char* end = nullptr;
+    const unsigned long long v = std::strtoull(s, &end, 10);
+    return (end == s) ? def : v;
+}
+int env_backend(const char* name, int def, bool allow_both) {
+    const char* s = std::getenv(name);
+    if (!s) return def;
+    if (!std::strcmp(s, "0") || !std::strcmp(s, "INT8")) return 0;
+    if (!std::strcmp(s, "1") || !std::strcmp(s, "FP8")) return 1;
+    if (allow_both && (!std::strcmp(s, "2") || !std::strcmp(s, "BOTH"))) return 2;
+    return def;
+}
+
+struct TypeInfo {
+    const char* nmod;
+    const char* fast;
+    unsigned max_moduli;
+    bool cplx;
+};
+const TypeInfo kTypes[4] = {
+    {"GEMMUL8_NUM_MOD_S", "GEMMUL8_FASTMODE_S", 13u, false},
+    {"GEMMUL8_NUM_MOD_D", "GEMMUL8_FASTMODE_D", 20u, false},
+    {"GEMMUL8_NUM_MOD_C", "GEMMUL8_FASTMODE_C", 13u, true},
+    {"GEMMUL8_NUM_MOD_Z", "GEMMUL8_FASTMODE_Z", 20u, true},
+};
+
+// process-wide workspace floor, computed once (hook.cu:232-281)
+size_t g_maxA = 0, g_maxB = 0, g_maxC = 0;
+std::once_flag g_max_once;
+void init_max_workspace() {
+    std::call_once(g_max_once, [] {
+        const size_t mm = env_u64("GEMMUL8_MAX_M", 0), mn = env_u64("GEMMUL8_MAX_N", 0), mk = env_u64("GEMMUL8_MAX_K", 0);
+        const unsigned mmod = (unsigned)env_u64("GEMMUL8_MAX_NUM_MOD", 2);
+        const bool cplx = env_u64("GEMMUL8_NUM_MOD_Z", 0) > 0 || env_u64("GEMMUL8_NUM_MOD_C", 0) > 0;
+        const int which = env_backend("GEMMUL8_MAXWS_BACKEND", 0, true);
+        for (int be = 0; be < 2; ++be) {
+            if (!(which == be || which == 2)) continue;
+            if (mmod < 2 || mmod > 20) continue;
+            size_t wa = 0, wb = 0;
+            const size_t w = gemmul8_work_size(cplx, be, mm, mn, mk, mmod, 1, 1, &wa, &wb);
+            g_maxA = std::max(g_maxA, wa);
+            g_maxB = std::max(g_maxB, wb);
+            g_maxC = std::max(g_maxC, w > wa + wb ? w - wa - wb : 0);
+        }
+    });
+}
+
+hipblasStatus_t grow(Buffer& b, size_t need, hipStream_t stream, const char* tag) {
+    if (need == 0 || (b.ptr && b.size >= need)) return HIPBLAS_STATUS_SUCCESS;
+    if (b.ptr) {
+        const hipError_t e = hipFreeAsync(b.ptr, stream);
+        if (e != hipSuccess) {
+            std::fprintf(stderr, "[GEMMUL8 HOOK] hipFreeAsync failed for %s (%s)\n", tag, hipGetErrorString(e));
+            return HIPBLAS_STATUS_INTERNAL_ERROR;
+        }
+        b.ptr = nullptr;
+        b.size = 0;
+    }
+    void* p = nullptr;
+    const hipError_t e = hipMallocAsync(&p, need, stream);
+    if (e != hipSuccess) {
+        std::fprintf(stderr, "[GEMMUL8 HOOK] hipMallocAsync failed for %s size %zu bytes (%s)\n", tag, need, hipGetErrorString(e));
+        return HIPBLAS_STATUS_ALLOC_FAILED;
+    }
+    b.ptr = p;
+    b.size = need;
+    return HIPBLAS_STATUS_SUCCESS;
+}
+
+template <typename Fn> Fn real_fn(const char* name) { return reinterpret_cast<Fn>(dlsym(RTLD_NEXT, name)); }
+
+hipStream_t handle_stream(hipblasHandle_t h, hipblasStatus_t* st) {
+    using Fn = hipblasStatus_t (*)(hipblasHandle_t, hipStream_t*);
+    static Fn fn = [] {
+        Fn f = real_fn<Fn>("hipblasGetStream");
+        if (!f) f = reinterpret_cast<Fn>(dlsym(RTLD_DEFAULT, "hipblasGetStream"));
+        return f;
+    }();
+    hipStream_t s = nullptr;
+    *st = fn ? fn(h, &s) : HIPBLAS_STATUS_NOT_INITIALIZED;
+    return s;
+}
+
+// order work on the new stream after everything queued on the previous one (hook.cu:141-162)
+hipblasStatus_t order_streams(HandleState& st, hipStream_t cur) {
+    if (!st.have_stream) {
+        st.last_stream = cur;
+        st.have_stream = true;
+        return HIPBLAS_STATUS_SUCCESS;
+    }
+    if (st.last_stream == cur) return HIPBLAS_STATUS_SUCCESS;
+    if (!st.last_event && hipEventCreateWithFlags(&st.last_event, hipEventDisableTiming) != hipSuccess) return HIPBLAS_STATUS_INTERNAL_ERROR;
+    if (hipEventRecord(st.last_event, st.last_stream) != hipSuccess) return HIPBLAS_STATUS_INTERNAL_ERROR;
+    if (hipStreamWaitEvent(cur, st.last_event, 0) != hipSuccess) return HIPBLAS_STATUS_INTERNAL_ERROR;
+    st.last_stream = cur;
+    return HIPBLAS_STATUS_SUCCESS;
+}
+
+// returns true and sets *status when the call was emulated; false -> caller passes through
+bool try_emulate(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, hipblasOperation_t tb, int m, int n, int k, const void* alpha,
+                 const void* A, int lda, const void* B, int ldb, const void* beta, void* C, int ldc, hipblasStatus_t* status) {
+    const TypeInfo& ti = kTypes[dtype];
+    const unsigned N = (unsigned)env_u64(ti.nmod, 0);
+    if (N < 2u || N > ti.max_moduli) return false;
+    const bool fastmode = env_one(ti.fast);
+    const bool enA = env_one("GEMMUL8_SKIP_SCALE_A"), enB = env_one("GEMMUL8_SKIP_SCALE_B");
+    const int backend = env_backend("GEMMUL8_BACKEND", 0, false);
+
+    auto sp = state_of(handle);
+    std::lock_guard<std::mutex> lk(sp->mtx);
+    init_max_workspace();
+    hipblasStatus_t st;
+    hipStream_t stream = handle_stream(handle, &st);
+    if (st != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
+    if ((st = order_streams(*sp, stream)) != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
+
+    size_t needA = 0, needB = 0;
+    const size_t tot = gemmul8_work_size(ti.cplx, backend, (size_t)m, (size_t)n, (size_t)k, N, enA, enB, &needA, &needB);
+    if (tot < needA + needB) return *status = HIPBLAS_STATUS_INVALID_VALUE, true;
+    size_t reqA = needA, reqB = needB, reqC = tot - needA - needB;
+    if (enA || enB) {  // keep buffers (hence cached planes) stable across differently sized calls
+        if (enA) reqA = std::max(reqA, g_maxA);
+        if (enB) reqB = std::max(reqB, g_maxB);
+        reqC = std::max(reqC, g_maxC);
+    }
+    if ((st = grow(sp->wA, reqA, stream, "workA")) != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
+    if ((st = grow(sp->wB, reqB, stream, "workB")) != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
+    if ((st = grow(sp->wC, reqC, stream, "workC")) != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
+
+    const Cache& c = sp->last;
+    bool skipA = false, skipB = false;
+    if (c.valid && c.num_moduli == N && c.k == (size_t)k && c.dtype == dtype && c.fastmode == fastmode && c.backend == backend) {
+        skipA = enA && c.workA == sp->wA.ptr && c.A == A && c.m == (size_t)m && c.lda == (size_t)lda && c.op_A == (int)ta;
+        skipB = enB && c.workB == sp->wB.ptr && c.B == B && c.n == (size_t)n && c.ldb == (size_t)ldb && c.op_B == (int)tb;
+    }
+    const int rc = gemmul8_gemm(stream, dtype, backend, (int)ta, (int)tb, (size_t)m, (size_t)n, (size_t)k, alpha, A, (size_t)lda, B,
+                                (size_t)ldb, beta, C, (size_t)ldc, N, fastmode, sp->wC.ptr, sp->wA.ptr, sp->wB.ptr, enA, enB, skipA, skipB,
+                                nullptr);
+    if (rc == GEMMUL8_E_UNSUPPORTED) {
+        static bool warned = false;
+        if (!warned) std::fprintf(stderr, "[GEMMUL8 HOOK] requested emulation (type %d, backend %d) is not built: using the native routine\n", dtype, backend), warned = true;
+        return false;
+    }
+    if (rc != 0) return *status = (rc > 0 ? HIPBLAS_STATUS_INTERNAL_ERROR : HIPBLAS_STATUS_INVALID_VALUE), true;
+    Cache& u = sp->last;
+    u.valid = true;
+    u.num_moduli = N;
+    u.op_A = (int)ta, u.op_B = (int)tb;
+    u.m = m, u.n = n, u.k = k, u.lda = lda, u.ldb = ldb;
+    u.A = A, u.B = B;
+    u.workA = sp->wA.ptr, u.workB = sp->wB.ptr;
+    u.dtype = dtype, u.backend = backend, u.fastmode = fastmode;
+    return *status = HIPBLAS_STATUS_SUCCESS, true;
+}
+
+void release_state(hipblasHandle_t handle) {
+    std::shared_ptr<HandleState> sp;
+    {
+        std::lock_guard<std::mutex> g(g_map_mtx);
+        auto it = g_map.find(handle);
+        if (it == g_map.end()) return;
+        sp = it->second;
+        g_map.erase(it);
+    }
+    std::lock_guard<std::mutex> lk(sp->mtx);
+    hipStream_t stream = nullptr;
+    bool have = sp->have_stream;
+    if (have) stream = sp->last_stream;
+    else {
+        hipblasStatus_t st;
+        stream = handle_stream(handle, &st);
+        have = (st == HIPBLAS_STATUS_SUCCESS);
+    }
+    if (!have) (void)hipDeviceSynchronize();
+    for (Buffer* b : {&sp->wA, &sp->wB, &sp->wC}) {
+        if (!b->ptr) continue;
+        hipError_t e = have ? hipFreeAsync(b->ptr, stream) : hipFree(b->ptr);
+        if (e != hipSuccess && have && hipStreamSynchronize(stream) == hipSuccess) e = hipFree(b->ptr);
+        if (e != hipSuccess) std::fprintf(stderr, "[GEMMUL8 HOOK] hipblasDestroy: freeing a workspace failed (%s)\n", hipGetErrorString(e));
+        b->ptr = nullptr;
+        b->size = 0;
+    }
+    if (sp->last_event) (void)hipEventDestroy(sp->last_event), sp->last_event = nullptr;
+}
+
+#define OZ2_EARLY_OUT()                                           \
+    if (m <= 0 || n <= 0 || k <= 0) return HIPBLAS_STATUS_SUCCESS; \
+    if (!A || !B || !C) return HIPBLAS_STATUS_INVALID_VALUE;
+
+}  // namespace
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+hipblasStatus_t hipblasDestroy(hipblasHandle_t handle) {
+    release_state(handle);
+    using Fn = hipblasStatus_t (*)(hipblasHandle_t);
+    static Fn real = real_fn<Fn>("hipblasDestroy");
+    return real ? real(handle) : HIPBLAS_STATUS_NOT_INITIALIZED;
+}
+
+#define OZ2_GEMM_HOOK(NAME, T, CODE)                                                                                                   \
+    hipblasStatus_t NAME(hipblasHandle_t handle, hipblasOperation_t transA, hipblasOperation_t transB, int m, int n, int k,             \
+                         const T* alpha, const T* A, int lda, const T* B, int ldb, const T* beta, T* C, int ldc) {                      \
+        OZ2_EARLY_OUT()                                                                                                                 \
+        hipblasStatus_t st;                                                                                                             \
+        if (try_emulate(CODE, handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, &st)) return st;                    \
+        using Fn = hipblasStatus_t (*)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int, const T*, const T*, int, \
+                                       const T*, int, const T*, T*, int);                                                               \
+        static Fn real = real_fn<Fn>(#NAME);                                                                                            \
+        return real ? real(handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc) : HIPBLAS_STATUS_NOT_INITIALIZED;      \
+    }
+OZ2_GEMM_HOOK(hipblasSgemm, float, GEMMUL8_S)
+OZ2_GEMM_HOOK(hipblasDgemm, double, GEMMUL8_D)
+OZ2_GEMM_HOOK(hipblasCgemm, hipComplex, GEMMUL8_C)
+OZ2_GEMM_HOOK(hipblasZgemm, hipDoubleComplex, GEMMUL8_Z)
+#undef OZ2_GEMM_HOOK
+
+hipblasStatus_t hipblasGemmEx(hipblasHandle_t handle, hipblasOperation_t transA, hipblasOperation_t transB, int m, int n, int k,
+                              const void* alpha, const void* A, hipDataType aType, int lda, const void* B, hipDataType bType, int ldb,
+                              const void* beta, void* C, hipDataType cType, int ldc, hipblasComputeType_t computeType,
+                              hipblasGemmAlgo_t algo) {
+    OZ2_EARLY_OUT()
+    int dtype = -1;  // same (computeType, A/B/C type) dispatch as hook.cu:961-1030
+    const bool same = (aType == bType && bType == cType);
+    if (same && computeType == HIPBLAS_COMPUTE_32F && aType == HIP_R_32F) dtype = GEMMUL8_S;
+    else if (same && computeType == HIPBLAS_COMPUTE_64F && aType == HIP_R_64F) dtype = GEMMUL8_D;
+    else if (same && computeType == HIPBLAS_COMPUTE_32F && aType == HIP_C_32F) dtype = GEMMUL8_C;
+    else if (same && computeType == HIPBLAS_COMPUTE_64F && aType == HIP_C_64F) dtype = GEMMUL8_Z;
+    hipblasStatus_t st;
+    if (dtype >= 0 && try_emulate(dtype, handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, &st)) return st;
+    using Fn = hipblasStatus_t (*)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int, const void*, const void*,
+                                   hipDataType, int, const void*, hipDataType, int, const void*, void*, hipDataType, int,
+                                   hipblasComputeType_t, hipblasGemmAlgo_t);
+    static Fn real = real_fn<Fn>("hipblasGemmEx");
+    return real ? real(handle, transA, transB, m, n, k, alpha, A, aType, lda, B, bType, ldb, beta, C, cType, ldc, computeType, algo)
+                : HIPBLAS_STATUS_NOT_INITIALIZED;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -16,6 +16,12 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#if defined(__GNUC__)
+#define GEMMUL8_API __attribute__((visibility("default")))
+#else
+#define GEMMUL8_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -37,7 +43,7 @@ enum {
 /* Workspace bytes; same formula as the reference so callers' allocations stay valid.
  * Replaces gemmul8::workSize<is_Complex,backend> (include/gemmul8.hpp:25-35,
  * src/gemmul8_real.hpp:8-47, src/gemmul8_complex.hpp:8-47). */
-size_t gemmul8_work_size(int is_complex, int backend, size_t m, size_t n, size_t k, unsigned num_moduli,
+GEMMUL8_API size_t gemmul8_work_size(int is_complex, int backend, size_t m, size_t n, size_t k, unsigned num_moduli,
                          int enable_skip_scalA, int enable_skip_scalB, size_t *workSizeA, size_t *workSizeB);
 
 /* Whole emulated GEMM: C = alpha*op(A)*op(B) + beta*C.
@@ -46,7 +52,7 @@ size_t gemmul8_work_size(int is_complex, int backend, size_t m, size_t n, size_t
  * alpha/beta may be host or device pointers (detected like inverse_scaling_real.hpp:211-213).
  * timers_ns: NULL = fully asynchronous; else 4 doubles [scaling, low-prec GEMM, requantise (always
  * 0: fused into the GEMM epilogue), inverse scaling] in ns, measured with events (one host sync). */
-int gemmul8_gemm(void *stream, int dtype, int backend, int op_A, int op_B, size_t m, size_t n, size_t k,
+GEMMUL8_API int gemmul8_gemm(void *stream, int dtype, int backend, int op_A, int op_B, size_t m, size_t n, size_t k,
                  const void *alpha, const void *A, size_t lda, const void *B, size_t ldb, const void *beta, void *C,
                  size_t ldc, unsigned num_moduli, int fastmode, void *work, void *workA, void *workB,
                  int enable_skip_scalA, int enable_skip_scalB, int skip_scalA, int skip_scalB, double *timers_ns);
@@ -68,7 +74,7 @@ typedef struct gemmul8_layout {
     size_t scratch_bytes;
 } gemmul8_layout;
 
-int gemmul8_get_layout(int dtype, int backend, size_t m, size_t n, size_t k, unsigned num_moduli, void *work, void *workA,
+GEMMUL8_API int gemmul8_get_layout(int dtype, int backend, size_t m, size_t n, size_t k, unsigned num_moduli, void *work, void *workA,
                        void *workB, int enable_skip_scalA, int enable_skip_scalB, gemmul8_layout *out);
 
 /* ---- phase-level entry points (one per kernel family) -------------------------------------- */
@@ -77,25 +83,25 @@ int gemmul8_get_layout(int dtype, int backend, size_t m, size_t n, size_t k, uns
  * accurate path (extract, bound GEMM with max epilogue, shift).  Replaces fast::scaling /
  * accu::scaling (src/scaling_fast_real.hpp:222-268, src/scaling_accu_real.hpp:380-457 and the
  * complex variants). */
-int gemmul8_scale(void *stream, int dtype, int backend, int op_A, int op_B, size_t m, size_t n, size_t k, const void *A,
+GEMMUL8_API int gemmul8_scale(void *stream, int dtype, int backend, int op_A, int op_B, size_t m, size_t n, size_t k, const void *A,
                   size_t lda, const void *B, size_t ldb, unsigned num_moduli, int fastmode, unsigned t_begin,
                   unsigned t_end, const gemmul8_layout *L, int skipA, int skipB);
 
 /* Low-precision GEMMs of moduli [t_begin, t_end) with the requantise epilogue: fills C_mid planes.
  * Replaces gemm_low_prec_* + conv_hi2mid (src/matmult.hpp:120-389, src/conv_hi2mid_real.hpp,
  * src/conv_hi2mid_complex.hpp; loop at src/gemmul8_real.hpp:144-191). */
-int gemmul8_lowprec_gemm(void *stream, int dtype, int backend, size_t m, size_t n, size_t k, unsigned num_moduli,
+GEMMUL8_API int gemmul8_lowprec_gemm(void *stream, int dtype, int backend, size_t m, size_t n, size_t k, unsigned num_moduli,
                          unsigned t_begin, unsigned t_end, const gemmul8_layout *L);
 
 /* CRT accumulation + inverse scaling + axpby on an arbitrary column block: C_mid planes given by
  * pointer/stride so that a GPU can finish the columns it owns after an exchange of residue planes.
  * Replaces inverse_scaling (src/inverse_scaling_real.hpp:242-278, inverse_scaling_complex.hpp). */
-int gemmul8_crt(void *stream, int dtype, int backend, unsigned num_moduli, size_t m, size_t n, const void *C_mid,
+GEMMUL8_API int gemmul8_crt(void *stream, int dtype, int backend, unsigned num_moduli, size_t m, size_t n, const void *C_mid,
                 size_t ld_mid, size_t plane_stride, const int16_t *sftA, const int16_t *sftB, const void *alpha,
                 const void *beta, void *C, size_t ldc);
 
 /* Library identification (build arch, version) */
-const char *gemmul8_version(void);
+GEMMUL8_API const char *gemmul8_version(void);
 
 #ifdef __cplusplus
 }
