@@ -33,7 +33,7 @@ class Layout(C.Structure):
 _lib = None
 
 EXPORTS = ["gemmul8_version", "gemmul8_work_size", "gemmul8_gemm", "gemmul8_get_layout", "gemmul8_scale",
-           "gemmul8_lowprec_gemm", "gemmul8_crt"]
+           "gemmul8_scale_bounds", "gemmul8_scale_finish", "gemmul8_lowprec_gemm", "gemmul8_crt"]
 
 
 def _bind_hip_runtime():
@@ -81,6 +81,14 @@ def lib():
     L.gemmul8_scale.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
                                 C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint, C.c_int, C.c_uint, C.c_uint,
                                 C.POINTER(Layout), C.c_int, C.c_int]
+    L.gemmul8_scale_bounds.restype = C.c_int
+    L.gemmul8_scale_bounds.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
+                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint, C.c_size_t, C.c_size_t,
+                                       C.POINTER(Layout), C.c_int, C.c_int]
+    L.gemmul8_scale_finish.restype = C.c_int
+    L.gemmul8_scale_finish.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
+                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint, C.c_int, C.c_uint, C.c_uint,
+                                       C.POINTER(Layout), C.c_int, C.c_int]
     L.gemmul8_lowprec_gemm.restype = C.c_int
     L.gemmul8_lowprec_gemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint,
                                        C.c_uint, C.c_uint, C.POINTER(Layout)]

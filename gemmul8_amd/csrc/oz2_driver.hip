@@ -127,14 +127,53 @@ int gemmul8_get_layout(int dtype, int backend, size_t m, size_t n, size_t k, uns
     return GEMMUL8_OK;
 }
 
-int gemmul8_scale(void* stream_, int dtype, int backend, int op_A, int op_B, size_t m, size_t n, size_t k, const void* A, size_t lda,
-                  const void* B, size_t ldb, unsigned N, int fastmode, unsigned t_begin, unsigned t_end, const gemmul8_layout* L,
-                  int skipA, int skipB) {
+// scratch carving shared by the two halves of the scaling phase: rowmax int32[mp] | colmax int32[pad(n)] | amax bits
+static int scale_scratch(const gemmul8_layout* L, size_t n, int** rowmax, int** colmax, void** amax) {
+    const size_t np = padding256(n);
+    const size_t need = 4 * L->mp + 4 * np + 8 * std::max(L->mp, np);
+    if (L->scratch_bytes < need) return GEMMUL8_E_ARG;
+    *rowmax = (int*)L->scratch;
+    *colmax = *rowmax + L->mp;
+    *amax = (void*)(*colmax + np);
+    return GEMMUL8_OK;
+}
+
+int gemmul8_scale_bounds(void* stream_, int dtype, int backend, int op_A, int op_B, size_t m, size_t n, size_t k, const void* A,
+                         size_t lda, const void* B, size_t ldb, unsigned N, size_t col_begin, size_t col_end, const gemmul8_layout* L,
+                         int skipA, int skipB) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!L || !A || !B) return GEMMUL8_E_ARG;
+    if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
+    if (backend != kINT8 || is_complex(dtype)) return GEMMUL8_E_UNSUPPORTED;
+    op_A = norm_op(op_A);
+    op_B = norm_op(op_B);
+    if (op_A < 0 || op_A > 2 || op_B < 0 || op_B > 2 || col_begin > col_end || col_end > n) return GEMMUL8_E_ARG;
+    if (skipA && skipB) return GEMMUL8_OK;
+    const bool cplx = is_complex(dtype);
+    const bool kmajA = op_A != 0, kmajB = op_B == 0;
+    const bool conjA = cplx && op_A == 2, conjB = cplx && op_B == 2;
+    int *rowmax, *colmax;
+    void* amax;
+    int rc = scale_scratch(L, n, &rowmax, &colmax, &amax);
+    if (rc) return rc;
+    const size_t np = padding256(n);
+    const size_t bstrideA = cplx ? L->sizeA : 0, bstrideB = cplx ? L->sizeB : 0;
+    if (!skipA) OZ2_HIP(launch_extract(stream, dtype, backend, kmajA, conjA, m, k, A, lda, (int8_t*)L->A_bound, bstrideA, L->kp, L->sftA, amax));
+    if (!skipB) OZ2_HIP(launch_extract(stream, dtype, backend, kmajB, conjB, n, k, B, ldb, (int8_t*)L->B_bound, bstrideB, L->kp, L->sftB, amax));
+    OZ2_HIP(hipMemsetAsync(rowmax, 0, 4 * (L->mp + np), stream));
+    if (col_end > col_begin)
+        OZ2_HIP(launch_gemm_i8_max(stream, (const int8_t*)L->A_bound, (const int8_t*)L->B_bound + col_begin * L->kp, L->kp, m,
+                                   col_end - col_begin, rowmax, colmax + col_begin));
+    return GEMMUL8_OK;
+}
+
+int gemmul8_scale_finish(void* stream_, int dtype, int backend, int op_A, int op_B, size_t m, size_t n, size_t k, const void* A,
+                         size_t lda, const void* B, size_t ldb, unsigned N, int fastmode, unsigned t_begin, unsigned t_end,
+                         const gemmul8_layout* L, int skipA, int skipB) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!L || !A || !B) return GEMMUL8_E_ARG;
     if (N < 2 || N > 20 || t_end > N || t_begin > t_end) return GEMMUL8_E_NUM_MODULI;
-    if (backend != kINT8) return GEMMUL8_E_UNSUPPORTED;
-    if (is_complex(dtype)) return GEMMUL8_E_UNSUPPORTED;
+    if (backend != kINT8 || is_complex(dtype)) return GEMMUL8_E_UNSUPPORTED;
     op_A = norm_op(op_A);
     op_B = norm_op(op_B);
     if (op_A < 0 || op_A > 2 || op_B < 0 || op_B > 2) return GEMMUL8_E_ARG;
@@ -142,35 +181,34 @@ int gemmul8_scale(void* stream_, int dtype, int backend, int op_A, int op_B, siz
     const bool cplx = is_complex(dtype);
     const bool kmajA = op_A != 0, kmajB = op_B == 0;
     const bool conjA = cplx && op_A == 2, conjB = cplx && op_B == 2;
-    int8_t* A_lo = (int8_t*)L->A_lo;
-    int8_t* B_lo = (int8_t*)L->B_lo;
-
     if (fastmode) {
         if (!skipA) OZ2_HIP(launch_fast_shift(stream, dtype, backend, N, kmajA, m, k, A, lda, L->sftA));
         if (!skipB) OZ2_HIP(launch_fast_shift(stream, dtype, backend, N, kmajB, n, k, B, ldb, L->sftB));
     } else {
-        // scratch: rowmax int32[mp] | colmax int32[pad(n)] | amax bits
-        const size_t np = padding256(n);
-        const size_t need = 4 * L->mp + 4 * np + 8 * std::max(L->mp, np);
-        if (L->scratch_bytes < need) return GEMMUL8_E_ARG;
-        int* rowmax = (int*)L->scratch;
-        int* colmax = rowmax + L->mp;
-        void* amax = (void*)(colmax + np);
-        const size_t bstrideA = cplx ? L->sizeA : 0, bstrideB = cplx ? L->sizeB : 0;
-        if (!skipA) OZ2_HIP(launch_extract(stream, dtype, backend, kmajA, conjA, m, k, A, lda, (int8_t*)L->A_bound, bstrideA, L->kp, L->sftA, amax));
-        if (!skipB) OZ2_HIP(launch_extract(stream, dtype, backend, kmajB, conjB, n, k, B, ldb, (int8_t*)L->B_bound, bstrideB, L->kp, L->sftB, amax));
-        OZ2_HIP(hipMemsetAsync(rowmax, 0, 4 * (L->mp + np), stream));
-        OZ2_HIP(launch_gemm_i8_max(stream, (const int8_t*)L->A_bound, (const int8_t*)L->B_bound, L->kp, m, n, rowmax, colmax));
+        int *rowmax, *colmax;
+        void* amax;
+        int rc = scale_scratch(L, n, &rowmax, &colmax, &amax);
+        if (rc) return rc;
         if (!skipA) OZ2_HIP(launch_shift_finalize(stream, backend, N, m, rowmax, L->sftA));
         if (!skipB) OZ2_HIP(launch_shift_finalize(stream, backend, N, n, colmax, L->sftB));
     }
     if (!skipA)
-        OZ2_HIP(launch_quantise(stream, dtype, backend, N, (int)t_begin, (int)t_end, kmajA, conjA, m, k, A, lda, L->sftA, A_lo, L->sizeA,
-                                L->part_strideA, L->kp));
+        OZ2_HIP(launch_quantise(stream, dtype, backend, N, (int)t_begin, (int)t_end, kmajA, conjA, m, k, A, lda, L->sftA, (int8_t*)L->A_lo,
+                                L->sizeA, L->part_strideA, L->kp));
     if (!skipB)
-        OZ2_HIP(launch_quantise(stream, dtype, backend, N, (int)t_begin, (int)t_end, kmajB, conjB, n, k, B, ldb, L->sftB, B_lo, L->sizeB,
-                                L->part_strideB, L->kp));
+        OZ2_HIP(launch_quantise(stream, dtype, backend, N, (int)t_begin, (int)t_end, kmajB, conjB, n, k, B, ldb, L->sftB, (int8_t*)L->B_lo,
+                                L->sizeB, L->part_strideB, L->kp));
     return GEMMUL8_OK;
+}
+
+int gemmul8_scale(void* stream_, int dtype, int backend, int op_A, int op_B, size_t m, size_t n, size_t k, const void* A, size_t lda,
+                  const void* B, size_t ldb, unsigned N, int fastmode, unsigned t_begin, unsigned t_end, const gemmul8_layout* L,
+                  int skipA, int skipB) {
+    if (!fastmode) {
+        int rc = gemmul8_scale_bounds(stream_, dtype, backend, op_A, op_B, m, n, k, A, lda, B, ldb, N, 0, n, L, skipA, skipB);
+        if (rc) return rc;
+    }
+    return gemmul8_scale_finish(stream_, dtype, backend, op_A, op_B, m, n, k, A, lda, B, ldb, N, fastmode, t_begin, t_end, L, skipA, skipB);
 }
 
 int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t n, size_t k, unsigned N, unsigned t_begin,

@@ -87,6 +87,19 @@ GEMMUL8_API int gemmul8_scale(void *stream, int dtype, int backend, int op_A, in
                   size_t lda, const void *B, size_t ldb, unsigned num_moduli, int fastmode, unsigned t_begin,
                   unsigned t_end, const gemmul8_layout *L, int skipA, int skipB);
 
+/* The two halves of gemmul8_scale, split where a multi-GPU run must exchange data:
+ *  _bounds (accurate mode only): 7-bit bound planes of A and B, then the bound GEMM restricted to
+ *          columns [col_begin, col_end) of op(B); leaves int32 rowmax[mp] at L->scratch and colmax[pad256(n)]
+ *          right behind it (zero outside the computed columns) -- ranks combine them with one
+ *          all-reduce(MAX) over the (mp + pad256(n)) int32 words;
+ *  _finish: final shifts (from the maxima, or the fast-mode norms) and the residue planes. */
+GEMMUL8_API int gemmul8_scale_bounds(void *stream, int dtype, int backend, int op_A, int op_B, size_t m, size_t n, size_t k,
+                                     const void *A, size_t lda, const void *B, size_t ldb, unsigned num_moduli, size_t col_begin,
+                                     size_t col_end, const gemmul8_layout *L, int skipA, int skipB);
+GEMMUL8_API int gemmul8_scale_finish(void *stream, int dtype, int backend, int op_A, int op_B, size_t m, size_t n, size_t k,
+                                     const void *A, size_t lda, const void *B, size_t ldb, unsigned num_moduli, int fastmode,
+                                     unsigned t_begin, unsigned t_end, const gemmul8_layout *L, int skipA, int skipB);
+
 /* Low-precision GEMMs of moduli [t_begin, t_end) with the requantise epilogue: fills C_mid planes.
  * Replaces gemm_low_prec_* + conv_hi2mid (src/matmult.hpp:120-389, src/conv_hi2mid_real.hpp,
  * src/conv_hi2mid_complex.hpp; loop at src/gemmul8_real.hpp:144-191). */

@@ -283,40 +283,52 @@ static int accu_shift_from_max_f32(float amax, float log2P) {
     return (int)floorf(fmaf_dir(-0x1.000006p-1f, l, log2P, FE_DOWNWARD));
 }
 
-/* sftA/sftB in: sft0 from oz2_extract; out: NEGATED final shifts. rmax/cmax optional outputs. */
+/* INT8 bound GEMM restricted to columns [c0,c1): rowmax[m] (max-combined into the given array) and
+ * colmax[n] entries c0..c1-1.  Arrays must be zero-initialised by the caller (multi-GPU ranks
+ * combine their partial arrays with an element-wise max). */
+void oz2_bound_maxima_i8(int cplx, size_t m, size_t n, size_t k, const uint8_t *Abar, const uint8_t *Bbar, size_t c0, size_t c1,
+                         int32_t *rmax, int32_t *cmax) {
+    const size_t pa = m * k, pb = n * k;
+    for (size_t j = c0; j < c1; ++j)
+        for (size_t i = 0; i < m; ++i) {
+            int32_t v;
+            if (!cplx) {
+                int32_t s = 0;
+                const int8_t *a = (const int8_t *)Abar + i * k, *b = (const int8_t *)Bbar + j * k;
+                for (size_t kk = 0; kk < k; ++kk) s += (int32_t)a[kk] * b[kk];
+                v = s;
+            } else {
+                /* C1 = Ar*Bi + Ai*Br ; C0 = (Ar-Ai)*(Br-Bi) ; bounds: max(C0+C1, C1) */
+                const int8_t *ar = (const int8_t *)Abar + i * k, *ai = ar + pa, *ad = ai + pa;
+                const int8_t *br = (const int8_t *)Bbar + j * k, *bi = br + pb, *bd = bi + pb;
+                int32_t cc0 = 0, cc1 = 0;
+                for (size_t kk = 0; kk < k; ++kk) {
+                    cc1 += (int32_t)ar[kk] * bi[kk] + (int32_t)ai[kk] * br[kk];
+                    cc0 += (int32_t)ad[kk] * bd[kk];
+                }
+                int32_t t3 = cc0 + cc1;
+                v = t3 > cc1 ? t3 : cc1;
+            }
+            if (v > rmax[i]) rmax[i] = v;
+            if (v > cmax[j]) cmax[j] = v;
+        }
+}
+/* sft: in sft0 (oz2_extract), out NEGATED final shift = -(sft0 + f(max)) */
+void oz2_shift_finalize_i8(int backend, unsigned N, size_t rows, const int32_t *maxv, int16_t *sft) {
+    const float log2P = log2P_of(backend, N);
+    for (size_t i = 0; i < rows; ++i) sft[i] = (int16_t)(-(sft[i] + accu_shift_from_max_i32(maxv[i], log2P)));
+}
+
+/* sftA/sftB in: sft0 from oz2_extract; out: NEGATED final shifts. */
 void oz2_bound_shifts(int backend, int cplx, unsigned N, size_t m, size_t n, size_t k, const uint8_t *Abar,
                       const uint8_t *Bbar, int16_t *sftA, int16_t *sftB, int update_A, int update_B) {
     const float log2P = log2P_of(backend, N);
     const size_t pa = m * k, pb = n * k;
     if (backend == OZ_INT8) {
         int32_t *rmax = calloc(m, 4), *cmax = calloc(n, 4);
-        for (size_t j = 0; j < n; ++j)
-            for (size_t i = 0; i < m; ++i) {
-                int32_t v;
-                if (!cplx) {
-                    int32_t s = 0;
-                    const int8_t *a = (const int8_t *)Abar + i * k, *b = (const int8_t *)Bbar + j * k;
-                    for (size_t kk = 0; kk < k; ++kk) s += (int32_t)a[kk] * b[kk];
-                    v = s;
-                } else {
-                    /* C1 = Ar*Bi + Ai*Br ; C0 = (Ar-Ai)*(Br-Bi) ; bounds: max(C0+C1, C1) */
-                    const int8_t *ar = (const int8_t *)Abar + i * k, *ai = ar + pa, *ad = ai + pa;
-                    const int8_t *br = (const int8_t *)Bbar + j * k, *bi = br + pb, *bd = bi + pb;
-                    int32_t c0 = 0, c1 = 0;
-                    for (size_t kk = 0; kk < k; ++kk) {
-                        c1 += (int32_t)ar[kk] * bi[kk] + (int32_t)ai[kk] * br[kk];
-                        c0 += (int32_t)ad[kk] * bd[kk];
-                    }
-                    int32_t t3 = c0 + c1;
-                    v = t3 > c1 ? t3 : c1;
-                }
-                if (v > rmax[i]) rmax[i] = v;
-                if (v > cmax[j]) cmax[j] = v;
-            }
-        if (update_A)
-            for (size_t i = 0; i < m; ++i) sftA[i] = (int16_t)(-(sftA[i] + accu_shift_from_max_i32(rmax[i], log2P)));
-        if (update_B)
-            for (size_t j = 0; j < n; ++j) sftB[j] = (int16_t)(-(sftB[j] + accu_shift_from_max_i32(cmax[j], log2P)));
+        oz2_bound_maxima_i8(cplx, m, n, k, Abar, Bbar, 0, n, rmax, cmax);
+        if (update_A) oz2_shift_finalize_i8(backend, N, m, rmax, sftA);
+        if (update_B) oz2_shift_finalize_i8(backend, N, n, cmax, sftB);
         free(rmax);
         free(cmax);
     } else {

@@ -1,0 +1,56 @@
+"""-m gpu: the moduli-sharded driver with the REAL HipEngine, two ranks sharing cuda:0 (gloo, host-staged
+exchange -- the GPU box has one GPU; the 8-GPU run uses the same code with NCCL/RCCL).  The assembled
+result must be bit-identical to the single-GPU C-ABI result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, N, fast, m, n, k, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gemmul8_amd as g
+        from gemmul8_amd import dist as gd
+        torch.cuda.set_device(0)
+        rng = np.random.default_rng(4)
+        A = torch.from_numpy(rng.random((k, m)) - 0.5).cuda()  # (cols, rows) = column-major m x k
+        B = torch.from_numpy(rng.random((n, k)) - 0.5).cuda()
+        Cm = torch.zeros((n, m), dtype=torch.float64, device="cuda")
+        plan = gd.ShardedGemm(g.D, g.INT8, m, n, k, N, fastmode=fast, device=torch.device("cuda", 0))
+        plan.run(A, B, Cm)
+        torch.cuda.synchronize()
+        full = plan.gather_result(Cm)
+        if rank == 0:
+            ref, _, _ = g.gemm(A, B, N, fastmode=fast)
+            torch.cuda.synchronize()
+            q.put(bool(torch.equal(full, ref)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,fast", [(14, False), (15, True)])
+def test_two_ranks_one_gpu_bitwise(N, fast):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    m, n, k = 300, 515, 1000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, N, fast, m, n, k, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get(timeout=10)
