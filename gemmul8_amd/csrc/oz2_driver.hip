@@ -144,7 +144,7 @@ int gemmul8_scale_bounds(void* stream_, int dtype, int backend, int op_A, int op
     hipStream_t stream = (hipStream_t)stream_;
     if (!L || !A || !B) return GEMMUL8_E_ARG;
     if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
-    if (backend != kINT8 || is_complex(dtype)) return GEMMUL8_E_UNSUPPORTED;
+    if (backend != kINT8) return GEMMUL8_E_UNSUPPORTED;
     op_A = norm_op(op_A);
     op_B = norm_op(op_B);
     if (op_A < 0 || op_A > 2 || op_B < 0 || op_B > 2 || col_begin > col_end || col_end > n) return GEMMUL8_E_ARG;
@@ -161,9 +161,23 @@ int gemmul8_scale_bounds(void* stream_, int dtype, int backend, int op_A, int op
     if (!skipA) OZ2_HIP(launch_extract(stream, dtype, backend, kmajA, conjA, m, k, A, lda, (int8_t*)L->A_bound, bstrideA, L->kp, L->sftA, amax));
     if (!skipB) OZ2_HIP(launch_extract(stream, dtype, backend, kmajB, conjB, n, k, B, ldb, (int8_t*)L->B_bound, bstrideB, L->kp, L->sftB, amax));
     OZ2_HIP(hipMemsetAsync(rowmax, 0, 4 * (L->mp + np), stream));
-    if (col_end > col_begin)
-        OZ2_HIP(launch_gemm_i8_max(stream, (const int8_t*)L->A_bound, (const int8_t*)L->B_bound + col_begin * L->kp, L->kp, m,
-                                   col_end - col_begin, rowmax, colmax + col_begin));
+    if (col_end > col_begin) {
+        const int8_t* Ab = (const int8_t*)L->A_bound;
+        const int8_t* Bb = (const int8_t*)L->B_bound + col_begin * L->kp;
+        if (!cplx) {
+            const int8_t* As[1] = {Ab};
+            const int8_t* Bs[1] = {Bb};
+            OZ2_HIP(launch_gemm_i8_max(stream, 1, As, Bs, L->kp, m, col_end - col_begin, rowmax, colmax + col_begin));
+        } else {
+            // bound planes: 0 = |Re|, 1 = |Im|, 2 = |Re|-|Im| (scaling_accu_complex.hpp:441-460, find_max.hpp:99-114):
+            //   C1 = ArBi + AiBr (K-concatenation of two products), C1 + C0 = ArBr + AiBi with C0 = (Ar-Ai)(Br-Bi);
+            //   the maxima of both matrices accumulate into the same rowmax/colmax.
+            const int8_t* As[3] = {Ab, Ab + L->sizeA, Ab + 2 * L->sizeA};
+            const int8_t* Bs[3] = {Bb + L->sizeB, Bb, Bb + 2 * L->sizeB};
+            OZ2_HIP(launch_gemm_i8_max(stream, 2, As, Bs, L->kp, m, col_end - col_begin, rowmax, colmax + col_begin));
+            OZ2_HIP(launch_gemm_i8_max(stream, 3, As, Bs, L->kp, m, col_end - col_begin, rowmax, colmax + col_begin));
+        }
+    }
     return GEMMUL8_OK;
 }
 
@@ -173,7 +187,7 @@ int gemmul8_scale_finish(void* stream_, int dtype, int backend, int op_A, int op
     hipStream_t stream = (hipStream_t)stream_;
     if (!L || !A || !B) return GEMMUL8_E_ARG;
     if (N < 2 || N > 20 || t_end > N || t_begin > t_end) return GEMMUL8_E_NUM_MODULI;
-    if (backend != kINT8 || is_complex(dtype)) return GEMMUL8_E_UNSUPPORTED;
+    if (backend != kINT8) return GEMMUL8_E_UNSUPPORTED;
     op_A = norm_op(op_A);
     op_B = norm_op(op_B);
     if (op_A < 0 || op_A > 2 || op_B < 0 || op_B > 2) return GEMMUL8_E_ARG;
@@ -217,9 +231,32 @@ int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t
     (void)k;
     if (!L) return GEMMUL8_E_ARG;
     if (N < 2 || N > 20 || t_end > N || t_begin > t_end) return GEMMUL8_E_NUM_MODULI;
-    if (backend != kINT8 || is_complex(dtype)) return GEMMUL8_E_UNSUPPORTED;
-    OZ2_HIP(launch_gemm_i8_mod(stream, (const int8_t*)L->A_lo, (const int8_t*)L->B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)t_begin,
-                               (int)t_end, (int8_t*)L->C_mid, L->mp, L->sizeC));
+    if (backend != kINT8) return GEMMUL8_E_UNSUPPORTED;
+    const int8_t* A_lo = (const int8_t*)L->A_lo;
+    const int8_t* B_lo = (const int8_t*)L->B_lo;
+    if (!is_complex(dtype)) {
+        OZ2_HIP(launch_gemm_i8_mod(stream, A_lo, B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)t_begin, (int)t_end,
+                                   (int8_t*)L->C_mid + (size_t)t_begin * L->sizeC, L->mp, L->sizeC));
+        return GEMMUL8_OK;
+    }
+    // complex (gemmul8_complex.hpp:154-206, conv_hi2mid_complex.hpp:9-127): per modulus X = ArBr, Y = AiBi,
+    // Z = (Ar+Ai)(Br+Bi).  The residues of X and Y go to scratch planes (the reference's C_hi region), the Z GEMM
+    // combines them in its epilogue into the interleaved (Cr, Ci) plane.  Moduli are chunked to the scratch size.
+    const size_t per_mod = 2 * L->sizeC;
+    size_t chunk = L->scratch_bytes / per_mod;
+    if (chunk == 0) return GEMMUL8_E_ARG;
+    int8_t* rx = (int8_t*)L->scratch;
+    for (unsigned t0 = t_begin; t0 < t_end; t0 += (unsigned)chunk) {
+        const unsigned t1 = std::min<unsigned>(t_end, t0 + (unsigned)chunk);
+        int8_t* ry = rx + (size_t)(t1 - t0) * L->sizeC;
+        OZ2_HIP(launch_gemm_i8_mod(stream, A_lo + (size_t)t0 * L->sizeA, B_lo + (size_t)t0 * L->sizeB, L->sizeA, L->sizeB, L->kp, m, n,
+                                   (int)t0, (int)t1, rx, L->mp, L->sizeC));
+        OZ2_HIP(launch_gemm_i8_mod(stream, A_lo + L->part_strideA + (size_t)t0 * L->sizeA, B_lo + L->part_strideB + (size_t)t0 * L->sizeB,
+                                   L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1, ry, L->mp, L->sizeC));
+        OZ2_HIP(launch_gemm_i8_cplx(stream, A_lo + 2 * L->part_strideA + (size_t)t0 * L->sizeA,
+                                    B_lo + 2 * L->part_strideB + (size_t)t0 * L->sizeB, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1, rx,
+                                    ry, L->sizeC, (int8_t*)L->C_mid + (size_t)t0 * 2 * L->sizeC, L->mp, 2 * L->sizeC));
+    }
     return GEMMUL8_OK;
 }
 

@@ -23,9 +23,12 @@ ModTable make_mod_table(int backend);
 
 // ---- INT8 MFMA GEMM (oz2_gemm_i8.hip)
 hipError_t launch_gemm_i8_mod(hipStream_t stream, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp, size_t m,
-                              size_t n, int t_begin, int t_end, int8_t* Cmid, size_t ldc, size_t strideC);
-hipError_t launch_gemm_i8_max(hipStream_t stream, const int8_t* A, const int8_t* B, size_t kp, size_t m, size_t n, int* rowmax,
-                              int* colmax);
+                              size_t n, int t_begin, int t_end, int8_t* out, size_t ldo, size_t strideO);
+hipError_t launch_gemm_i8_cplx(hipStream_t stream, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp, size_t m,
+                               size_t n, int t_begin, int t_end, const int8_t* rx, const int8_t* ry, size_t strideR, int8_t* out,
+                               size_t ldo, size_t strideO);
+hipError_t launch_gemm_i8_max(hipStream_t stream, int nseg, const int8_t* const* A, const int8_t* const* B, size_t kp, size_t m, size_t n,
+                              int* rowmax, int* colmax);
 
 // ---- scale / quantise (oz2_scale.hip).  An operand has `rows` logical rows (m for A, n for B) of
 // length k; K-major: element (r,kk) at X[r*ld+kk]; row-strided: X[kk*ld+r].  lo planes are

@@ -85,3 +85,41 @@ def test_config1_sgemm_256_moduli2():
     B = (np.random.default_rng(54321).random((256, 256)) - 0.5).astype(np.float32)
     for fast in (True, False):
         gu.parity_case(A, B, 2, fast)
+
+
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+@pytest.mark.parametrize("fast", [False, True])
+@pytest.mark.parametrize("N", [2, 7, 13, 16, 20])
+def test_parity_small_complex(dtype, fast, N):
+    import gpu_util as gu
+    if dtype == np.complex64 and N > 13:
+        pytest.skip("complex-float documented for N<=13")
+    rng = np.random.default_rng(7000 + 10 * N + fast)
+    m, n, k = 37, 41, 300
+    A, B = rand((m, k), dtype, rng), rand((k, n), dtype, rng)
+    A[5, :] = 0
+    B[:, 7] = 0
+    gu.parity_case(A, B, N, fast)
+
+
+@pytest.mark.parametrize("opA,opB", [("N", "N"), ("T", "N"), ("N", "C"), ("C", "T"), ("C", "C")])
+def test_parity_complex_ops_axpby(opA, opB):
+    """complex op(N/T/C) x (alpha,beta) pairs of debug/test.cu:106-141 (incl. -1.5+1.2i, 1.5+1.2i)."""
+    import gpu_util as gu
+    rng = np.random.default_rng(11)
+    m, n, k = 45, 33, 47
+    A = rand((m, k) if opA == "N" else (k, m), np.complex128, rng)
+    B = rand((k, n) if opB == "N" else (n, k), np.complex128, rng)
+    C0 = rand((m, n), np.complex128, rng)
+    for alpha, beta in ((1, 0), (1, 1), (-1, 0), (-1, 1), (-1.5 + 1.2j, 1.5 + 1.2j)):
+        gu.parity_case(A, B, 15, False, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0)
+    gu.parity_case(A, B, 12, True, opA=opA, opB=opB, alpha=-1.5 + 1.2j, beta=1.5 + 1.2j, C0=C0)
+
+
+def test_parity_complex_shapes():
+    import gpu_util as gu
+    rng = np.random.default_rng(99)
+    for (m, n, k) in [(256, 256, 256), (300, 520, 700), (1, 1, 1), (513, 255, 1025)]:
+        A, B = rand((m, k), np.complex128, rng), rand((k, n), np.complex128, rng)
+        gu.parity_case(A, B, 20, False)
+        gu.parity_case(A, B, 9, True)
