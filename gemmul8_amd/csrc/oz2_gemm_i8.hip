@@ -36,22 +36,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "oz2_gemm_common.hpp"
 #include "oz2_kernels.h"
 
 namespace oz2 {
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-
-constexpr int BM = 256, BN = 256, BK = 128;
-constexpr int TILE_BYTES = BM * BK;          // 32 KiB per operand per stage
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // A + B
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;   // two stages = 128 KiB
-constexpr int WS_THREADS = 768;              // 8 consumer + 4 producer waves
-#ifndef OZ2_PSLOTS
-#define OZ2_PSLOTS 4
-#endif
-constexpr int PSLOTS = OZ2_PSLOTS;  // slots (of 8 per K-step) over which a producer spreads its 16 DMA instructions
 
 enum { EPI_MOD = 0, EPI_MAX = 1, EPI_CPLX = 2 };
 
@@ -84,68 +72,18 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---- XCD-aware tile mapping: block b runs on XCD b%8; give each XCD a contiguous tile range
-    const int tiles_per_plane = args.tiles_m * args.tiles_n;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int plane = bid / tiles_per_plane;
-    int rem = bid - plane * tiles_per_plane;
-    constexpr int GM = 8;  // grouped ordering: 8 tile-rows per group, tile-row fastest inside a group
-    const int group_sz = GM * args.tiles_n;
-    const int g = rem / group_sz;
-    const int first_m = g * GM;
-    const int gm = (args.tiles_m - first_m) < GM ? (args.tiles_m - first_m) : GM;
-    rem -= g * group_sz;
-    const int tm = first_m + rem % gm;
-    const int tn = rem / gm;
-
+    const TileMap tmap = map_tile(args.tiles_m, args.tiles_n);
+    const int plane = tmap.plane, tm = tmap.tm, tn = tmap.tn;
     const size_t offA = (size_t)plane * args.strideA + (size_t)tm * BM * args.kp;
     const size_t offB = (size_t)plane * args.strideB + (size_t)tn * BN * args.kp;
     const int nB_valid = (args.n - tn * BN) < BN ? (args.n - tn * BN) : BN;
     const int KT1 = args.kp / BK;        // K-steps per segment
     const int KT = KT1 * args.nseg;      // total K-steps
 
-    if (wave >= 8) {
-        // ------------------------------ producer wave pw = 0..3: DMA instructions q = pw*16 .. pw*16+15 of each tile.
-        // 4096 16-byte slots per stage: slot p <-> operand (p>=2048: B), row = (p&2047)>>3, physical chunk = p&7,
-        // logical chunk = physical ^ ((row>>1)&7).
-        const int pw = wave - 8;
-        auto issue = [&](int kt, int q, char* stage) {
-            const int seg = kt / KT1;
-            const int kin = kt - seg * KT1;
-            const int p = (pw * 16 + q) * 64 + lane;
-            const bool isB = p >= 2048;
-            const int pp = p & 2047;
-            int row = pp >> 3;
-            const int c = (pp & 7) ^ ((row >> 1) & 7);
-            if (isB) row = row < nB_valid ? row : nB_valid - 1;  // B planes have exactly n rows: clamp instead of padding
-            const int8_t* src = (isB ? args.B[seg] + offB : args.A[seg] + offA) + (size_t)row * args.kp + (size_t)kin * BK + c * 16;
-            char* dst = stage + ((pw * 16 + q) * 64) * 16;  // wave-uniform; the hardware adds lane*16
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst,
-                                             16, 0, 0);
-        };
-#pragma unroll
-        for (int q = 0; q < 16; ++q) issue(0, q, smem);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        for (int kt = 0; kt < KT; ++kt) {
-            char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
-            const bool more = kt + 1 < KT;
-#pragma unroll
-            for (int sl = 0; sl < 8; ++sl) {
-                if (sl < PSLOTS && more) {
-#pragma unroll
-                    for (int q = 0; q < 16 / PSLOTS; ++q) issue(kt + 1, sl * (16 / PSLOTS) + q, nxt);
-                }
-                if (sl == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-        }
-        __builtin_amdgcn_s_barrier();
+    if (wave >= 8) {  // ------------------------------ producer waves: LDS-DMA only
+        const int8_t* const gA[3] = {args.A[0] + offA, args.A[1] + offA, args.A[2] + offA};
+        const int8_t* const gB[3] = {args.B[0] + offB, args.B[1] + offB, args.B[2] + offB};
+        producer_loop(gA, gB, args.kp, KT1, KT, nB_valid, smem, wave - 8, lane);
         return;
     }
 
