@@ -115,4 +115,36 @@ __device__ __forceinline__ int mod_i32_sym(int a, int p, int pinv32) {
     return wrapping(rem, p);
 }
 
+// ---------------------------------------------------------------- OCP FP8 e4m3 helpers (FP8 backend)
+// two small integers (|v| <= 16, exactly representable) -> two e4m3 bytes in the low half of the result
+__device__ __forceinline__ unsigned fp8x2_from_ints(int a, int b) {
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32((float)a, (float)b, 0, false) & 0xFFFFu;
+}
+// smallest e4m3 value >= a for 0 <= a < 448 (restates fp8_e4m3_ru, scaling.hpp:48-54: RN conversion, then
+// one encoding step up if the result fell below a)
+template <typename U> __device__ __forceinline__ unsigned fp8_round_up(U a) {
+    unsigned r = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32((float)a, 0.0f, 0, false) & 0xFFu;
+    const float y = __builtin_amdgcn_cvt_f32_fp8((int)r, 0);
+    return r + ((U)y < a ? 1u : 0u);
+}
+__device__ __forceinline__ float fp8_to_float(unsigned byte) { return __builtin_amdgcn_cvt_f32_fp8((int)byte, 0); }
+
+// FP8 residue splitting (mod.hpp:159-189).  Square moduli p = s^2 (t < 6): a = s*hi + lo, hi = rint(a/s);
+// otherwise a = 16*hi + lo with hi = sign(a)*ceil(|a|/16) and a third value hi + lo.
+// (hi keeps the sign of zero: rintf(-0.09) = -0.0f is stored as the e4m3 byte 0x80, exactly like the reference)
+__device__ __forceinline__ void fp8_split_sq(int a, int s, float inv_s, float& hi, float& lo) {
+    const float af = (float)a;
+    hi = rintf(af * inv_s);
+    lo = fmaf(-(float)s, hi, af);
+}
+__device__ __forceinline__ unsigned fp8x2_from_floats(float a, float b) {
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xFFFFu;
+}
+__device__ __forceinline__ void fp8_split_kara(int a, int& hi, int& lo) {
+    const unsigned absu = (unsigned)(a < 0 ? -a : a);
+    const int q = (int)((absu + 15u) >> 4);
+    hi = a < 0 ? -q : q;
+    lo = a - 16 * hi;
+}
+
 }  // namespace oz2

@@ -144,7 +144,8 @@ int gemmul8_scale_bounds(void* stream_, int dtype, int backend, int op_A, int op
     hipStream_t stream = (hipStream_t)stream_;
     if (!L || !A || !B) return GEMMUL8_E_ARG;
     if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
-    if (backend != kINT8) return GEMMUL8_E_UNSUPPORTED;
+    if (backend == kFP8 && is_complex(dtype)) return GEMMUL8_E_UNSUPPORTED;  // FP8 complex (9 GEMMs / modulus): not built yet
+    if (backend == kFP8 && k > 65536) return GEMMUL8_E_ARG;                  // exact FP32 accumulation needs k*16*16 <= 2^24
     op_A = norm_op(op_A);
     op_B = norm_op(op_B);
     if (op_A < 0 || op_A > 2 || op_B < 0 || op_B > 2 || col_begin > col_end || col_end > n) return GEMMUL8_E_ARG;
@@ -164,7 +165,9 @@ int gemmul8_scale_bounds(void* stream_, int dtype, int backend, int op_A, int op
     if (col_end > col_begin) {
         const int8_t* Ab = (const int8_t*)L->A_bound;
         const int8_t* Bb = (const int8_t*)L->B_bound + col_begin * L->kp;
-        if (!cplx) {
+        if (backend == kFP8) {
+            OZ2_HIP(launch_gemm_f8_max(stream, Ab, Bb, L->kp, k, m, col_end - col_begin, rowmax, colmax + col_begin));
+        } else if (!cplx) {
             const int8_t* As[1] = {Ab};
             const int8_t* Bs[1] = {Bb};
             OZ2_HIP(launch_gemm_i8_max(stream, 1, As, Bs, L->kp, m, col_end - col_begin, rowmax, colmax + col_begin));
@@ -187,7 +190,8 @@ int gemmul8_scale_finish(void* stream_, int dtype, int backend, int op_A, int op
     hipStream_t stream = (hipStream_t)stream_;
     if (!L || !A || !B) return GEMMUL8_E_ARG;
     if (N < 2 || N > 20 || t_end > N || t_begin > t_end) return GEMMUL8_E_NUM_MODULI;
-    if (backend != kINT8) return GEMMUL8_E_UNSUPPORTED;
+    if (backend == kFP8 && is_complex(dtype)) return GEMMUL8_E_UNSUPPORTED;
+    if (backend == kFP8 && k > 65536) return GEMMUL8_E_ARG;
     op_A = norm_op(op_A);
     op_B = norm_op(op_B);
     if (op_A < 0 || op_A > 2 || op_B < 0 || op_B > 2) return GEMMUL8_E_ARG;
@@ -231,9 +235,26 @@ int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t
     (void)k;
     if (!L) return GEMMUL8_E_ARG;
     if (N < 2 || N > 20 || t_end > N || t_begin > t_end) return GEMMUL8_E_NUM_MODULI;
-    if (backend != kINT8) return GEMMUL8_E_UNSUPPORTED;
     const int8_t* A_lo = (const int8_t*)L->A_lo;
     const int8_t* B_lo = (const int8_t*)L->B_lo;
+    if (backend == kFP8) {
+        if (is_complex(dtype)) return GEMMUL8_E_UNSUPPORTED;
+        // three e4m3 GEMMs per modulus (gemmul8_real.hpp:159-181); the residues of the first two wait in int16 scratch planes
+        // (the reference's C_hi region) for the third one's epilogue.  Moduli are chunked to the scratch size.
+        const size_t per_mod = 2 * 2 * L->sizeC;
+        const size_t chunk = L->scratch_bytes / per_mod;
+        if (chunk == 0) return GEMMUL8_E_ARG;
+        int16_t* r0 = (int16_t*)L->scratch;
+        for (unsigned t0 = t_begin; t0 < t_end; t0 += (unsigned)chunk) {
+            const unsigned t1 = std::min<unsigned>(t_end, t0 + (unsigned)chunk);
+            int16_t* r1 = r0 + (size_t)(t1 - t0) * L->sizeC;
+            OZ2_HIP(launch_gemm_f8(stream, 0, A_lo, B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1, r0, L->mp, L->sizeC, nullptr, nullptr, 0));
+            OZ2_HIP(launch_gemm_f8(stream, 1, A_lo, B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1, r1, L->mp, L->sizeC, nullptr, nullptr, 0));
+            OZ2_HIP(launch_gemm_f8(stream, 2, A_lo, B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1,
+                                   (int16_t*)L->C_mid + (size_t)t0 * L->sizeC, L->mp, L->sizeC, r0, r1, L->sizeC));
+        }
+        return GEMMUL8_OK;
+    }
     if (!is_complex(dtype)) {
         OZ2_HIP(launch_gemm_i8_mod(stream, A_lo, B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)t_begin, (int)t_end,
                                    (int8_t*)L->C_mid + (size_t)t_begin * L->sizeC, L->mp, L->sizeC));

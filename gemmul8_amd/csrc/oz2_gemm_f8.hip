@@ -1,0 +1,307 @@
+// FP8 (OCP e4m3) x FP8 -> FP32 "TN" GEMM on gfx950 MFMA with fused epilogues (FP8 backend of Ozaki-II).
+//
+// Replaces gemm_low_prec_f8x1 / f8x3 (GEMMul8/src/matmult.hpp:180-208,307-350) and the FP8 requantise
+// pass (src/conv_hi2mid_real.hpp:28-46, src/mod.hpp:106-130).  All values the main GEMMs multiply are
+// integers of magnitude <= 16 held as e4m3 (src/mod.hpp:159-189), so products and FP32 sums are exact
+// for k <= 65536; the bound GEMM (values up to 256 with 3-bit mantissas) is inexact and is inflated by
+// (k+1)*2^-24 exactly like the reference (src/find_max.hpp:82-96).
+//
+// Per modulus three GEMMs (src/gemmul8_real.hpp:159-181):
+//   square moduli (t < 6, p = s^2, a = s*hi + lo):  C0 = Ahi*Blo, C1 = Alo*Bhi, C2 = Alo*Blo,  value = s*(C0+C1) + C2
+//   Karatsuba   (t >= 6,        a = 16*hi + lo):    C0 = Ahi*Bhi, C1 = Alo*Blo, C2 = (Ahi+Alo)(Bhi+Blo),
+//                                                   value = 256*C0 + 16*(C2-C0-C1) + C1
+//   EPI_PART  : out = int16 residue of one of C0 / C1 (scratch planes)
+//   EPI_FINAL : C = C2; combines with the residues of C0, C1 and stores C_mid[t] = int16(value mod p_t)
+//   EPI_MAX   : row/col maxima of fma_ru(ku, C, C) as float bit patterns (atomicMax on non-negative floats)
+//
+// Same structure as oz2_gemm_i8.hip (256x256 tile, 8 consumer + 4 LDS-DMA producer waves, BK = 128 bytes,
+// swizzled 128-B LDS rows, ping-pong segments); the matrix instruction is the block-scaled
+// v_mfma_scale_f32_32x32x64_f8f6f4 with unit scales (E8M0 0x7F) -- the only full-rate FP8 MFMA on CDNA4
+// (the unscaled 32x32x16 fp8 form runs at the BF16 rate).  A K-step is 2 MFMA-K of 64; each is split into two
+// LOAD/MFMA segment pairs (row blocks 0-1, then 2-3) to stay within 168 VGPRs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "oz2_gemm_common.hpp"
+#include "oz2_kernels.h"
+
+namespace oz2 {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+enum { EPI_PART = 0, EPI_FINAL = 1, EPI_FMAX = 2 };
+
+struct F8Args {
+    const int8_t* A;      // base of the A planes; plane of block b at A + planeA[b]*strideA
+    const int8_t* B;
+    size_t strideA, strideB;
+    int planeA[20], planeB[20];
+    int kp, m, n, tiles_m, tiles_n;
+    int t_begin;          // block b <-> modulus t_begin + b
+    int16_t* out;         // EPI_PART: scratch plane b at out + b*strideO; EPI_FINAL: C_mid plane (t_begin+b) likewise
+    size_t ldo, strideO;
+    const int16_t* r0;    // EPI_FINAL: residues of C0, C1 (plane b at r0/r1 + b*strideR)
+    const int16_t* r1;
+    size_t strideR;
+    int* rowmax;          // EPI_FMAX (float bit patterns)
+    int* colmax;
+    float ku;             // (k+1) * 2^-24
+    int moduli[20];
+    int pinv32[20];
+    int sqrtp[6];
+};
+
+__device__ __forceinline__ unsigned pack16(int a, int b) { return ((unsigned)a & 0xFFFFu) | ((unsigned)b << 16); }
+
+template <int EPI>
+__global__ void __launch_bounds__(WS_THREADS) gemm_f8_kernel(const F8Args args) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const TileMap tmap = map_tile(args.tiles_m, args.tiles_n);
+    const int plane = tmap.plane, tm = tmap.tm, tn = tmap.tn;
+    const size_t offA = (size_t)args.planeA[plane] * args.strideA + (size_t)tm * BM * args.kp;
+    const size_t offB = (size_t)args.planeB[plane] * args.strideB + (size_t)tn * BN * args.kp;
+    const int nB_valid = (args.n - tn * BN) < BN ? (args.n - tn * BN) : BN;
+    const int KT = args.kp / BK;
+
+    if (wave >= 8) {
+        const int8_t* const gA[3] = {args.A + offA, args.A + offA, args.A + offA};
+        const int8_t* const gB[3] = {args.B + offB, args.B + offB, args.B + offB};
+        producer_loop(gA, gB, args.kp, KT, KT, nB_valid, smem, wave - 8, lane);
+        return;
+    }
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int frow = lane & 31;
+    const int khalf = lane >> 5;
+    const int sw = (frow >> 1) & 7;
+    const int a_base = (wm * 128 + frow) * BK;
+    const int b_base = TILE_BYTES + (wn * 64 + frow) * BK;
+
+    v16f acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    auto frag = [&](const char* base, int c0) {  // 32 bytes = logical chunks c0, c0+1 of this lane's row
+        const v4i lo = *(const v4i*)(base + ((c0 ^ sw) << 4));
+        const v4i hi = *(const v4i*)(base + (((c0 + 1) ^ sw) << 4));
+        return v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    constexpr int UNIT = 0x7F7F7F7F;  // E8M0 scale 2^0 for every 32-element block
+
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < KT; ++kt) {
+        char* cur = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+            const int c0 = ks2 * 4 + khalf * 2;
+            v8i bf[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                v8i af[2];
+                if (half == 0) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bf[j] = frag(cur + b_base + j * 32 * BK, c0);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = frag(cur + a_base + (half * 2 + i) * 32 * BK, c0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[half * 2 + i][j] =
+                            __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[i], bf[j], acc[half * 2 + i][j], 0, 0, 0, UNIT, 0, UNIT);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+
+    const int i0 = tm * BM + wm * 128;
+    const int j0 = tn * BN + wn * 64;
+
+    if constexpr (EPI == EPI_PART || EPI == EPI_FINAL) {
+        const int t = args.t_begin + plane;
+        const int p = args.moduli[t];
+        const int pinv = args.pinv32[t];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = j0 + j * 32 + frow;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned d[4][2];  // quad q: rows 8q+4h..+3 as 4 x int16
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int r[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) r[b] = mod_i32_sym(__float2int_rn(acc[i][j][q * 4 + b]), p, pinv);
+                    d[q][0] = pack16(r[0], r[1]);
+                    d[q][1] = pack16(r[2], r[3]);
+                }
+                unsigned z[8];  // after the exchange: 16 consecutive rows (h=0: rows 0..15, h=1: rows 16..31)
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    auto s0 = __builtin_amdgcn_permlane32_swap(d[0][w], d[2][w], false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(d[1][w], d[3][w], false, false);
+                    z[0 + w] = s0[0];  // rows 0-3   (own quad 0 | quad 2 of the lower half)
+                    z[2 + w] = s0[1];  // rows 4-7
+                    z[4 + w] = s1[0];  // rows 8-11
+                    z[6 + w] = s1[1];  // rows 12-15
+                }
+                if (col < args.n) {
+                    const size_t e = (size_t)col * args.ldo + i0 + i * 32 + khalf * 16;
+                    int16_t* dst = args.out + (size_t)plane * args.strideO + e;
+                    if constexpr (EPI == EPI_FINAL) {
+                        const uint4* p0 = (const uint4*)(args.r0 + (size_t)plane * args.strideR + e);
+                        const uint4* p1 = (const uint4*)(args.r1 + (size_t)plane * args.strideR + e);
+                        const uint4 x0 = p0[0], x1 = p0[1], y0 = p1[0], y1 = p1[1];
+                        const unsigned xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                        const unsigned ys[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) {
+                            int o[2];
+#pragma unroll
+                            for (int hlf = 0; hlf < 2; ++hlf) {
+                                const int R0 = (int)(int16_t)(xs[w] >> (16 * hlf)), R1 = (int)(int16_t)(ys[w] >> (16 * hlf)),
+                                          R2 = (int)(int16_t)(z[w] >> (16 * hlf));
+                                int v;
+                                if (t < 6) v = args.sqrtp[t] * (R0 + R1) + R2;
+                                else v = 256 * R0 + 16 * (R2 - R0 - R1) + R1;
+                                o[hlf] = mod_i32_sym(v, p, pinv);
+                            }
+                            z[w] = pack16(o[0], o[1]);
+                        }
+                    }
+                    ((uint4*)dst)[0] = make_uint4(z[0], z[1], z[2], z[3]);
+                    ((uint4*)dst)[1] = make_uint4(z[4], z[5], z[6], z[7]);
+                }
+            }
+        }
+    } else {
+        const float ku = args.ku;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float cm = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    const float c = acc[i][j][r];
+                    const float v = (row < args.m) ? __fmaf_ru(ku, c, c) : 0.0f;
+                    cm = fmaxf(cm, v);
+                }
+            cm = fmaxf(cm, __shfl_xor(cm, 32));
+            const int col = j0 + j * 32 + frow;
+            if (khalf == 0 && col < args.n && cm > 0.0f) atomicMax(args.colmax + col, __float_as_int(cm));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = j0 + j * 32 + frow;
+                    const float c = acc[i][j][r];
+                    const float a = (col < args.n) ? __fmaf_ru(ku, c, c) : 0.0f;
+                    v = fmaxf(v, a);
+                }
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+                const int row = i0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (frow == 0 && row < args.m && v > 0.0f) atomicMax(args.rowmax + row, __float_as_int(v));
+            }
+    }
+}
+
+static void fill_common(F8Args& a, size_t kp, size_t m, size_t n) {
+    a.kp = (int)kp;
+    a.m = (int)m;
+    a.n = (int)n;
+    a.tiles_m = (int)((m + BM - 1) / BM);
+    a.tiles_n = (int)((n + BN - 1) / BN);
+    for (int t = 0; t < 20; ++t) {
+        const int p = GEMMUL8_MODULI_FP8[t];
+        a.moduli[t] = p;
+        a.pinv32[t] = (int)(4294967296ull / (unsigned long long)p);
+    }
+    for (int t = 0; t < 6; ++t) a.sqrtp[t] = GEMMUL8_SQRT_MODULI_FP8[t];
+}
+
+template <int EPI> static hipError_t launch(hipStream_t stream, const F8Args& a, int planes) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_f8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int grid = planes * a.tiles_m * a.tiles_n;
+    if (grid <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gemm_f8_kernel<EPI>, dim3(grid), dim3(WS_THREADS), LDS_BYTES, stream, a);
+    return hipGetLastError();
+}
+
+// first low-precision plane of modulus t: 2 planes for t < 6 (hi, lo), 3 afterwards (hi, lo, hi+lo)  (table.hpp:69-75)
+static int first_plane(int t) { return t < 6 ? 2 * t : 12 + 3 * (t - 6); }
+
+// which = 0,1: partial products C0 / C1 -> int16 residue scratch; which = 2: C2 with the final combine -> C_mid
+hipError_t launch_gemm_f8(hipStream_t stream, int which, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp, size_t m,
+                          size_t n, int t_begin, int t_end, int16_t* out, size_t ldo, size_t strideO, const int16_t* r0, const int16_t* r1,
+                          size_t strideR) {
+    F8Args a{};
+    a.A = A;
+    a.B = B;
+    a.strideA = strideA;
+    a.strideB = strideB;
+    a.t_begin = t_begin;
+    a.out = out;
+    a.ldo = ldo;
+    a.strideO = strideO;
+    a.r0 = r0;
+    a.r1 = r1;
+    a.strideR = strideR;
+    for (int t = t_begin; t < t_end; ++t) {
+        const int q = first_plane(t), b = t - t_begin;
+        if (t < 6) {  // hi = q, lo = q+1 :  C0 = Ahi*Blo, C1 = Alo*Bhi, C2 = Alo*Blo
+            a.planeA[b] = which == 0 ? q : q + 1;
+            a.planeB[b] = which == 1 ? q : q + 1;
+        } else {      // C0 = hi*hi, C1 = lo*lo, C2 = (hi+lo)*(hi+lo)
+            a.planeA[b] = q + which;
+            a.planeB[b] = q + which;
+        }
+    }
+    fill_common(a, kp, m, n);
+    return which == 2 ? launch<EPI_FINAL>(stream, a, t_end - t_begin) : launch<EPI_PART>(stream, a, t_end - t_begin);
+}
+
+hipError_t launch_gemm_f8_max(hipStream_t stream, const int8_t* A, const int8_t* B, size_t kp, size_t k, size_t m, size_t n, int* rowmax,
+                              int* colmax) {
+    F8Args a{};
+    a.A = A;
+    a.B = B;
+    a.rowmax = rowmax;
+    a.colmax = colmax;
+    a.ku = (float)(k + 1) * 0x1.0p-24f;
+    fill_common(a, kp, m, n);
+    return launch<EPI_FMAX>(stream, a, 1);
+}
+
+}  // namespace oz2

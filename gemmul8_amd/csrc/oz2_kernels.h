@@ -30,6 +30,13 @@ hipError_t launch_gemm_i8_cplx(hipStream_t stream, const int8_t* A, const int8_t
 hipError_t launch_gemm_i8_max(hipStream_t stream, int nseg, const int8_t* const* A, const int8_t* const* B, size_t kp, size_t m, size_t n,
                               int* rowmax, int* colmax);
 
+// ---- FP8 MFMA GEMM (oz2_gemm_f8.hip)
+hipError_t launch_gemm_f8(hipStream_t stream, int which, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp, size_t m,
+                          size_t n, int t_begin, int t_end, int16_t* out, size_t ldo, size_t strideO, const int16_t* r0, const int16_t* r1,
+                          size_t strideR);
+hipError_t launch_gemm_f8_max(hipStream_t stream, const int8_t* A, const int8_t* B, size_t kp, size_t k, size_t m, size_t n, int* rowmax,
+                              int* colmax);
+
 // ---- scale / quantise (oz2_scale.hip).  An operand has `rows` logical rows (m for A, n for B) of
 // length k; K-major: element (r,kk) at X[r*ld+kk]; row-strided: X[kk*ld+r].  lo planes are
 // [rows_pad][kp] int8, zero-filled for kk in [k,kp).

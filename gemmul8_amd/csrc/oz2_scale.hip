@@ -108,6 +108,7 @@ struct StageArgs {
     int backend;
     int conj;
     int t_begin, t_end;
+    int sqrtp[6];
     ModTable mt;
 };
 
@@ -116,6 +117,19 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
     using E = ET<T>;
     int8_t* out = a.lo + row * a.kp + k0;
     if constexpr (MODE == MODE_BOUND) {
+        if (a.backend == kFP8) {
+            // e4m3 round-up of |x|*2^s (< 2^8), computed in the input precision (scaling.hpp:77-82); real types only
+            using U = typename E::U;
+            unsigned w = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const U x = (U)E::re(v[e]);
+                const U sc = sizeof(U) == 8 ? (U)scalbn(fabs((double)x), s) : (U)scalbnf(fabsf((float)x), s);
+                w |= fp8_round_up<U>(sc) << (8 * e);
+            }
+            *(unsigned*)out = w;
+            return;
+        }
         unsigned wr = 0, wi = 0, wd = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -150,6 +164,34 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
             }
         }
         const short(*pow2)[64] = a.backend == kINT8 ? c_pow2mod_int8 : c_pow2mod_fp8;
+        if (a.backend == kFP8) {
+            // residues up to +-544 are split into 2-3 e4m3 planes of integers <= 16 (mod.hpp:159-189, 361-410); real types only
+            for (int t = a.t_begin; t < a.t_end; ++t) {
+                const ModConst mc = a.mt.mc[t];
+                int rr[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rr[e] = residue_sym(Lr[e], Er[e], nr[e], mc, pow2[t]);
+                int8_t* o = out + (size_t)(t < 6 ? 2 * t : 12 + 3 * (t - 6)) * a.plane_stride;
+                if (t < 6) {
+                    const int sq = a.sqrtp[t];
+                    const float inv = 1.0f / (float)sq;
+                    float hi[4], lo[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fp8_split_sq(rr[e], sq, inv, hi[e], lo[e]);
+                    *(unsigned*)o = fp8x2_from_floats(hi[0], hi[1]) | (fp8x2_from_floats(hi[2], hi[3]) << 16);
+                    *(unsigned*)(o + a.plane_stride) = fp8x2_from_floats(lo[0], lo[1]) | (fp8x2_from_floats(lo[2], lo[3]) << 16);
+                } else {
+                    int hi[4], lo[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fp8_split_kara(rr[e], hi[e], lo[e]);
+                    *(unsigned*)o = fp8x2_from_ints(hi[0], hi[1]) | (fp8x2_from_ints(hi[2], hi[3]) << 16);
+                    *(unsigned*)(o + a.plane_stride) = fp8x2_from_ints(lo[0], lo[1]) | (fp8x2_from_ints(lo[2], lo[3]) << 16);
+                    *(unsigned*)(o + 2 * a.plane_stride) =
+                        fp8x2_from_ints(hi[0] + lo[0], hi[1] + lo[1]) | (fp8x2_from_ints(hi[2] + lo[2], hi[3] + lo[3]) << 16);
+                }
+            }
+            return;
+        }
         for (int t = a.t_begin; t < a.t_end; ++t) {
             const ModConst mc = a.mt.mc[t];
             unsigned wr = 0, wi = 0, ws = 0;
@@ -373,18 +415,19 @@ hipError_t launch_quantise(hipStream_t stream, int dtype, int backend, unsigned 
     a.t_begin = t_begin;
     a.t_end = t_end;
     a.mt = make_mod_table(backend);
+    for (int t = 0; t < 6; ++t) a.sqrtp[t] = GEMMUL8_SQRT_MODULI_FP8[t];
     (void)N;
     return dispatch_stage<MODE_MOD>(stream, dtype, kmajor, a);
 }
 
 // ------------------------------------------------------------------ accurate-mode shift from the bound maxima
-__global__ void shift_finalize_kernel(size_t rows, const int* maxv, int16_t* sft, float log2P) {
+__global__ void shift_finalize_kernel(size_t rows, const int* maxv, int16_t* sft, float log2P, int float_max) {
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
-    const int amax = maxv[r];
+    const int amax = maxv[r];  // INT8: int32 maximum; FP8: bit pattern of a non-negative float
     int f = 0;  // all-zero row/column: the reference is undefined here (log2(0)); any shift is valid
     if (amax > 0) {
-        const float l = __log2f(__int2float_rn(amax));
+        const float l = __log2f(float_max ? __int_as_float(amax) : __int2float_rn(amax));
         f = __float2int_rd(__fmaf_rd(-0x1.000006p-1f, l, log2P));
     }
     sft[r] = (int16_t)(-((int)sft[r] + f));
@@ -392,7 +435,7 @@ __global__ void shift_finalize_kernel(size_t rows, const int* maxv, int16_t* sft
 hipError_t launch_shift_finalize(hipStream_t stream, int backend, unsigned N, size_t rows, const int* maxv, int16_t* sft) {
     if (rows == 0) return hipSuccess;
     const float log2P = backend == kINT8 ? GEMMUL8_LOG2P_INT8[N - 2] : GEMMUL8_LOG2P_FP8[N - 2];
-    hipLaunchKernelGGL(shift_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, rows, maxv, sft, log2P);
+    hipLaunchKernelGGL(shift_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, rows, maxv, sft, log2P, backend == kFP8 ? 1 : 0);
     return hipGetLastError();
 }
 

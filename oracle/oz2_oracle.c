@@ -223,6 +223,18 @@ static double e4m3_to_double(uint8_t b) {
     double v = e ? ldexp(1.0 + m / 8.0, e - 7) : ldexp(m / 8.0, -6);
     return s ? -v : v;
 }
+static int8_t F8_INT_LUT[256]; /* e4m3 byte -> integer value (main planes hold integers of magnitude <= 16) */
+static double F8_DBL_LUT[256];
+static int f8_lut_ready = 0;
+static void f8_lut_init(void) {
+    if (f8_lut_ready) return;
+    for (int b = 0; b < 256; ++b) {
+        const double v = ((b & 0x7F) == 0x7F) ? 0.0 : e4m3_to_double((uint8_t)b);
+        F8_DBL_LUT[b] = v;
+        F8_INT_LUT[b] = (v >= -127 && v <= 127 && v == (double)(int)v) ? (int8_t)v : 0;
+    }
+    f8_lut_ready = 1;
+}
 /* fp8_e4m3_ru (scaling.hpp:48-54): RN conversion, then +1 encoding step if the result is below a */
 static uint8_t e4m3_ru(double a) {
     uint8_t r = e4m3_from_double_rn(a);
@@ -337,6 +349,7 @@ void oz2_bound_shifts(int backend, int cplx, unsigned N, size_t m, size_t n, siz
            find_max.hpp:82-96).  Accumulate in double (exact) and round to float once per entry,
            which is what an exact-product / fp32-accumulate engine returns when no rounding occurs;
            the inflation covers the engine's rounding either way. */
+        f8_lut_init();
         float *rmax = calloc(m, 4), *cmax = calloc(n, 4);
         const float ku = (float)(k + 1) * 0x1.0p-24f;
         for (size_t j = 0; j < n; ++j)
@@ -344,7 +357,7 @@ void oz2_bound_shifts(int backend, int cplx, unsigned N, size_t m, size_t n, siz
                 float v;
                 if (!cplx) {
                     double s = 0;
-                    for (size_t kk = 0; kk < k; ++kk) s += e4m3_to_double(Abar[i * k + kk]) * e4m3_to_double(Bbar[j * k + kk]);
+                    for (size_t kk = 0; kk < k; ++kk) s += F8_DBL_LUT[Abar[i * k + kk]] * F8_DBL_LUT[Bbar[j * k + kk]];
                     float t = (float)s;
                     v = fmaf_dir(ku, t, t, FE_UPWARD);
                 } else {
@@ -352,9 +365,9 @@ void oz2_bound_shifts(int backend, int cplx, unsigned N, size_t m, size_t n, siz
                     const uint8_t *br = Bbar + j * k, *bi = br + pb, *bd = bi + pb;
                     double c0 = 0, c1 = 0, c2 = 0;
                     for (size_t kk = 0; kk < k; ++kk) {
-                        c1 += e4m3_to_double(ar[kk]) * e4m3_to_double(bi[kk]);
-                        c2 += e4m3_to_double(ai[kk]) * e4m3_to_double(br[kk]);
-                        c0 += e4m3_to_double(ad[kk]) * e4m3_to_double(bd[kk]);
+                        c1 += F8_DBL_LUT[ar[kk]] * F8_DBL_LUT[bi[kk]];
+                        c2 += F8_DBL_LUT[ai[kk]] * F8_DBL_LUT[br[kk]];
+                        c0 += F8_DBL_LUT[ad[kk]] * F8_DBL_LUT[bd[kk]];
                     }
                     float ArBi = (float)c1, AiBr = (float)c2, AriBri = (float)c0;
                     float ArBi_up = fmaf_dir(ku, ArBi, ArBi, FE_UPWARD);
@@ -533,9 +546,9 @@ static int64_t dot_i8(const int8_t *a, const int8_t *b, size_t k) {
 }
 static int64_t dot_f8(const uint8_t *a, const uint8_t *b, size_t k) {
     /* all stored values are integers of magnitude <= 16: products and sums are exact in fp32 for
-       k <= 65536; accumulate in int64 and let the caller reduce (any exact engine agrees). */
-    int64_t s = 0;
-    for (size_t kk = 0; kk < k; ++kk) s += (int64_t)e4m3_to_double(a[kk]) * (int64_t)e4m3_to_double(b[kk]);
+       k <= 65536; accumulate in int32 (any exact engine agrees). */
+    int32_t s = 0;
+    for (size_t kk = 0; kk < k; ++kk) s += (int32_t)F8_INT_LUT[a[kk]] * (int32_t)F8_INT_LUT[b[kk]];
     return s;
 }
 /* residue of one (part-plane set) product, before the final symmetric wrap */
@@ -556,6 +569,7 @@ static int64_t modprod(int backend, int t, const uint8_t *a, const uint8_t *b, s
 /* C_mid: real int8|int16 [N][n][m] ; complex interleaved [N][n][m][2] */
 void oz2_gemm_mod(int backend, int cplx, unsigned N, size_t m, size_t n, size_t k, const uint8_t *A_lo,
                   const uint8_t *B_lo, void *C_mid, unsigned t_begin, unsigned t_end) {
+    f8_lut_init();
     const int *p = moduli_of(backend);
     const size_t pa = m * k, pb = n * k;
     const size_t nm = oz2_num_mat(backend, N);

@@ -123,3 +123,45 @@ def test_parity_complex_shapes():
         A, B = rand((m, k), np.complex128, rng), rand((k, n), np.complex128, rng)
         gu.parity_case(A, B, 20, False)
         gu.parity_case(A, B, 9, True)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("fast", [False, True])
+@pytest.mark.parametrize("N", [2, 5, 6, 7, 12, 13, 20])
+def test_parity_small_real_fp8(dtype, fast, N):
+    """FP8-e4m3 backend (gemmLt<T,FP8> in the reference): e4m3 planes, int16 C_mid, final C -- bit-exact."""
+    import gemmul8_amd as g
+    import gpu_util as gu
+    if dtype == np.float32 and N > 13:
+        pytest.skip("float documented for N<=13")
+    rng = np.random.default_rng(300 * N + fast)
+    m, n, k = 37, 41, 300
+    A, B = rand((m, k), dtype, rng), rand((k, n), dtype, rng)
+    A[5, :] = 0
+    B[:, 7] = 0
+    gu.parity_case(A, B, N, fast, backend=g.FP8)
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 256, 256), (260, 300, 520), (1, 1, 1), (257, 255, 513)])
+def test_parity_shapes_fp8(m, n, k):
+    import gemmul8_amd as g
+    import gpu_util as gu
+    rng = np.random.default_rng(m + n + k + 1)
+    A, B = rand((m, k), np.float32, rng), rand((k, n), np.float32, rng)
+    gu.parity_case(A, B, 6, False, backend=g.FP8)   # BASELINE config 3 parameters (SGEMM, moduli=6)
+    gu.parity_case(A, B, 13, True, backend=g.FP8, opA="T" if m == k else "N")
+    Ad, Bd = A.astype(np.float64), B.astype(np.float64)
+    gu.parity_case(Ad, Bd, 13, False, backend=g.FP8, alpha=-1.5, beta=1.5, C0=rand((m, n), np.float64, rng))
+
+
+def test_kat_sample_fp8_on_gpu():
+    """sample/dgemm_cuBLASLt_fp8.cu: the 4x5x3 known-answer vectors with N=13 on the FP8 backend."""
+    import gemmul8_amd as g
+    import gpu_util as gu
+    d = json.load(open(os.path.join(GOLD, "kat_dgemm_4x5x3.json")))
+    A = np.array([float.fromhex(x) for x in d["A"]]).reshape((4, 5), order="F")
+    B = np.array([float.fromhex(x) for x in d["B"]]).reshape((5, 3), order="F")
+    Cx = np.array([float.fromhex(x) for x in d["C_exact"]]).reshape((4, 3), order="F")
+    C = gu.hip_gemm(A, B, 13, backend=g.FP8)
+    assert np.sqrt(((C - Cx) ** 2).sum()) < 4e-15
+    gu.parity_case(A, B, 13, False, backend=g.FP8)
