@@ -94,11 +94,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("GEMMUL8_DIST_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL ("nccl") is the product path; GEMMUL8_DIST_BACKEND=gloo only exists to smoke-test this file with
+        # several ranks sharing one GPU (host-staged exchange), where NCCL refuses duplicate devices.
+        backend = os.environ.get("GEMMUL8_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     import ctypes as C
     import gemmul8_amd as g
 

@@ -256,8 +256,8 @@ int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t
         return GEMMUL8_OK;
     }
     if (!is_complex(dtype)) {
-        OZ2_HIP(launch_gemm_i8_mod(stream, A_lo, B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)t_begin, (int)t_end,
-                                   (int8_t*)L->C_mid + (size_t)t_begin * L->sizeC, L->mp, L->sizeC));
+        OZ2_HIP(launch_gemm_i8_mod(stream, A_lo + (size_t)t_begin * L->sizeA, B_lo + (size_t)t_begin * L->sizeB, L->sizeA, L->sizeB, L->kp, m, n,
+                                   (int)t_begin, (int)t_end, (int8_t*)L->C_mid + (size_t)t_begin * L->sizeC, L->mp, L->sizeC));
         return GEMMUL8_OK;
     }
     // complex (gemmul8_complex.hpp:154-206, conv_hi2mid_complex.hpp:9-127): per modulus X = ArBr, Y = AiBi,
