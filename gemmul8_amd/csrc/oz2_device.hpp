@@ -94,11 +94,17 @@ __device__ __forceinline__ int mod_small_pos(int s, int p, float invp) {
 
 // symmetric residue of +-M*2^E in (-p/2, p/2]; pow2row = GEMMUL8_POW2MOD[t] (only read when E > 0)
 __device__ __forceinline__ int residue_sym(const Limbs& L, int E, bool neg, const ModConst& mc, const short* pow2row) {
-    int s = L.l0 + __mul24(L.l1, mc.c18) + __mul24(L.l2, mc.c36);
-    int r = mod_small_pos(s, mc.p, mc.invp);
-    if (E > 0) r = mod_small_pos(__mul24(r, (int)pow2row[E < 63 ? E : 63]), mc.p, mc.invp);
-    if (neg && r != 0) r = mc.p - r;
-    if (r > (mc.p >> 1)) r -= mc.p;
+    const int p = mc.p;
+    int s = L.l0 + __mul24(L.l1, mc.c18) + __mul24(L.l2, mc.c36);   // < 2^29
+    int r = s - __mul24((int)rintf((float)s * mc.invp), p);          // |r| <= 0.6 p
+    if (E > 0) {                                                      // only for num_moduli > 15 (|A'| >= 2^53)
+        s = __mul24(r, (int)pow2row[E < 63 ? E : 63]);
+        r = s - __mul24((int)rintf((float)s * mc.invp), p);
+    }
+    r = neg ? -r : r;
+    const int h = p >> 1;
+    r = (r > h) ? r - p : r;
+    r = (r + h < ((p & 1) ^ 1)) ? r + p : r;  // odd p: r < -(p-1)/2 ; even p: r <= -p/2 (the representative of p/2 is +p/2)
     return r;
 }
 
