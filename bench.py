@@ -78,6 +78,23 @@ def host_blas(n):
             "lib": "numpy-bundled OpenBLAS DGEMM", "shape": f"{n}^3", "seconds": best}
 
 
+def native_fp64(A, B):
+    """The reference's own comparator (testing/test_flops.hpp:87-115): the vendor's native DGEMM on the same GPU
+    (rocBLAS through torch.matmul).  Yardstick only -- nothing in the product calls a BLAS."""
+    n = A.shape[0]
+    for _ in range(2):
+        torch.matmul(B, A)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        Cn = torch.matmul(B, A)  # tensors are (cols, rows): (B^T A^T) = (A B)^T in column-major terms
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    return {"value": 2.0 * n ** 3 / ms * 1e-9, "unit": "TFLOPS", "ms": ms, "lib": "rocBLAS DGEMM via torch.matmul (float64)"}, Cn
+
+
 def sampled_error(A, B, C, n):
     """max |C-Chat|/|Chat| on a 48x48 sampled block, Chat = long-double (80-bit) product."""
     rows = np.arange(0, n, n // 48)[:48]
@@ -196,6 +213,10 @@ def main():
             "roofline": roof,
         }
         out["max_rel_err"] = sampled_error(A, B, Cfull, n)
+        if world == 1:
+            nat, Cn = native_fp64(A, B)
+            nat["max_rel_err"] = sampled_error(A, B, Cn, n)
+            out["native_fp64_dgemm_same_gpu"] = nat
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline_port(N, args.fast)
             out["host_blas_dgemm"] = host_blas(n)
