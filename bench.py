@@ -33,6 +33,9 @@ def parse():
     ap.add_argument("--moduli", type=int, default=14)
     ap.add_argument("--fast", action="store_true", help="fast mode (14 GEMMs) instead of accurate (15)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines (profiling runs)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
+                    help="BASELINE.json config: 2 = DGEMM 8192^3 N=14 INT8 (headline, default); 3 = SGEMM 16384^3 N=6 FP8; "
+                         "5 = ZGEMM 8192^3 N=20 INT8 (single GPU only; extra measurement lines, not the driver's metric)")
     return ap.parse_args()
 
 
@@ -106,8 +109,82 @@ def sampled_error(A, B, C, n):
     return float(np.max(np.abs((got - ref) / ref)))
 
 
+def run_other_config(args):
+    """Configs 3 and 5 of BASELINE.json on one GPU: whole-call timing through gemmul8_gemm (events), accuracy on a sampled block."""
+    import gemmul8_amd as g
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    if args.config == 3:
+        n, N, dt, be, name, cflops = 16384, 6, torch.float32, g.FP8, "SGEMM", 1
+    else:
+        n, N, dt, be, name, cflops = 8192, 20, torch.complex128, g.INT8, "ZGEMM", 4
+    if args.size != 8192:
+        n = args.size
+    gen = torch.Generator(device=dev).manual_seed(12345)
+    rdt = torch.float32 if dt == torch.float32 else torch.float64
+    def rnd():
+        x = torch.rand((n, n), generator=gen, dtype=rdt, device=dev) - 0.5
+        if dt.is_complex:
+            x = torch.complex(x, torch.rand((n, n), generator=gen, dtype=rdt, device=dev) - 0.5)
+        return x.contiguous()
+    A, B = rnd(), rnd()
+    Cm = torch.zeros((n, n), dtype=dt, device=dev)
+    tot, _, _ = g.work_size(dt.is_complex, be, n, n, n, N)
+    work = torch.empty(tot, dtype=torch.uint8, device=dev)
+    mode = bool(args.fast)
+    for _ in range(args.warmup):
+        g.gemm(A, B, N, fastmode=mode, backend=be, C_out=Cm, work=work)
+    torch.cuda.synchronize()
+    ts, phases = [], np.zeros(4)
+    for _ in range(args.steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.gemm(A, B, N, fastmode=mode, backend=be, C_out=Cm, work=work)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    _, tm, _ = g.gemm(A, B, N, fastmode=mode, backend=be, C_out=Cm, work=work, timers=True)
+    ms = float(np.median(ts))
+    rows = np.arange(0, n, n // 32)[:32]
+    cols = np.arange(7, n, n // 32)[:32]
+    hp = np.clongdouble if dt.is_complex else np.longdouble
+    Ah = A[:, rows].cpu().numpy().T.astype(hp)
+    Bh = B[cols, :].cpu().numpy().T.astype(hp)
+    ref = Ah @ Bh
+    got = Cm[cols][:, rows].cpu().numpy().T
+    err = float(np.max(np.abs(got - ref) / np.abs(ref)))
+    # the reference's comparator (testing/test_accuracy.hpp): the vendor's native GEMM of the same type, same metric
+    torch.matmul(B, A)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    Cn = torch.matmul(B, A)
+    e1.record()
+    torch.cuda.synchronize()
+    nat_ms = e0.elapsed_time(e1)
+    gotn = Cn[cols][:, rows].cpu().numpy().T
+    errn = float(np.max(np.abs(gotn - ref) / np.abs(ref)))
+    del Cn
+    gcnt = {3: 3 * N + (0 if mode else 1), 5: 3 * N + (0 if mode else 5)}[args.config]  # complex bounds: K-concatenated 2+3 units
+    out = {"metric": f"emulated {name} TFLOPS (config {args.config})", "value": cflops * 2.0 * n ** 3 / ms * 1e-9, "unit": "TFLOPS",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "fp8 e4m3 MFMA (f32 accumulate) + f64 CRT" if be == g.FP8 else "int8 MFMA (i32 accumulate) + f64 CRT",
+           "data": "synthetic U(-0.5,0.5)", "config": {"workload": f"{name} {n}^3, moduli={N}, {'FP8' if be == g.FP8 else 'INT8'} backend, "
+                                                                      f"{'fast' if mode else 'accurate'} mode, op N/N, alpha=1, beta=0"},
+           "phase_ms": {"scaling": tm[0] * 1e-6, "lowprec_gemm": tm[1] * 1e-6, "requantise": tm[2] * 1e-6, "inverse_scaling": tm[3] * 1e-6},
+           "roofline": {"bound": "mfma", "achieved": gcnt * 2.0 * n ** 3 / (tm[1] * 1e-6 + 1e-30) * 1e-9 if mode else None, "peak": 5000.0,
+                        "unit": "TOP/s", "lowprec_units_of_2mnk": gcnt, "lowprec_phase_ms": tm[1] * 1e-6,
+                        "lowprec_rate_TOPs": (3 * N) * 2.0 * n ** 3 / (tm[1] * 1e-6) * 1e-9},
+           "max_rel_err": err,
+           "native_same_gpu": {"lib": f"rocBLAS/hipBLASLt {name} via torch.matmul", "value": cflops * 2.0 * n ** 3 / nat_ms * 1e-9,
+                               "unit": "TFLOPS", "ms": nat_ms, "max_rel_err": errn}}
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
+    if args.config != 2:
+        return run_other_config(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -47,24 +47,26 @@ __device__ __forceinline__ TileMap map_tile(int tiles_m, int tiles_n) {
     return t;
 }
 
-// Producer wave pw = 0..3: DMA instructions q = pw*16 .. pw*16+15 of every K-tile (4096 16-byte slots per stage:
-// slot p <-> operand (p>=2048: B), row = (p&2047)>>3, physical chunk = p&7, logical chunk = physical ^ ((row>>1)&7)).
+// One LDS-DMA instruction of a K-tile: instruction Q = 0..63 moves the 64 16-byte slots p = Q*64 + lane of a stage
+// (4096 slots: slot p <-> operand (p>=2048: B), row = (p&2047)>>3, physical chunk = p&7,
+// logical chunk = physical ^ ((row>>1)&7)).  tA/tB: this workgroup's first row at the K offset of the tile.
+__device__ __forceinline__ void dma_issue(const int8_t* tA, const int8_t* tB, int Q, char* stage, int kp, int nB_valid, int lane) {
+    const int p = Q * 64 + lane;
+    const bool isB = p >= 2048;
+    const int pp = p & 2047;
+    int row = pp >> 3;
+    const int c = (pp & 7) ^ ((row >> 1) & 7);
+    if (isB) row = row < nB_valid ? row : nB_valid - 1;  // B planes have exactly n rows: clamp instead of padding
+    const int8_t* src = (isB ? tB : tA) + (size_t)row * kp + c * 16;
+    char* dst = stage + (Q * 64) * 16;  // wave-uniform; the hardware adds lane*16
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+
+// Producer wave pw = 0..3: DMA instructions Q = pw*16 .. pw*16+15 of every K-tile.
 // gA[s]/gB[s]: K-segment s, already offset to this workgroup's first row.  Executes 8*KT + 2 barriers.
 __device__ __forceinline__ void producer_loop(const int8_t* const (&gA)[3], const int8_t* const (&gB)[3], int kp, int KT1, int KT,
                                               int nB_valid, char* smem, int pw, int lane) {
-    // per-lane constants of the 16 instructions this wave issues per tile (independent of kt)
-    auto issue = [&](const int8_t* tA, const int8_t* tB, int q, char* stage) {
-        const int p = (pw * 16 + q) * 64 + lane;
-        const bool isB = p >= 2048;
-        const int pp = p & 2047;
-        int row = pp >> 3;
-        const int c = (pp & 7) ^ ((row >> 1) & 7);
-        if (isB) row = row < nB_valid ? row : nB_valid - 1;  // B planes have exactly n rows: clamp instead of padding
-        const int8_t* src = (isB ? tB : tA) + (size_t)row * kp + c * 16;
-        char* dst = stage + ((pw * 16 + q) * 64) * 16;  // wave-uniform; the hardware adds lane*16
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16,
-                                         0, 0);
-    };
+    auto issue = [&](const int8_t* tA, const int8_t* tB, int q, char* stage) { dma_issue(tA, tB, pw * 16 + q, stage, kp, nB_valid, lane); };
 #pragma unroll
     for (int q = 0; q < 16; ++q) issue(gA[0], gB[0], q, smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

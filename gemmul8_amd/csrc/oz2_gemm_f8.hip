@@ -14,11 +14,13 @@
 //   EPI_FINAL : C = C2; combines with the residues of C0, C1 and stores C_mid[t] = int16(value mod p_t)
 //   EPI_MAX   : row/col maxima of fma_ru(ku, C, C) as float bit patterns (atomicMax on non-negative floats)
 //
-// Same structure as oz2_gemm_i8.hip (256x256 tile, 8 consumer + 4 LDS-DMA producer waves, BK = 128 bytes,
-// swizzled 128-B LDS rows, ping-pong segments); the matrix instruction is the block-scaled
+// Same tiling as oz2_gemm_i8.hip (256x256 tile, BK = 128 bytes, swizzled 128-B LDS rows fed by LDS-DMA, ping-pong
+// LOAD/MFMA segments with the two wave halves one slot apart); the matrix instruction is the block-scaled
 // v_mfma_scale_f32_32x32x64_f8f6f4 with unit scales (E8M0 0x7F) -- the only full-rate FP8 MFMA on CDNA4
-// (the unscaled 32x32x16 fp8 form runs at the BF16 rate).  A K-step is 2 MFMA-K of 64; each is split into two
-// LOAD/MFMA segment pairs (row blocks 0-1, then 2-3) to stay within 168 VGPRs.
+// (the unscaled 32x32x16 fp8 form runs at the BF16 rate).  Its 8-VGPR fragments (A 2x8 + B 2x8 live next to the 128
+// accumulators) do not fit the 168-VGPR budget of the 12-wave INT8 layout -- that version spilled accumulators
+// inside the K loop -- so this kernel runs 8 waves (2 per SIMD, 256 VGPRs) and the consumer waves issue the
+// LDS-DMA of the next K-tile themselves in their first two LOAD segments (8 instructions per wave and K-tile).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -54,8 +56,10 @@ struct F8Args {
 
 __device__ __forceinline__ unsigned pack16(int a, int b) { return ((unsigned)a & 0xFFFFu) | ((unsigned)b << 16); }
 
+constexpr int F8_THREADS = 512;
+
 template <int EPI>
-__global__ void __launch_bounds__(WS_THREADS) gemm_f8_kernel(const F8Args args) {
+__global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -68,12 +72,13 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_f8_kernel(const F8Args args) 
     const int nB_valid = (args.n - tn * BN) < BN ? (args.n - tn * BN) : BN;
     const int KT = args.kp / BK;
 
-    if (wave >= 8) {
-        const int8_t* const gA[3] = {args.A + offA, args.A + offA, args.A + offA};
-        const int8_t* const gB[3] = {args.B + offB, args.B + offB, args.B + offB};
-        producer_loop(gA, gB, args.kp, KT, KT, nB_valid, smem, wave - 8, lane);
-        return;
-    }
+    const int8_t* const gA = args.A + offA;
+    const int8_t* const gB = args.B + offB;
+    auto dma_tile = [&](int kt, int q0, int q1) {  // this wave's DMA instructions q0..q1-1 of K-tile kt
+        char* stage = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int q = q0; q < q1; ++q) dma_issue(gA + (size_t)kt * BK, gB + (size_t)kt * BK, wave * 8 + q, stage, args.kp, nB_valid, lane);
+    };
 
     const int wm = wave >> 2, wn = wave & 3;
     const int frow = lane & 31;
@@ -97,10 +102,16 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_f8_kernel(const F8Args args) 
     };
     constexpr int UNIT = 0x7F7F7F7F;  // E8M0 scale 2^0 for every 32-element block
 
+    dma_tile(0, 0, 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();
+    // Hazards: the stage written during K-step kt was last read in K-step kt-1, whose LOAD segments every wave has
+    // finished (lgkmcnt(0) + barrier) before the leading half enters slot 0 of K-step kt; each wave drains its own
+    // DMA (vmcnt(0)) in its last LOAD segment, one barrier before anyone reads the new stage.
     for (int kt = 0; kt < KT; ++kt) {
         char* cur = smem + (kt & 1) * STAGE_BYTES;
+        const bool more = kt + 1 < KT;
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
             const int c0 = ks2 * 4 + khalf * 2;
@@ -108,13 +119,15 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_f8_kernel(const F8Args args) 
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 v8i af[2];
+                if (ks2 == 0 && more) dma_tile(kt + 1, half * 4, half * 4 + 4);
                 if (half == 0) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) bf[j] = frag(cur + b_base + j * 32 * BK, c0);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) af[i] = frag(cur + a_base + (half * 2 + i) * 32 * BK, c0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (ks2 == 1 && half == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -141,6 +154,10 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_f8_kernel(const F8Args args) 
         const int t = args.t_begin + plane;
         const int p = args.moduli[t];
         const int pinv = args.pinv32[t];
+        // value = k0*R0 + k1*R1 + k2*R2:  square moduli s*(R0+R1) + R2;  Karatsuba 256*R0 + 16*(R2-R0-R1) + R1
+        const int k0 = t < 6 ? args.sqrtp[t < 6 ? t : 0] : 240;
+        const int k1 = t < 6 ? k0 : -15;
+        const int k2 = t < 6 ? 1 : 16;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = j0 + j * 32 + frow;
@@ -181,10 +198,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_f8_kernel(const F8Args args) 
                             for (int hlf = 0; hlf < 2; ++hlf) {
                                 const int R0 = (int)(int16_t)(xs[w] >> (16 * hlf)), R1 = (int)(int16_t)(ys[w] >> (16 * hlf)),
                                           R2 = (int)(int16_t)(z[w] >> (16 * hlf));
-                                int v;
-                                if (t < 6) v = args.sqrtp[t] * (R0 + R1) + R2;
-                                else v = 256 * R0 + 16 * (R2 - R0 - R1) + R1;
-                                o[hlf] = mod_i32_sym(v, p, pinv);
+                                o[hlf] = mod_i32_sym(k0 * R0 + k1 * R1 + k2 * R2, p, pinv);
                             }
                             z[w] = pack16(o[0], o[1]);
                         }
@@ -255,7 +269,7 @@ template <int EPI> static hipError_t launch(hipStream_t stream, const F8Args& a,
     }
     const int grid = planes * a.tiles_m * a.tiles_n;
     if (grid <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gemm_f8_kernel<EPI>, dim3(grid), dim3(WS_THREADS), LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(gemm_f8_kernel<EPI>, dim3(grid), dim3(F8_THREADS), LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 

@@ -65,8 +65,13 @@ struct GemmArgs {
     int pinv32[20];
 };
 
+#ifndef OZ2_I8_WS
+#define OZ2_I8_WS 1
+#endif
+constexpr int I8_THREADS = OZ2_I8_WS ? WS_THREADS : 512;
+
 template <int EPI>
-__global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args) {
+__global__ void __launch_bounds__(I8_THREADS) gemm_i8_kernel(const GemmArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -80,12 +85,21 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     const int KT1 = args.kp / BK;        // K-steps per segment
     const int KT = KT1 * args.nseg;      // total K-steps
 
+#if OZ2_I8_WS
     if (wave >= 8) {  // ------------------------------ producer waves: LDS-DMA only
         const int8_t* const gA[3] = {args.A[0] + offA, args.A[1] + offA, args.A[2] + offA};
         const int8_t* const gB[3] = {args.B[0] + offB, args.B[1] + offB, args.B[2] + offB};
         producer_loop(gA, gB, args.kp, KT1, KT, nB_valid, smem, wave - 8, lane);
         return;
     }
+#else
+    const int8_t* tA = args.A[0] + offA;  // K-tile being fetched (kt + 1 inside the loop)
+    const int8_t* tB = args.B[0] + offB;
+    int seg = 0, kin = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dma_issue(tA, tB, wave * 8 + q, smem, args.kp, nB_valid, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 
     // ------------------------------ consumer waves
     const int wm = wave >> 2, wn = wave & 3;
@@ -107,14 +121,33 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     if (wm == 1) __builtin_amdgcn_s_barrier();  // trailing half: one segment behind
     for (int kt = 0; kt < KT; ++kt) {
         char* cur = smem + (kt & 1) * STAGE_BYTES;
+#if !OZ2_I8_WS
+        char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+        const bool more = kt + 1 < KT;
+        if (++kin == KT1) kin = 0, ++seg;
+        {
+            const int sg = seg < 3 ? seg : 2;
+            tA = args.A[sg] + offA + (size_t)kin * BK;
+            tB = args.B[sg] + offB + (size_t)kin * BK;
+        }
+#endif
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int coff = (((ks << 1) | khalf) ^ sw) << 4;
             v4i af[4], bf[2];
+#if !OZ2_I8_WS
+            if (ks < 2 && more) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dma_issue(tA, tB, wave * 8 + ks * 4 + q, nxt, args.kp, nB_valid, lane);
+            }
+#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = *(const v4i*)(cur + a_base + i * 32 * BK + coff);
 #pragma unroll
             for (int j = 0; j < 2; ++j) bf[j] = *(const v4i*)(cur + b_base + j * 32 * BK + coff);
+#if !OZ2_I8_WS
+            if (ks == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -254,7 +287,7 @@ template <int EPI> static hipError_t launch(hipStream_t stream, const GemmArgs& 
     }
     const int grid = planes * a.tiles_m * a.tiles_n;
     if (grid <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gemm_i8_kernel<EPI>, dim3(grid), dim3(WS_THREADS), LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(gemm_i8_kernel<EPI>, dim3(grid), dim3(I8_THREADS), LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 
