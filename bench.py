@@ -12,6 +12,7 @@ the batched INT8 MFMA GEMM, events recorded on the launch stream inside the time
 the box's cores, same shape) and `max_rel_err` (vs an 80-bit long-double product on a sampled block).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -279,11 +280,20 @@ def main():
         if gemm_ms:
             ach = ops / (gemm_ms * 1e-3) * 1e-12
             roof = {"bound": "mfma", "kernel": "oz2::gemm_i8_kernel<EPI_MOD> (batched over moduli)", "achieved": ach, "peak": peak,
-                    "unit": "TOP/s", "frac": ach / peak, "traffic": None, "launch_ms": gemm_ms, "ops_per_launch": ops}
+                    "unit": "TOP/s", "frac": ach / peak, "traffic": None, "launch_ms": gemm_ms, "ops_per_launch": ops,
+                    "algorithmic_bytes_per_launch": planes_here * 3.0 * n * n}
+            # HBM-side bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
+            # WRITE_SIZE, tools/pmc_traffic.py); only valid for the configuration that was profiled
+            tf = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+            if tf and world == 1 and n == 8192 and N == 14:
+                rec = json.load(open(tf[-1])).get("oz2::gemm_i8_kernel<0>")
+                if rec:
+                    roof["traffic"] = rec["hbm_side_bytes_per_launch"]
+                    roof["traffic_source"] = "profiles/" + os.path.basename(tf[-1])
         out = {
             "metric": "emulated DGEMM TFLOPS (N=8192, moduli=14)", "value": value, "unit": "TFLOPS", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "int8 MFMA (i32 accumulate) + f64 CRT", "data": "synthetic U(-0.5,0.5), seeds 12345/54321",
+            "vs_baseline": None, "dtype": "int8", "dtype_detail": "int8 MFMA (i32 accumulate) + f64 CRT", "data": "synthetic U(-0.5,0.5), seeds 12345/54321",
             "config": {"workload": f"DGEMM {n}x{n}x{n}, moduli={N}, INT8 backend, {'fast' if args.fast else 'accurate'} mode "
                                    f"({N + (0 if args.fast else 1)} INT8 GEMMs), op N/N, alpha=1, beta=0, inputs resident in HBM",
                        "parallelism": parallelism},

@@ -121,6 +121,23 @@ __device__ __forceinline__ int mod_i32_sym(int a, int p, int pinv32) {
     return wrapping(rem, p);
 }
 
+// The same residue for ODD p and |a| <= 2^30 (k <= 65536) with full-rate instructions only (v_mul_hi/v_mul_lo_u32 are
+// quarter rate): two fp32 quotient steps.  Step 1: q = rint(float(a)/p) is off by at most 2 (float(a) is exact to
+// 2^-24 relative, |a|/p < 2^23 so q*p is a 24-bit multiply), leaving |r| <= 2.5 p.  Step 2 is exact: float(r) is exact
+// and r/p is at least 1/(2p) away from a rounding tie for odd p, so the result is the canonical representative in
+// [-(p-1)/2, (p-1)/2] -- identical to mod_i32_sym (checked exhaustively over residue classes in tests/test_cabi.py
+// through the oracle and bit-for-bit by the GPU parity tests).
+__device__ __forceinline__ int mod_i32_sym_odd(int a, int p, float invp) {
+    int q = (int)rintf((float)a * invp);
+    const int r = a - __mul24(q, p);
+    q = (int)rintf((float)r * invp);
+    return r - __mul24(q, p);
+}
+// |a| < 2^16: one exact step
+__device__ __forceinline__ int mod_small_sym_odd(int a, int p, float invp) {
+    return a - __mul24((int)rintf((float)a * invp), p);
+}
+
 // ---------------------------------------------------------------- OCP FP8 e4m3 helpers (FP8 backend)
 // two small integers (|v| <= 16, exactly representable) -> two e4m3 bytes in the low half of the result
 __device__ __forceinline__ unsigned fp8x2_from_ints(int a, int b) {

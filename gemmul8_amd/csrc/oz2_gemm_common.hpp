@@ -23,15 +23,27 @@ constexpr int PSLOTS = OZ2_PSLOTS;  // slots (of 8 per K-step) over which a prod
 struct TileMap {
     int plane, tm, tn;
 };
-// block b runs on XCD b%8: give each XCD a contiguous tile range; inside a plane, groups of 8 tile-rows with the
-// tile-row index fastest, so the 32 CUs of an XCD work on 8 x 4 tiles sharing 8 + 4 operand panels.
-__device__ __forceinline__ TileMap map_tile(int tiles_m, int tiles_n) {
+// block b runs on XCD b%8 (round-robin dispatch).  The tile sequence (plane-major; inside a plane groups of 8 tile-rows
+// with the tile-row index fastest) is cut into chunks of 256 = the tiles in flight at once; inside a chunk XCD x takes
+// 32 consecutive tiles = 8 x 4 tiles sharing 8 + 4 operand panels in its L2, and all 8 XCDs work on the SAME plane and
+// the same 8 A panels, so the L2 misses of one chunk (<= 8 + 32 panels of one plane) are served by the 256 MiB
+// Infinity Cache instead of HBM.  The tail (< 264 blocks) is split contiguously over the XCDs.
+#ifndef OZ2_MAP_CHUNKED
+#define OZ2_MAP_CHUNKED 1
+#endif
+// bid: (virtual) workgroup id -- blockIdx.x + round * gridDim.x in the persistent kernels, gridDim.x a multiple of 8
+// whenever there is more than one round -- nwg: total number of tiles.
+__device__ __forceinline__ TileMap map_tile(int bid, int nwg, int tiles_m, int tiles_n) {
     const int tiles_per_plane = tiles_m * tiles_n;
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
     {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int fc = OZ2_MAP_CHUNKED ? ((nwg >> 3) >> 5) : 0;  // full chunks of 256
+        if (idx < fc * 32) {
+            bid = (idx >> 5) * 256 + xcd * 32 + (idx & 31);
+        } else {
+            const int rem = nwg - fc * 256, q = rem >> 3, r = rem & 7, i2 = idx - fc * 32;
+            bid = fc * 256 + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i2;
+        }
     }
     TileMap t;
     t.plane = bid / tiles_per_plane;
@@ -60,36 +72,6 @@ __device__ __forceinline__ void dma_issue(const int8_t* tA, const int8_t* tB, in
     const int8_t* src = (isB ? tB : tA) + (size_t)row * kp + c * 16;
     char* dst = stage + (Q * 64) * 16;  // wave-uniform; the hardware adds lane*16
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-}
-
-// Producer wave pw = 0..3: DMA instructions Q = pw*16 .. pw*16+15 of every K-tile.
-// gA[s]/gB[s]: K-segment s, already offset to this workgroup's first row.  Executes 8*KT + 2 barriers.
-__device__ __forceinline__ void producer_loop(const int8_t* const (&gA)[3], const int8_t* const (&gB)[3], int kp, int KT1, int KT,
-                                              int nB_valid, char* smem, int pw, int lane) {
-    auto issue = [&](const int8_t* tA, const int8_t* tB, int q, char* stage) { dma_issue(tA, tB, pw * 16 + q, stage, kp, nB_valid, lane); };
-#pragma unroll
-    for (int q = 0; q < 16; ++q) issue(gA[0], gB[0], q, smem);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int seg = 0, kin = 0;  // segment / K-step inside the segment of tile kt+1 (no divisions in the loop)
-    for (int kt = 0; kt < KT; ++kt) {
-        char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
-        const bool more = kt + 1 < KT;
-        if (++kin == KT1) kin = 0, ++seg;
-        const int sg = seg < 3 ? seg : 2;
-        const int8_t* tA = gA[sg] + (size_t)kin * BK;
-        const int8_t* tB = gB[sg] + (size_t)kin * BK;
-#pragma unroll
-        for (int sl = 0; sl < 8; ++sl) {
-            if (sl < PSLOTS && more) {
-#pragma unroll
-                for (int q = 0; q < 16 / PSLOTS; ++q) issue(tA, tB, sl * (16 / PSLOTS) + q, nxt);
-            }
-            if (sl == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-    }
-    __builtin_amdgcn_s_barrier();
 }
 
 }  // namespace oz2

@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const TileMap tmap = map_tile(args.tiles_m, args.tiles_n);
+    const TileMap tmap = map_tile(blockIdx.x, gridDim.x, args.tiles_m, args.tiles_n);
     const int plane = tmap.plane, tm = tmap.tm, tn = tmap.tn;
     const size_t offA = (size_t)args.planeA[plane] * args.strideA + (size_t)tm * BM * args.kp;
     const size_t offB = (size_t)args.planeB[plane] * args.strideB + (size_t)tn * BN * args.kp;
@@ -158,6 +158,28 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
         const int k0 = t < 6 ? args.sqrtp[t < 6 ? t : 0] : 240;
         const int k1 = t < 6 ? k0 : -15;
         const int k2 = t < 6 ? 1 : 16;
+        // Odd p: residues in fp32 (accumulators are exact integers, |c| <= 2^24): q = rint(c/p) may be off by one near a
+        // rounding tie (error 2^-23 * 2^24/p vs tie distance 1/2p), a second step on |r| <= 1.5 p is exact; the combined
+        // value (|v| < 2^18) needs one step.  p = 1024 (even: the tie +-512 must keep the reference's representative)
+        // takes the integer path.
+        const bool odd = p & 1;
+        const float pf = (float)p, invp = 1.0f / pf;
+        auto red_acc = [&](float c) -> int {
+            if (odd) {
+                float q = rintf(c * invp);
+                float r = fmaf(-q, pf, c);
+                q = rintf(r * invp);
+                return (int)fmaf(-q, pf, r);
+            }
+            return mod_i32_sym(__float2int_rn(c), p, pinv);
+        };
+        auto red_small = [&](int v) -> int {
+            if (odd) {
+                const float vf = (float)v;
+                return (int)fmaf(-rintf(vf * invp), pf, vf);
+            }
+            return mod_i32_sym(v, p, pinv);
+        };
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = j0 + j * 32 + frow;
@@ -168,7 +190,7 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
                 for (int q = 0; q < 4; ++q) {
                     int r[4];
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) r[b] = mod_i32_sym(__float2int_rn(acc[i][j][q * 4 + b]), p, pinv);
+                    for (int b = 0; b < 4; ++b) r[b] = red_acc(acc[i][j][q * 4 + b]);
                     d[q][0] = pack16(r[0], r[1]);
                     d[q][1] = pack16(r[2], r[3]);
                 }
@@ -198,7 +220,7 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
                             for (int hlf = 0; hlf < 2; ++hlf) {
                                 const int R0 = (int)(int16_t)(xs[w] >> (16 * hlf)), R1 = (int)(int16_t)(ys[w] >> (16 * hlf)),
                                           R2 = (int)(int16_t)(z[w] >> (16 * hlf));
-                                o[hlf] = mod_i32_sym(k0 * R0 + k1 * R1 + k2 * R2, p, pinv);
+                                o[hlf] = red_small(k0 * R0 + k1 * R1 + k2 * R2);
                             }
                             z[w] = pack16(o[0], o[1]);
                         }

@@ -61,173 +61,104 @@ struct GemmArgs {
     size_t strideR;
     int* rowmax;           // EPI_MAX
     int* colmax;
+    int total_tiles;       // planes * tiles_m * tiles_n
     int moduli[20];
     int pinv32[20];
 };
 
-#ifndef OZ2_I8_WS
-#define OZ2_I8_WS 1
+// Epilogues on a wave's 128 x (32*NJ) accumulator block (first row i0, first column j0).  Accumulator map of
+// v_mfma_i32_32x32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); MFMA rows <-> C rows i (A_lo rows),
+// MFMA cols <-> C cols j.
+#ifndef OZ2_ABL_EPI
+#define OZ2_ABL_EPI 0  // 1: no stores, 2: every plane takes the p = 256 path (timing ablations only)
 #endif
-constexpr int I8_THREADS = OZ2_I8_WS ? WS_THREADS : 512;
-
-template <int EPI>
-__global__ void __launch_bounds__(I8_THREADS) gemm_i8_kernel(const GemmArgs args) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    const TileMap tmap = map_tile(args.tiles_m, args.tiles_n);
-    const int plane = tmap.plane, tm = tmap.tm, tn = tmap.tn;
-    const size_t offA = (size_t)plane * args.strideA + (size_t)tm * BM * args.kp;
-    const size_t offB = (size_t)plane * args.strideB + (size_t)tn * BN * args.kp;
-    const int nB_valid = (args.n - tn * BN) < BN ? (args.n - tn * BN) : BN;
-    const int KT1 = args.kp / BK;        // K-steps per segment
-    const int KT = KT1 * args.nseg;      // total K-steps
-
-#if OZ2_I8_WS
-    if (wave >= 8) {  // ------------------------------ producer waves: LDS-DMA only
-        const int8_t* const gA[3] = {args.A[0] + offA, args.A[1] + offA, args.A[2] + offA};
-        const int8_t* const gB[3] = {args.B[0] + offB, args.B[1] + offB, args.B[2] + offB};
-        producer_loop(gA, gB, args.kp, KT1, KT, nB_valid, smem, wave - 8, lane);
-        return;
-    }
-#else
-    const int8_t* tA = args.A[0] + offA;  // K-tile being fetched (kt + 1 inside the loop)
-    const int8_t* tB = args.B[0] + offB;
-    int seg = 0, kin = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) dma_issue(tA, tB, wave * 8 + q, smem, args.kp, nB_valid, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-
-    // ------------------------------ consumer waves
-    const int wm = wave >> 2, wn = wave & 3;
+enum { RED_GENERIC = 0, RED_ODD = 1, RED_256 = 2 };
+// RED selects how an accumulator is reduced (uniform per plane): RED_256: p = 256, the symmetric residue IS the low byte;
+// RED_ODD: odd p and k <= 65536, two-step fp32 quotient (full-rate VALU only); RED_GENERIC: 32-bit multiply-high.
+template <int EPI, int NJ, int RED>
+__device__ __forceinline__ void i8_epilogue_mod(const v16i (&acc)[4][NJ], const GemmArgs& args, int plane, int i0, int j0, int lane) {
     const int frow = lane & 31;
     const int khalf = lane >> 5;
-    const int sw = (frow >> 1) & 7;
-    const int a_base = (wm * 128 + frow) * BK;
-    const int b_base = TILE_BYTES + (wn * 64 + frow) * BK;
-
-    v16i acc[4][2];
+    const int t = args.t_begin + plane;
+    const int p = args.moduli[t];
+    const int pinv = args.pinv32[t];
+    const float invp = 1.0f / (float)p;
+    auto red = [&](int x) {
+        if constexpr (RED == RED_256) return x;
+        else if constexpr (RED == RED_ODD) return mod_i32_sym_odd(x, p, invp);
+        else return mod_i32_sym(x, p, pinv);
+    };
+    auto red_small = [&](int x) {
+        if constexpr (RED == RED_256) return x;
+        else if constexpr (RED == RED_ODD) return mod_small_sym_odd(x, p, invp);
+        else return mod_i32_sym(x, p, pinv);
+    };
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < NJ; ++j) {
+        const int col = j0 + j * 32 + frow;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 4; ++i) {
+            unsigned d[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-
-    __builtin_amdgcn_s_barrier();               // tile 0 published by the producers
-    if (wm == 1) __builtin_amdgcn_s_barrier();  // trailing half: one segment behind
-    for (int kt = 0; kt < KT; ++kt) {
-        char* cur = smem + (kt & 1) * STAGE_BYTES;
-#if !OZ2_I8_WS
-        char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
-        const bool more = kt + 1 < KT;
-        if (++kin == KT1) kin = 0, ++seg;
-        {
-            const int sg = seg < 3 ? seg : 2;
-            tA = args.A[sg] + offA + (size_t)kin * BK;
-            tB = args.B[sg] + offB + (size_t)kin * BK;
-        }
-#endif
+            for (int q = 0; q < 4; ++q) {
+                unsigned w = 0;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int coff = (((ks << 1) | khalf) ^ sw) << 4;
-            v4i af[4], bf[2];
-#if !OZ2_I8_WS
-            if (ks < 2 && more) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) dma_issue(tA, tB, wave * 8 + ks * 4 + q, nxt, args.kp, nB_valid, lane);
+                for (int b = 0; b < 4; ++b) {
+                    const int r = red(acc[i][j][q * 4 + b]);
+                    w |= ((unsigned)r & 0xFFu) << (8 * b);
+                }
+                d[q] = w;
             }
-#endif
+            // lane-half h owns rows 8q+4h..+3.  Exchange so that h=0 owns rows 0..15 and h=1 rows 16..31.
+            auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+            const unsigned z[4] = {s0[0], s0[1], s1[0], s1[1]};
+            if (col < args.n && !(OZ2_ABL_EPI == 1 && args.kp > 0)) {
+                const size_t e = (size_t)col * args.ldo + i0 + i * 32 + khalf * 16;  // first of 16 consecutive rows
+                if constexpr (EPI == EPI_MOD) {
+                    *(uint4*)(args.out + (size_t)plane * args.strideO + e) = make_uint4(z[0], z[1], z[2], z[3]);
+                } else {
+                    const uint4 x4 = *(const uint4*)(args.rx + (size_t)plane * args.strideR + e);
+                    const uint4 y4 = *(const uint4*)(args.ry + (size_t)plane * args.strideR + e);
+                    const unsigned xs[4] = {x4.x, x4.y, x4.z, x4.w}, ys[4] = {y4.x, y4.y, y4.z, y4.w};
+                    unsigned o[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *(const v4i*)(cur + a_base + i * 32 * BK + coff);
+                    for (int w4 = 0; w4 < 4; ++w4) {
+                        unsigned lo = 0, hi = 0;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = *(const v4i*)(cur + b_base + j * 32 * BK + coff);
-#if !OZ2_I8_WS
-            if (ks == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
+                        for (int b = 0; b < 4; ++b) {
+                            const int X = (int)(int8_t)(xs[w4] >> (8 * b)), Y = (int)(int8_t)(ys[w4] >> (8 * b)), Z = (int)(int8_t)(z[w4] >> (8 * b));
+                            const int cr = red_small(X - Y), ci = red_small(Z - X - Y);
+                            const unsigned pair = ((unsigned)cr & 0xFFu) | (((unsigned)ci & 0xFFu) << 8);
+                            if (b < 2) lo |= pair << (16 * b);
+                            else hi |= pair << (16 * (b - 2));
+                        }
+                        o[2 * w4] = lo;
+                        o[2 * w4 + 1] = hi;
+                    }
+                    uint4* dst = (uint4*)(args.out + (size_t)plane * args.strideO + 2 * e);
+                    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+                    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+                }
+            }
         }
     }
-    if (wm == 0) __builtin_amdgcn_s_barrier();
+}
 
-    // ------------------------------ epilogues.  Accumulator map of v_mfma_i32_32x32x32: col = lane&31,
-    // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); MFMA rows <-> C rows i (A_lo rows), MFMA cols <-> C cols j.
-    const int i0 = tm * BM + wm * 128;
-    const int j0 = tn * BN + wn * 64;
+template <int EPI, int NJ>
+__device__ __forceinline__ void i8_epilogue(const v16i (&acc)[4][NJ], const GemmArgs& args, int plane, int i0, int j0, int lane) {
+    const int frow = lane & 31;
+    const int khalf = lane >> 5;
 
     if constexpr (EPI == EPI_MOD || EPI == EPI_CPLX) {
-        const int t = args.t_begin + plane;
-        const int p = args.moduli[t];
-        const int pinv = args.pinv32[t];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = j0 + j * 32 + frow;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                unsigned d[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    unsigned w = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int r = mod_i32_sym(acc[i][j][q * 4 + b], p, pinv);
-                        w |= ((unsigned)r & 0xFFu) << (8 * b);
-                    }
-                    d[q] = w;
-                }
-                // lane-half h owns rows 8q+4h..+3.  Exchange so that h=0 owns rows 0..15 and h=1 rows 16..31.
-                auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
-                auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
-                const unsigned z[4] = {s0[0], s0[1], s1[0], s1[1]};
-                if (col < args.n) {
-                    const size_t e = (size_t)col * args.ldo + i0 + i * 32 + khalf * 16;  // first of 16 consecutive rows
-                    if constexpr (EPI == EPI_MOD) {
-                        *(uint4*)(args.out + (size_t)plane * args.strideO + e) = make_uint4(z[0], z[1], z[2], z[3]);
-                    } else {
-                        const uint4 x4 = *(const uint4*)(args.rx + (size_t)plane * args.strideR + e);
-                        const uint4 y4 = *(const uint4*)(args.ry + (size_t)plane * args.strideR + e);
-                        const unsigned xs[4] = {x4.x, x4.y, x4.z, x4.w}, ys[4] = {y4.x, y4.y, y4.z, y4.w};
-                        unsigned o[8];
-#pragma unroll
-                        for (int w4 = 0; w4 < 4; ++w4) {
-                            unsigned lo = 0, hi = 0;
-#pragma unroll
-                            for (int b = 0; b < 4; ++b) {
-                                const int X = (int)(int8_t)(xs[w4] >> (8 * b)), Y = (int)(int8_t)(ys[w4] >> (8 * b)), Z = (int)(int8_t)(z[w4] >> (8 * b));
-                                const int cr = mod_i32_sym(X - Y, p, pinv), ci = mod_i32_sym(Z - X - Y, p, pinv);
-                                const unsigned pair = ((unsigned)cr & 0xFFu) | (((unsigned)ci & 0xFFu) << 8);
-                                if (b < 2) lo |= pair << (16 * b);
-                                else hi |= pair << (16 * (b - 2));
-                            }
-                            o[2 * w4] = lo;
-                            o[2 * w4 + 1] = hi;
-                        }
-                        uint4* dst = (uint4*)(args.out + (size_t)plane * args.strideO + 2 * e);
-                        dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-                        dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
-                    }
-                }
-            }
-        }
+        const int p = args.moduli[args.t_begin + plane];
+        if (p == 256 || OZ2_ABL_EPI == 2) i8_epilogue_mod<EPI, NJ, RED_256>(acc, args, plane, i0, j0, lane);
+        else if ((p & 1) && args.kp * args.nseg <= 65536) i8_epilogue_mod<EPI, NJ, RED_ODD>(acc, args, plane, i0, j0, lane);
+        else i8_epilogue_mod<EPI, NJ, RED_GENERIC>(acc, args, plane, i0, j0, lane);
     } else {
         // column max over this lane's 64 rows (masked to valid rows), then across the two lane halves
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             int cm = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -249,7 +180,7 @@ __global__ void __launch_bounds__(I8_THREADS) gemm_i8_kernel(const GemmArgs args
             for (int r = 0; r < 16; ++r) {
                 int v = 0;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     const int col = j0 + j * 32 + frow;
                     const int a = (col < args.n) ? acc[i][j][r] : 0;
                     v = a > v ? a : v;
@@ -265,6 +196,150 @@ __global__ void __launch_bounds__(I8_THREADS) gemm_i8_kernel(const GemmArgs args
     }
 }
 
+// Persistent, wave-specialised kernel: one workgroup per CU (128 KiB of LDS) loops over tiles vb = blockIdx.x,
+// blockIdx.x + gridDim.x, ...; 8 consumer waves (2 x 4, each 128 x 64 of the 256 x 256 tile) run MFMA + epilogue, 4
+// producer waves only issue LDS-DMA.  The two-stage K pipeline runs straight through tile boundaries: while the consumers
+// are in the last K-step and the epilogue of a tile the producers already fetch the first K-tile of the next one, the
+// epilogue's stores drain behind the next tile's MFMAs, and there is no workgroup launch / LDS re-allocation between
+// tiles -- a non-persistent version of this kernel lost ~11 us of a ~120 us tile to those three.
+template <int EPI>
+__global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int KT1 = args.kp / BK;    // K-steps per segment
+    const int KT = KT1 * args.nseg;  // K-steps per tile
+    const int total = args.total_tiles;
+    const int G = gridDim.x;
+
+    if (wave >= 8) {  // ------------------------------ producer waves: LDS-DMA only
+        // Wave pw issues DMA instructions Q = 16 pw .. 16 pw + 15 of every K-tile (1 KiB = 8 rows x 128 B each; 4096 16-byte
+        // LDS slots per stage: slot s <-> operand (s >= 2048: B), row (s & 2047) >> 3, physical chunk s & 7 holding logical
+        // chunk (s & 7) ^ ((row >> 1) & 7)), i.e. waves 0,1 fetch A and waves 2,3 fetch B.  Per tile: a wave-uniform base
+        // pointer per K segment and 16 per-lane byte offsets (row * kp + chunk, B rows clamped to the rows that exist), so
+        // the K loop issues global_load_lds with SGPR base + VGPR offset and no address arithmetic.
+        const int pw = wave - 8;
+        const bool isB = pw >= 2;
+        unsigned doff[16];
+        const int8_t *g0, *g1, *g2;
+        auto uniform = [](const int8_t* ptr) {
+            const unsigned long long v = (unsigned long long)ptr;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+            return (const int8_t*)(((unsigned long long)hi << 32) | lo);
+        };
+#define PRODUCER_SET_TILE(vb_)                                                                                               \
+    do {                                                                                                                     \
+        const TileMap tmap_ = map_tile((vb_), total, args.tiles_m, args.tiles_n);                                            \
+        const size_t off_ = isB ? (size_t)tmap_.plane * args.strideB + (size_t)tmap_.tn * BN * args.kp                       \
+                                : (size_t)tmap_.plane * args.strideA + (size_t)tmap_.tm * BM * args.kp;                      \
+        g0 = uniform((isB ? args.B[0] : args.A[0]) + off_);                                                                  \
+        g1 = uniform((isB ? args.B[1] : args.A[1]) + off_);                                                                  \
+        g2 = uniform((isB ? args.B[2] : args.A[2]) + off_);                                                                  \
+        const int nvalid_ = isB ? ((args.n - tmap_.tn * BN) < BN ? (args.n - tmap_.tn * BN) : BN) : BM;                       \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                                     \
+            const int pp_ = (((pw & 1) * 16 + q) * 64 + lane);                                                               \
+            int row_ = pp_ >> 3;                                                                                             \
+            const int c_ = (pp_ & 7) ^ ((row_ >> 1) & 7);                                                                    \
+            row_ = row_ < nvalid_ ? row_ : nvalid_ - 1;                                                                      \
+            doff[q] = (unsigned)row_ * (unsigned)args.kp + c_ * 16;                                                          \
+        }                                                                                                                    \
+    } while (0)
+#define PRODUCER_DMA(src_, q_, stage_)                                                                                       \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((src_) + doff[q_]),                     \
+                                     (__attribute__((address_space(3))) void*)((stage_) + (pw * 16 + (q_)) * 1024), 16, 0, 0)
+
+        int vb_next = blockIdx.x;  // tile of the K-tile to fetch next
+        PRODUCER_SET_TILE(vb_next);
+        int seg = 0, kin = 0;      // its segment / K-step inside the segment (no divisions in the loop)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) PRODUCER_DMA(g0, q, smem);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int g = 0;  // K-steps done (stage = g & 1)
+        for (int vb = blockIdx.x; vb < total; vb += G) {
+            for (int kt = 0; kt < KT; ++kt, ++g) {
+                char* nxt = smem + ((g + 1) & 1) * STAGE_BYTES;
+                // advance (vb_next, seg, kin) to the K-tile after the current one
+                bool more = true;
+                if (++kin == KT1) {
+                    kin = 0;
+                    if (++seg == args.nseg) {
+                        seg = 0;
+                        vb_next += G;
+                        more = vb_next < total;
+                        if (more) PRODUCER_SET_TILE(vb_next);
+                    }
+                }
+                const int8_t* src = (seg == 0 ? g0 : seg == 1 ? g1 : g2) + (size_t)kin * BK;
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) {
+                    if (sl < PSLOTS && more) {
+#pragma unroll
+                        for (int q = 0; q < 16 / PSLOTS; ++q) PRODUCER_DMA(src, sl * (16 / PSLOTS) + q, nxt);
+                    }
+                    if (sl == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+#undef PRODUCER_SET_TILE
+#undef PRODUCER_DMA
+        return;
+    }
+
+    // ------------------------------ consumer waves
+    const int wm = wave >> 2, wn = wave & 3;
+    const int frow = lane & 31;
+    const int khalf = lane >> 5;
+    const int sw = (frow >> 1) & 7;
+    const int a_base = (wm * 128 + frow) * BK;
+    const int b_base = TILE_BYTES + (wn * 64 + frow) * BK;
+
+    __builtin_amdgcn_s_barrier();               // K-tile 0 published by the producers
+    if (wm == 1) __builtin_amdgcn_s_barrier();  // trailing half: one segment behind
+    int g = 0;
+    for (int vb = blockIdx.x; vb < total; vb += G) {
+        v16i acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+        for (int kt = 0; kt < KT; ++kt, ++g) {
+            char* cur = smem + (g & 1) * STAGE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int coff = (((ks << 1) | khalf) ^ sw) << 4;
+                v4i af[4], bf[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = *(const v4i*)(cur + a_base + i * 32 * BK + coff);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = *(const v4i*)(cur + b_base + j * 32 * BK + coff);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n);
+        i8_epilogue<EPI, 2>(acc, args, tmap.plane, tmap.tm * BM + wm * 128, tmap.tn * BN + wn * 64, lane);
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+}
+
 static void fill_common(GemmArgs& a, size_t kp, size_t m, size_t n) {
     a.kp = (int)kp;
     a.m = (int)m;
@@ -278,16 +353,33 @@ static void fill_common(GemmArgs& a, size_t kp, size_t m, size_t n) {
     }
 }
 
-template <int EPI> static hipError_t launch(hipStream_t stream, const GemmArgs& a, int planes) {
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) return 256;
+        n = prop.multiProcessorCount;
+    }
+    return n;
+}
+
+template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int planes) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int grid = planes * a.tiles_m * a.tiles_n;
-    if (grid <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gemm_i8_kernel<EPI>, dim3(grid), dim3(I8_THREADS), LDS_BYTES, stream, a);
+    a.total_tiles = planes * a.tiles_m * a.tiles_n;
+    if (a.total_tiles <= 0) return hipSuccess;
+    // persistent: one workgroup per CU; a multiple of 8 keeps "workgroup b runs on XCD b % 8" aligned with map_tile.
+    // Measured interleaved against one-workgroup-per-tile launches of the same kernel (tools/gemm_ab.py, 8192 x 8192 x k,
+    // 14 planes): 13 % faster at k = 256, 7 % at k = 2048, 1 % at k = 8192.
+    int grid = num_cus() & ~7;
+    if (grid <= 0) grid = 8;
+    if (a.total_tiles < grid) grid = a.total_tiles;
+    hipLaunchKernelGGL(gemm_i8_kernel<EPI>, dim3(grid), dim3(WS_THREADS), LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 

@@ -1,0 +1,54 @@
+"""CPU model of the full-rate fp32 residue reduction used by the INT8 GEMM epilogue (oz2_device.hpp: mod_i32_sym_odd,
+mod_small_sym_odd) checked against exact integer arithmetic.  numpy float32 multiply / rint are the same IEEE operations
+the kernel is compiled to (-ffp-contract=off, v_mul_f32 + v_rndne_f32)."""
+import numpy as np
+import pytest
+
+INT8_MODULI = [256, 255, 253, 251, 247, 241, 239, 233, 229, 227, 223, 217, 211, 199, 197, 193, 191, 181, 179, 173]
+
+
+def sym_exact(a, p):
+    r = np.mod(a, p)
+    return np.where(r > (p - 1) // 2, r - p, r)
+
+
+def model_odd(a, p):
+    invp = np.float32(1.0) / np.float32(p)
+    q = np.rint(a.astype(np.float32) * invp).astype(np.int64)
+    assert np.all(np.abs(q) < 2 ** 23), "24-bit multiply operand out of range"
+    r = a - q * p
+    q2 = np.rint(r.astype(np.float32) * invp).astype(np.int64)
+    return r - q2 * p
+
+
+def test_moduli_table_matches():
+    import ctypes, os
+    # the list above is the generated table (first 20 INT8 moduli)
+    inc = open(os.path.join(os.path.dirname(__file__), "..", "gemmul8_amd", "csrc", "tables.inc")).read()
+    body = inc[inc.index("GEMMUL8_MODULI_INT8"):]
+    body = body[body.index("{") + 1:body.index("}")]
+    assert [int(x) for x in body.replace("\n", " ").split(",") if x.strip()] == INT8_MODULI
+
+
+@pytest.mark.parametrize("p", [m for m in INT8_MODULI if m & 1])
+def test_two_step_fp32_reduction_is_exact(p):
+    rng = np.random.default_rng(p)
+    lim = 2 ** 30
+    parts = [rng.integers(-lim, lim + 1, size=2_000_000, dtype=np.int64),
+             np.arange(-lim, -lim + 70_000, dtype=np.int64), np.arange(lim - 70_000, lim + 1, dtype=np.int64),
+             np.arange(-70_000, 70_000, dtype=np.int64)]
+    # every residue class at many quotients, including the rounding ties q*p +- (p-1)/2, (p+1)/2
+    qs = np.concatenate([rng.integers(-(lim // p), lim // p, size=4000), [-(lim // p), lim // p - 1, 0, 1, -1]])
+    rs = np.arange(-(p // 2) - 1, p // 2 + 2)
+    parts.append(np.clip((qs[:, None] * p + rs[None, :]).ravel(), -lim, lim))
+    a = np.concatenate(parts)
+    got = model_odd(a, p)
+    assert np.array_equal(got, sym_exact(a, p))
+
+
+@pytest.mark.parametrize("p", [m for m in INT8_MODULI if m & 1])
+def test_one_step_small(p):
+    a = np.arange(-65535, 65536, dtype=np.int64)
+    invp = np.float32(1.0) / np.float32(p)
+    got = a - np.rint(a.astype(np.float32) * invp).astype(np.int64) * p
+    assert np.array_equal(got, sym_exact(a, p))
