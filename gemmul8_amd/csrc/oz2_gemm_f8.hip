@@ -49,6 +49,7 @@ struct F8Args {
     int* rowmax;          // EPI_FMAX (float bit patterns)
     int* colmax;
     float ku;             // (k+1) * 2^-24
+    int total_tiles;      // planes * tiles_m * tiles_n
     int moduli[20];
     int pinv32[20];
     int sqrtp[6];
@@ -58,27 +59,173 @@ __device__ __forceinline__ unsigned pack16(int a, int b) { return ((unsigned)a &
 
 constexpr int F8_THREADS = 512;
 
+// int16 residue epilogues (EPI_PART / EPI_FINAL) of a wave's 128 x 64 accumulator block.  ODD: odd modulus -- residues in
+// fp32 (accumulators are exact integers, |c| <= 2^24): q = rint(c/p) may be off by one near a rounding tie (error
+// 2^-23 * 2^24/p against a tie distance of 1/2p), a second step on |r| <= 1.5 p is exact; the combined value (|v| < 2^18)
+// needs one step.  p = 1024 (even: the tie +-512 must keep the reference's representative) takes the integer path.
+template <int EPI, bool ODD>
+__device__ __forceinline__ void f8_epilogue_mod(const v16f (&acc)[4][2], const F8Args& args, int plane, int i0, int j0, int lane) {
+    const int frow = lane & 31;
+    const int khalf = lane >> 5;
+    const int t = args.t_begin + plane;
+    const int p = args.moduli[t];
+    const int pinv = args.pinv32[t];
+    // value = k0*R0 + k1*R1 + k2*R2:  square moduli s*(R0+R1) + R2;  Karatsuba 256*R0 + 16*(R2-R0-R1) + R1
+    const int k0 = t < 6 ? args.sqrtp[t < 6 ? t : 0] : 240;
+    const int k1 = t < 6 ? k0 : -15;
+    const int k2 = t < 6 ? 1 : 16;
+    const float pf = (float)p, invp = 1.0f / pf;
+    auto red_acc = [&](float c) -> int {
+        if constexpr (ODD) {
+            float q = rintf(c * invp);
+            const float r = fmaf(-q, pf, c);
+            q = rintf(r * invp);
+            return (int)fmaf(-q, pf, r);
+        } else {
+            return mod_i32_sym(__float2int_rn(c), p, pinv);
+        }
+    };
+    auto red_small = [&](int v) -> int {
+        if constexpr (ODD) {
+            const float vf = (float)v;
+            return (int)fmaf(-rintf(vf * invp), pf, vf);
+        } else {
+            return mod_i32_sym(v, p, pinv);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = j0 + j * 32 + frow;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned d[4][2];  // quad q: rows 8q+4h..+3 as 4 x int16
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int r[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) r[b] = red_acc(acc[i][j][q * 4 + b]);
+                d[q][0] = pack16(r[0], r[1]);
+                d[q][1] = pack16(r[2], r[3]);
+            }
+            unsigned z[8];  // after the exchange: 16 consecutive rows (h=0: rows 0..15, h=1: rows 16..31)
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                auto s0 = __builtin_amdgcn_permlane32_swap(d[0][w], d[2][w], false, false);
+                auto s1 = __builtin_amdgcn_permlane32_swap(d[1][w], d[3][w], false, false);
+                z[0 + w] = s0[0];  // rows 0-3   (own quad 0 | quad 2 of the lower half)
+                z[2 + w] = s0[1];  // rows 4-7
+                z[4 + w] = s1[0];  // rows 8-11
+                z[6 + w] = s1[1];  // rows 12-15
+            }
+            if (col < args.n) {
+                const size_t e = (size_t)col * args.ldo + i0 + i * 32 + khalf * 16;
+                int16_t* dst = args.out + (size_t)plane * args.strideO + e;
+                if constexpr (EPI == EPI_FINAL) {
+                    const uint4* p0 = (const uint4*)(args.r0 + (size_t)plane * args.strideR + e);
+                    const uint4* p1 = (const uint4*)(args.r1 + (size_t)plane * args.strideR + e);
+                    const uint4 x0 = p0[0], x1 = p0[1], y0 = p1[0], y1 = p1[1];
+                    const unsigned xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    const unsigned ys[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) {
+                        int o[2];
+#pragma unroll
+                        for (int hlf = 0; hlf < 2; ++hlf) {
+                            const int R0 = (int)(int16_t)(xs[w] >> (16 * hlf)), R1 = (int)(int16_t)(ys[w] >> (16 * hlf)),
+                                      R2 = (int)(int16_t)(z[w] >> (16 * hlf));
+                            o[hlf] = red_small(k0 * R0 + k1 * R1 + k2 * R2);
+                        }
+                        z[w] = pack16(o[0], o[1]);
+                    }
+                }
+                ((uint4*)dst)[0] = make_uint4(z[0], z[1], z[2], z[3]);
+                ((uint4*)dst)[1] = make_uint4(z[4], z[5], z[6], z[7]);
+            }
+        }
+    }
+}
+
+// EPI_FMAX: row / column maxima of the inflated bound products
+__device__ __forceinline__ void f8_epilogue_max(const v16f (&acc)[4][2], const F8Args& args, int i0, int j0, int lane) {
+    const int frow = lane & 31;
+    const int khalf = lane >> 5;
+    const float ku = args.ku;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float cm = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const float c = acc[i][j][r];
+                const float v = (row < args.m) ? __fmaf_ru(ku, c, c) : 0.0f;
+                cm = fmaxf(cm, v);
+            }
+        cm = fmaxf(cm, __shfl_xor(cm, 32));
+        const int col = j0 + j * 32 + frow;
+        if (khalf == 0 && col < args.n && cm > 0.0f) atomicMax(args.colmax + col, __float_as_int(cm));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = j0 + j * 32 + frow;
+                const float c = acc[i][j][r];
+                const float a = (col < args.n) ? __fmaf_ru(ku, c, c) : 0.0f;
+                v = fmaxf(v, a);
+            }
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+            const int row = i0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (frow == 0 && row < args.m && v > 0.0f) atomicMax(args.rowmax + row, __float_as_int(v));
+        }
+}
+
+// Persistent: one workgroup per CU loops over tiles vb = blockIdx.x, blockIdx.x + gridDim.x, ...; the two-stage K pipeline
+// runs straight through tile boundaries (the first K-tile of the next tile is fetched during the last K-step of the current
+// one, the epilogue's stores drain behind the next tile's MFMAs, no workgroup launch between tiles).
 template <int EPI>
 __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    const TileMap tmap = map_tile(blockIdx.x, gridDim.x, args.tiles_m, args.tiles_n);
-    const int plane = tmap.plane, tm = tmap.tm, tn = tmap.tn;
-    const size_t offA = (size_t)args.planeA[plane] * args.strideA + (size_t)tm * BM * args.kp;
-    const size_t offB = (size_t)args.planeB[plane] * args.strideB + (size_t)tn * BN * args.kp;
-    const int nB_valid = (args.n - tn * BN) < BN ? (args.n - tn * BN) : BN;
     const int KT = args.kp / BK;
+    const int total = args.total_tiles;
+    const int G = gridDim.x;
 
-    const int8_t* const gA = args.A + offA;
-    const int8_t* const gB = args.B + offB;
-    auto dma_tile = [&](int kt, int q0, int q1) {  // this wave's DMA instructions q0..q1-1 of K-tile kt
-        char* stage = smem + (kt & 1) * STAGE_BYTES;
-#pragma unroll
-        for (int q = q0; q < q1; ++q) dma_issue(gA + (size_t)kt * BK, gB + (size_t)kt * BK, wave * 8 + q, stage, args.kp, nB_valid, lane);
+    // LDS-DMA: wave w issues instructions Q = 8w .. 8w+7 of every K-tile (1 KiB = 8 rows x 128 B each; waves 0-3 fetch A,
+    // waves 4-7 fetch B; slot layout as in oz2_gemm_i8.hip).  Per tile: a wave-uniform base pointer and 8 per-lane byte
+    // offsets (B rows clamped to the rows that exist), so the K loop issues global_load_lds with SGPR base + VGPR offset.
+    const bool isB = wave >= 4;
+    unsigned doff[8];
+    const int8_t* gsrc;
+    auto uniform = [](const int8_t* ptr) {
+        const unsigned long long v = (unsigned long long)ptr;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (const int8_t*)(((unsigned long long)hi << 32) | lo);
     };
+#define F8_SET_TILE(vb_)                                                                                                     \
+    do {                                                                                                                     \
+        const TileMap tmap_ = map_tile((vb_), total, args.tiles_m, args.tiles_n);                                            \
+        gsrc = uniform(isB ? args.B + (size_t)args.planeB[tmap_.plane] * args.strideB + (size_t)tmap_.tn * BN * args.kp      \
+                           : args.A + (size_t)args.planeA[tmap_.plane] * args.strideA + (size_t)tmap_.tm * BM * args.kp);    \
+        const int nvalid_ = isB ? ((args.n - tmap_.tn * BN) < BN ? (args.n - tmap_.tn * BN) : BN) : BM;                       \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                                      \
+            const int pp_ = (((wave & 3) * 8 + q) * 64 + lane);                                                              \
+            int row_ = pp_ >> 3;                                                                                             \
+            const int c_ = (pp_ & 7) ^ ((row_ >> 1) & 7);                                                                    \
+            row_ = row_ < nvalid_ ? row_ : nvalid_ - 1;                                                                      \
+            doff[q] = (unsigned)row_ * (unsigned)args.kp + c_ * 16;                                                          \
+        }                                                                                                                    \
+    } while (0)
+#define F8_DMA(src_, q_, stage_)                                                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((src_) + doff[q_]),                     \
+                                     (__attribute__((address_space(3))) void*)((stage_) + (wave * 8 + (q_)) * 1024), 16, 0, 0)
 
     const int wm = wave >> 2, wn = wave & 3;
     const int frow = lane & 31;
@@ -87,14 +234,6 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
     const int a_base = (wm * 128 + frow) * BK;
     const int b_base = TILE_BYTES + (wn * 64 + frow) * BK;
 
-    v16f acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
     auto frag = [&](const char* base, int c0) {  // 32 bytes = logical chunks c0, c0+1 of this lane's row
         const v4i lo = *(const v4i*)(base + ((c0 ^ sw) << 4));
         const v4i hi = *(const v4i*)(base + (((c0 + 1) ^ sw) << 4));
@@ -102,170 +241,85 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
     };
     constexpr int UNIT = 0x7F7F7F7F;  // E8M0 scale 2^0 for every 32-element block
 
-    dma_tile(0, 0, 8);
+    int vb_next = blockIdx.x, kt_next = 0;  // K-tile to fetch next
+    F8_SET_TILE(vb_next);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) F8_DMA(gsrc, q, smem);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();
-    // Hazards: the stage written during K-step kt was last read in K-step kt-1, whose LOAD segments every wave has
-    // finished (lgkmcnt(0) + barrier) before the leading half enters slot 0 of K-step kt; each wave drains its own
-    // DMA (vmcnt(0)) in its last LOAD segment, one barrier before anyone reads the new stage.
-    for (int kt = 0; kt < KT; ++kt) {
-        char* cur = smem + (kt & 1) * STAGE_BYTES;
-        const bool more = kt + 1 < KT;
-#pragma unroll
-        for (int ks2 = 0; ks2 < 2; ++ks2) {
-            const int c0 = ks2 * 4 + khalf * 2;
-            v8i bf[2];
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                v8i af[2];
-                if (ks2 == 0 && more) dma_tile(kt + 1, half * 4, half * 4 + 4);
-                if (half == 0) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) bf[j] = frag(cur + b_base + j * 32 * BK, c0);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) af[i] = frag(cur + a_base + (half * 2 + i) * 32 * BK, c0);
-                if (ks2 == 1 && half == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[half * 2 + i][j] =
-                            __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[i], bf[j], acc[half * 2 + i][j], 0, 0, 0, UNIT, 0, UNIT);
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-    if (wm == 0) __builtin_amdgcn_s_barrier();
-
-    const int i0 = tm * BM + wm * 128;
-    const int j0 = tn * BN + wn * 64;
-
-    if constexpr (EPI == EPI_PART || EPI == EPI_FINAL) {
-        const int t = args.t_begin + plane;
-        const int p = args.moduli[t];
-        const int pinv = args.pinv32[t];
-        // value = k0*R0 + k1*R1 + k2*R2:  square moduli s*(R0+R1) + R2;  Karatsuba 256*R0 + 16*(R2-R0-R1) + R1
-        const int k0 = t < 6 ? args.sqrtp[t < 6 ? t : 0] : 240;
-        const int k1 = t < 6 ? k0 : -15;
-        const int k2 = t < 6 ? 1 : 16;
-        // Odd p: residues in fp32 (accumulators are exact integers, |c| <= 2^24): q = rint(c/p) may be off by one near a
-        // rounding tie (error 2^-23 * 2^24/p vs tie distance 1/2p), a second step on |r| <= 1.5 p is exact; the combined
-        // value (|v| < 2^18) needs one step.  p = 1024 (even: the tie +-512 must keep the reference's representative)
-        // takes the integer path.
-        const bool odd = p & 1;
-        const float pf = (float)p, invp = 1.0f / pf;
-        auto red_acc = [&](float c) -> int {
-            if (odd) {
-                float q = rintf(c * invp);
-                float r = fmaf(-q, pf, c);
-                q = rintf(r * invp);
-                return (int)fmaf(-q, pf, r);
-            }
-            return mod_i32_sym(__float2int_rn(c), p, pinv);
-        };
-        auto red_small = [&](int v) -> int {
-            if (odd) {
-                const float vf = (float)v;
-                return (int)fmaf(-rintf(vf * invp), pf, vf);
-            }
-            return mod_i32_sym(v, p, pinv);
-        };
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = j0 + j * 32 + frow;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                unsigned d[4][2];  // quad q: rows 8q+4h..+3 as 4 x int16
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int r[4];
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) r[b] = red_acc(acc[i][j][q * 4 + b]);
-                    d[q][0] = pack16(r[0], r[1]);
-                    d[q][1] = pack16(r[2], r[3]);
-                }
-                unsigned z[8];  // after the exchange: 16 consecutive rows (h=0: rows 0..15, h=1: rows 16..31)
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    auto s0 = __builtin_amdgcn_permlane32_swap(d[0][w], d[2][w], false, false);
-                    auto s1 = __builtin_amdgcn_permlane32_swap(d[1][w], d[3][w], false, false);
-                    z[0 + w] = s0[0];  // rows 0-3   (own quad 0 | quad 2 of the lower half)
-                    z[2 + w] = s0[1];  // rows 4-7
-                    z[4 + w] = s1[0];  // rows 8-11
-                    z[6 + w] = s1[1];  // rows 12-15
-                }
-                if (col < args.n) {
-                    const size_t e = (size_t)col * args.ldo + i0 + i * 32 + khalf * 16;
-                    int16_t* dst = args.out + (size_t)plane * args.strideO + e;
-                    if constexpr (EPI == EPI_FINAL) {
-                        const uint4* p0 = (const uint4*)(args.r0 + (size_t)plane * args.strideR + e);
-                        const uint4* p1 = (const uint4*)(args.r1 + (size_t)plane * args.strideR + e);
-                        const uint4 x0 = p0[0], x1 = p0[1], y0 = p1[0], y1 = p1[1];
-                        const unsigned xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                        const unsigned ys[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
-#pragma unroll
-                        for (int w = 0; w < 8; ++w) {
-                            int o[2];
-#pragma unroll
-                            for (int hlf = 0; hlf < 2; ++hlf) {
-                                const int R0 = (int)(int16_t)(xs[w] >> (16 * hlf)), R1 = (int)(int16_t)(ys[w] >> (16 * hlf)),
-                                          R2 = (int)(int16_t)(z[w] >> (16 * hlf));
-                                o[hlf] = red_small(k0 * R0 + k1 * R1 + k2 * R2);
-                            }
-                            z[w] = pack16(o[0], o[1]);
-                        }
-                    }
-                    ((uint4*)dst)[0] = make_uint4(z[0], z[1], z[2], z[3]);
-                    ((uint4*)dst)[1] = make_uint4(z[4], z[5], z[6], z[7]);
-                }
-            }
-        }
-    } else {
-        const float ku = args.ku;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float cm = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = i0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    const float c = acc[i][j][r];
-                    const float v = (row < args.m) ? __fmaf_ru(ku, c, c) : 0.0f;
-                    cm = fmaxf(cm, v);
-                }
-            cm = fmaxf(cm, __shfl_xor(cm, 32));
-            const int col = j0 + j * 32 + frow;
-            if (khalf == 0 && col < args.n && cm > 0.0f) atomicMax(args.colmax + col, __float_as_int(cm));
-        }
+    // Hazards: the stage written during K-step g was last read in K-step g-1, whose LOAD segments every wave has finished
+    // (lgkmcnt(0) + barrier) before the leading half enters slot 0 of K-step g; each wave drains its own DMA (vmcnt(0)) in
+    // its last LOAD segment, one barrier before anyone reads the new stage.
+    int g = 0;
+    for (int vb = blockIdx.x; vb < total; vb += G) {
+        v16f acc[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = 0.0f;
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = j0 + j * 32 + frow;
-                    const float c = acc[i][j][r];
-                    const float a = (col < args.n) ? __fmaf_ru(ku, c, c) : 0.0f;
-                    v = fmaxf(v, a);
-                }
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-                const int row = i0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                if (frow == 0 && row < args.m && v > 0.0f) atomicMax(args.rowmax + row, __float_as_int(v));
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+        for (int kt = 0; kt < KT; ++kt, ++g) {
+            char* cur = smem + (g & 1) * STAGE_BYTES;
+            char* nxt = smem + ((g + 1) & 1) * STAGE_BYTES;
+            bool more = true;
+            if (++kt_next == KT) {
+                kt_next = 0;
+                vb_next += G;
+                more = vb_next < total;
+                if (more) F8_SET_TILE(vb_next);
             }
+            const int8_t* src = gsrc + (size_t)kt_next * BK;
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                const int c0 = ks2 * 4 + khalf * 2;
+                v8i bf[2];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    v8i af[2];
+                    if (ks2 == 0 && more) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) F8_DMA(src, half * 4 + q, nxt);
+                    }
+                    if (half == 0) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) bf[j] = frag(cur + b_base + j * 32 * BK, c0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) af[i] = frag(cur + a_base + (half * 2 + i) * 32 * BK, c0);
+                    if (ks2 == 1 && half == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[half * 2 + i][j] =
+                                __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[i], bf[j], acc[half * 2 + i][j], 0, 0, 0, UNIT, 0, UNIT);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n);
+        const int i0 = tmap.tm * BM + wm * 128, j0 = tmap.tn * BN + wn * 64;
+        if constexpr (EPI == EPI_PART || EPI == EPI_FINAL) {
+            if (args.moduli[args.t_begin + tmap.plane] & 1) f8_epilogue_mod<EPI, true>(acc, args, tmap.plane, i0, j0, lane);
+            else f8_epilogue_mod<EPI, false>(acc, args, tmap.plane, i0, j0, lane);
+        } else {
+            f8_epilogue_max(acc, args, i0, j0, lane);
+        }
     }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+#undef F8_SET_TILE
+#undef F8_DMA
 }
 
 static void fill_common(F8Args& a, size_t kp, size_t m, size_t n) {
@@ -282,15 +336,29 @@ static void fill_common(F8Args& a, size_t kp, size_t m, size_t n) {
     for (int t = 0; t < 6; ++t) a.sqrtp[t] = GEMMUL8_SQRT_MODULI_FP8[t];
 }
 
-template <int EPI> static hipError_t launch(hipStream_t stream, const F8Args& a, int planes) {
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) return 256;
+        n = prop.multiProcessorCount;
+    }
+    return n;
+}
+
+template <int EPI> static hipError_t launch(hipStream_t stream, F8Args& a, int planes) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_f8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int grid = planes * a.tiles_m * a.tiles_n;
-    if (grid <= 0) return hipSuccess;
+    a.total_tiles = planes * a.tiles_m * a.tiles_n;
+    if (a.total_tiles <= 0) return hipSuccess;
+    int grid = num_cus() & ~7;  // persistent: one workgroup per CU (see oz2_gemm_i8.hip)
+    if (grid <= 0) grid = 8;
+    if (a.total_tiles < grid) grid = a.total_tiles;
     hipLaunchKernelGGL(gemm_f8_kernel<EPI>, dim3(grid), dim3(F8_THREADS), LDS_BYTES, stream, a);
     return hipGetLastError();
 }
