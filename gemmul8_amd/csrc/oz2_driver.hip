@@ -144,8 +144,7 @@ int gemmul8_scale_bounds(void* stream_, int dtype, int backend, int op_A, int op
     hipStream_t stream = (hipStream_t)stream_;
     if (!L || !A || !B) return GEMMUL8_E_ARG;
     if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
-    if (backend == kFP8 && is_complex(dtype)) return GEMMUL8_E_UNSUPPORTED;  // FP8 complex (9 GEMMs / modulus): not built yet
-    if (backend == kFP8 && k > 65536) return GEMMUL8_E_ARG;                  // exact FP32 accumulation needs k*16*16 <= 2^24
+    if (backend == kFP8 && k > 65536) return GEMMUL8_E_ARG;  // exact FP32 accumulation needs k*16*16 <= 2^24
     op_A = norm_op(op_A);
     op_B = norm_op(op_B);
     if (op_A < 0 || op_A > 2 || op_B < 0 || op_B > 2 || col_begin > col_end || col_end > n) return GEMMUL8_E_ARG;
@@ -165,8 +164,21 @@ int gemmul8_scale_bounds(void* stream_, int dtype, int backend, int op_A, int op
     if (col_end > col_begin) {
         const int8_t* Ab = (const int8_t*)L->A_bound;
         const int8_t* Bb = (const int8_t*)L->B_bound + col_begin * L->kp;
-        if (backend == kFP8) {
+        if (backend == kFP8 && !cplx) {
             OZ2_HIP(launch_gemm_f8_max(stream, Ab, Bb, L->kp, k, m, col_end - col_begin, rowmax, colmax + col_begin));
+        } else if (backend == kFP8) {
+            // complex FP8 (find_max.hpp, complex FP8 overloads; scaling_accu_complex.hpp:150-175): three separately inflated
+            // products ArBi, AiBr and (Ar-Ai)(Br-Bi) combined with round-up additions; the first two pass through a float
+            // scratch plane [ncols][mp] behind the maxima arrays.
+            const size_t ncols = col_end - col_begin;
+            const size_t used = 4 * L->mp + 4 * np + 8 * std::max(L->mp, np);
+            const size_t foff = (used + 255) / 256 * 256;
+            if (L->scratch_bytes < foff + 4 * L->mp * ncols) return GEMMUL8_E_ARG;
+            float* fbuf = (float*)((char*)L->scratch + foff);
+            OZ2_HIP(launch_gemm_f8_bound_cplx(stream, 1, Ab, Bb + L->sizeB, L->kp, k, m, ncols, fbuf, L->mp, rowmax, colmax + col_begin));
+            OZ2_HIP(launch_gemm_f8_bound_cplx(stream, 2, Ab + L->sizeA, Bb, L->kp, k, m, ncols, fbuf, L->mp, rowmax, colmax + col_begin));
+            OZ2_HIP(launch_gemm_f8_bound_cplx(stream, 3, Ab + 2 * L->sizeA, Bb + 2 * L->sizeB, L->kp, k, m, ncols, fbuf, L->mp, rowmax,
+                                              colmax + col_begin));
         } else if (!cplx) {
             const int8_t* As[1] = {Ab};
             const int8_t* Bs[1] = {Bb};
@@ -190,7 +202,6 @@ int gemmul8_scale_finish(void* stream_, int dtype, int backend, int op_A, int op
     hipStream_t stream = (hipStream_t)stream_;
     if (!L || !A || !B) return GEMMUL8_E_ARG;
     if (N < 2 || N > 20 || t_end > N || t_begin > t_end) return GEMMUL8_E_NUM_MODULI;
-    if (backend == kFP8 && is_complex(dtype)) return GEMMUL8_E_UNSUPPORTED;
     if (backend == kFP8 && k > 65536) return GEMMUL8_E_ARG;
     op_A = norm_op(op_A);
     op_B = norm_op(op_B);
@@ -237,8 +248,7 @@ int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t
     if (N < 2 || N > 20 || t_end > N || t_begin > t_end) return GEMMUL8_E_NUM_MODULI;
     const int8_t* A_lo = (const int8_t*)L->A_lo;
     const int8_t* B_lo = (const int8_t*)L->B_lo;
-    if (backend == kFP8) {
-        if (is_complex(dtype)) return GEMMUL8_E_UNSUPPORTED;
+    if (backend == kFP8 && !is_complex(dtype)) {
         // three e4m3 GEMMs per modulus (gemmul8_real.hpp:159-181); the residues of the first two wait in int16 scratch planes
         // (the reference's C_hi region) for the third one's epilogue.  Moduli are chunked to the scratch size.
         const size_t per_mod = 2 * 2 * L->sizeC;
@@ -252,6 +262,35 @@ int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t
             OZ2_HIP(launch_gemm_f8(stream, 1, A_lo, B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1, r1, L->mp, L->sizeC, nullptr, nullptr, 0));
             OZ2_HIP(launch_gemm_f8(stream, 2, A_lo, B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1,
                                    (int16_t*)L->C_mid + (size_t)t0 * L->sizeC, L->mp, L->sizeC, r0, r1, L->sizeC));
+        }
+        return GEMMUL8_OK;
+    }
+    if (backend == kFP8) {
+        // complex FP8: nine e4m3 GEMMs per modulus (gemmul8_complex.hpp:170-195, matmult.hpp:355-404): each of the three complex
+        // parts X = ArBr, Y = AiBi, Z = (Ar+Ai)(Br+Bi) is a 3-GEMM modular product as in the real case; the residues of X and Y
+        // wait in int16 scratch planes for the epilogue of Z's last GEMM, which writes the interleaved (Cr, Ci) plane
+        // (conv_hi2mid_complex.hpp:28-41).  Scratch per modulus: r0, r1, X, Y.
+        const size_t per_mod = 4 * 2 * L->sizeC;
+        const size_t chunk = L->scratch_bytes / per_mod;
+        if (chunk == 0) return GEMMUL8_E_ARG;
+        int16_t* r0 = (int16_t*)L->scratch;
+        for (unsigned t0 = t_begin; t0 < t_end; t0 += (unsigned)chunk) {
+            const unsigned t1 = std::min<unsigned>(t_end, t0 + (unsigned)chunk);
+            const size_t nt = t1 - t0;
+            int16_t *r1 = r0 + nt * L->sizeC, *rx = r1 + nt * L->sizeC, *ry = rx + nt * L->sizeC;
+            for (int part = 0; part < 3; ++part) {
+                const int8_t* Ap = A_lo + part * L->part_strideA;
+                const int8_t* Bp = B_lo + part * L->part_strideB;
+                OZ2_HIP(launch_gemm_f8(stream, 0, Ap, Bp, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1, r0, L->mp, L->sizeC, nullptr, nullptr, 0));
+                OZ2_HIP(launch_gemm_f8(stream, 1, Ap, Bp, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1, r1, L->mp, L->sizeC, nullptr, nullptr, 0));
+                if (part < 2) {
+                    OZ2_HIP(launch_gemm_f8(stream, 2, Ap, Bp, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1, part == 0 ? rx : ry, L->mp, L->sizeC,
+                                           r0, r1, L->sizeC));
+                } else {
+                    OZ2_HIP(launch_gemm_f8(stream, 3, Ap, Bp, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1,
+                                           (int16_t*)L->C_mid + (size_t)t0 * 2 * L->sizeC, L->mp, 2 * L->sizeC, r0, r1, L->sizeC, rx, ry));
+                }
+            }
         }
         return GEMMUL8_OK;
     }

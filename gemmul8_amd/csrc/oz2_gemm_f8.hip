@@ -32,7 +32,11 @@ namespace oz2 {
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-enum { EPI_PART = 0, EPI_FINAL = 1, EPI_FMAX = 2 };
+// EPI_FINAL_CPLX: like EPI_FINAL for the third complex part Z = (Ar+Ai)(Br+Bi), then (Cr, Ci) = (X - Y, Z - X - Y) mod p with
+// the residues X, Y of the first two parts -> interleaved int16 pairs (conv_hi2mid_complex.hpp:28-41).
+// EPI_FB1/2/3: the three bound GEMMs of the complex accurate mode (find_max.hpp, complex FP8): u = fma_ru(ku, c, c);
+//   1: store u (ArBi)   2: store add_ru(stored, u) (+ AiBr = s12)   3: s0 = add_ru(u, s12), maxima of max(s0, s12)
+enum { EPI_PART = 0, EPI_FINAL = 1, EPI_FMAX = 2, EPI_FINAL_CPLX = 3, EPI_FB1 = 4, EPI_FB2 = 5, EPI_FB3 = 6 };
 
 struct F8Args {
     const int8_t* A;      // base of the A planes; plane of block b at A + planeA[b]*strideA
@@ -46,6 +50,9 @@ struct F8Args {
     const int16_t* r0;    // EPI_FINAL: residues of C0, C1 (plane b at r0/r1 + b*strideR)
     const int16_t* r1;
     size_t strideR;
+    const int16_t* rx;    // EPI_FINAL_CPLX: residues of the complex parts X, Y (plane b at rx/ry + b*strideR)
+    const int16_t* ry;
+    float* fbuf;          // EPI_FB*: m x n float scratch, leading dimension ldo
     int* rowmax;          // EPI_FMAX (float bit patterns)
     int* colmax;
     float ku;             // (k+1) * 2^-24
@@ -120,7 +127,7 @@ __device__ __forceinline__ void f8_epilogue_mod(const v16f (&acc)[4][2], const F
             if (col < args.n) {
                 const size_t e = (size_t)col * args.ldo + i0 + i * 32 + khalf * 16;
                 int16_t* dst = args.out + (size_t)plane * args.strideO + e;
-                if constexpr (EPI == EPI_FINAL) {
+                if constexpr (EPI == EPI_FINAL || EPI == EPI_FINAL_CPLX) {
                     const uint4* p0 = (const uint4*)(args.r0 + (size_t)plane * args.strideR + e);
                     const uint4* p1 = (const uint4*)(args.r1 + (size_t)plane * args.strideR + e);
                     const uint4 x0 = p0[0], x1 = p0[1], y0 = p1[0], y1 = p1[1];
@@ -138,51 +145,106 @@ __device__ __forceinline__ void f8_epilogue_mod(const v16f (&acc)[4][2], const F
                         z[w] = pack16(o[0], o[1]);
                     }
                 }
-                ((uint4*)dst)[0] = make_uint4(z[0], z[1], z[2], z[3]);
-                ((uint4*)dst)[1] = make_uint4(z[4], z[5], z[6], z[7]);
+                if constexpr (EPI == EPI_FINAL_CPLX) {
+                    const uint4* px = (const uint4*)(args.rx + (size_t)plane * args.strideR + e);
+                    const uint4* py = (const uint4*)(args.ry + (size_t)plane * args.strideR + e);
+                    const uint4 x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1];
+                    const unsigned xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    const unsigned ys[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+                    unsigned o[16];  // 16 rows x (Cr, Ci) int16 pairs
+#pragma unroll
+                    for (int w = 0; w < 8; ++w)
+#pragma unroll
+                        for (int hlf = 0; hlf < 2; ++hlf) {
+                            const int X = (int)(int16_t)(xs[w] >> (16 * hlf)), Y = (int)(int16_t)(ys[w] >> (16 * hlf)),
+                                      Z = (int)(int16_t)(z[w] >> (16 * hlf));
+                            o[2 * w + hlf] = pack16(red_small(X - Y), red_small(Z - X - Y));
+                        }
+                    uint4* dc = (uint4*)(args.out + (size_t)plane * args.strideO + 2 * e);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) dc[w] = make_uint4(o[4 * w], o[4 * w + 1], o[4 * w + 2], o[4 * w + 3]);
+                } else {
+                    ((uint4*)dst)[0] = make_uint4(z[0], z[1], z[2], z[3]);
+                    ((uint4*)dst)[1] = make_uint4(z[4], z[5], z[6], z[7]);
+                }
             }
         }
     }
 }
 
-// EPI_FMAX: row / column maxima of the inflated bound products
-__device__ __forceinline__ void f8_epilogue_max(const v16f (&acc)[4][2], const F8Args& args, int i0, int j0, int lane) {
+// EPI_FMAX / EPI_FB*: u = fma_ru(ku, c, c) (find_max.hpp:82-96: the (k+1)*2^-24 inflation covers the FP32 accumulation
+// error of the inexact bound products); FMAX and FB3 then reduce row / column maxima (atomicMax on the bit patterns of
+// non-negative floats).
+template <int EPI>
+__device__ __forceinline__ void f8_epilogue_bound(v16f (&acc)[4][2], const F8Args& args, int i0, int j0, int lane) {
     const int frow = lane & 31;
     const int khalf = lane >> 5;
     const float ku = args.ku;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        float cm = 0.0f;
+        const int col = j0 + j * 32 + frow;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float u[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) u[b] = __fmaf_ru(ku, acc[i][j][q * 4 + b], acc[i][j][q * 4 + b]);
+                if constexpr (EPI != EPI_FMAX) {
+                    float4* fp = (float4*)(args.fbuf + (size_t)col * args.ldo + i0 + i * 32 + 8 * q + 4 * khalf);
+                    if (col < args.n) {
+                        if constexpr (EPI == EPI_FB1) {
+                            *fp = make_float4(u[0], u[1], u[2], u[3]);
+                        } else {
+                            const float4 w = *fp;
+                            const float ws[4] = {w.x, w.y, w.z, w.w};
+                            if constexpr (EPI == EPI_FB2) {
+                                *fp = make_float4(__fadd_ru(ws[0], u[0]), __fadd_ru(ws[1], u[1]), __fadd_ru(ws[2], u[2]), __fadd_ru(ws[3], u[3]));
+                            } else {
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) {
+                                    const float s0 = __fadd_ru(u[b], ws[b]);
+                                    u[b] = s0 > ws[b] ? s0 : ws[b];
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[i][j][q * 4 + b] = u[b];
+            }
+    }
+    if constexpr (EPI == EPI_FMAX || EPI == EPI_FB3) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float cm = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    cm = fmaxf(cm, (row < args.m) ? acc[i][j][r] : 0.0f);
+                }
+            cm = fmaxf(cm, __shfl_xor(cm, 32));
+            const int col = j0 + j * 32 + frow;
+            if (khalf == 0 && col < args.n && cm > 0.0f) atomicMax(args.colmax + col, __float_as_int(cm));
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                float v = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = j0 + j * 32 + frow;
+                    v = fmaxf(v, (col < args.n) ? acc[i][j][r] : 0.0f);
+                }
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
                 const int row = i0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                const float c = acc[i][j][r];
-                const float v = (row < args.m) ? __fmaf_ru(ku, c, c) : 0.0f;
-                cm = fmaxf(cm, v);
+                if (frow == 0 && row < args.m && v > 0.0f) atomicMax(args.rowmax + row, __float_as_int(v));
             }
-        cm = fmaxf(cm, __shfl_xor(cm, 32));
-        const int col = j0 + j * 32 + frow;
-        if (khalf == 0 && col < args.n && cm > 0.0f) atomicMax(args.colmax + col, __float_as_int(cm));
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = j0 + j * 32 + frow;
-                const float c = acc[i][j][r];
-                const float a = (col < args.n) ? __fmaf_ru(ku, c, c) : 0.0f;
-                v = fmaxf(v, a);
-            }
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-            const int row = i0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-            if (frow == 0 && row < args.m && v > 0.0f) atomicMax(args.rowmax + row, __float_as_int(v));
-        }
 }
 
 // Persistent: one workgroup per CU loops over tiles vb = blockIdx.x, blockIdx.x + gridDim.x, ...; the two-stage K pipeline
@@ -310,11 +372,11 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
         }
         const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n);
         const int i0 = tmap.tm * BM + wm * 128, j0 = tmap.tn * BN + wn * 64;
-        if constexpr (EPI == EPI_PART || EPI == EPI_FINAL) {
+        if constexpr (EPI == EPI_PART || EPI == EPI_FINAL || EPI == EPI_FINAL_CPLX) {
             if (args.moduli[args.t_begin + tmap.plane] & 1) f8_epilogue_mod<EPI, true>(acc, args, tmap.plane, i0, j0, lane);
             else f8_epilogue_mod<EPI, false>(acc, args, tmap.plane, i0, j0, lane);
         } else {
-            f8_epilogue_max(acc, args, i0, j0, lane);
+            f8_epilogue_bound<EPI>(acc, args, i0, j0, lane);
         }
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();
@@ -366,10 +428,12 @@ template <int EPI> static hipError_t launch(hipStream_t stream, F8Args& a, int p
 // first low-precision plane of modulus t: 2 planes for t < 6 (hi, lo), 3 afterwards (hi, lo, hi+lo)  (table.hpp:69-75)
 static int first_plane(int t) { return t < 6 ? 2 * t : 12 + 3 * (t - 6); }
 
-// which = 0,1: partial products C0 / C1 -> int16 residue scratch; which = 2: C2 with the final combine -> C_mid
+// which = 0,1: partial products C0 / C1 -> int16 residue scratch; which = 2: C2 with the final combine -> out (C_mid plane, or
+// a scratch plane holding the residue of a complex part); which = 3: C2 of the third complex part with the complex combine
+// (rx, ry = residues of X and Y, same stride as r0/r1) -> interleaved (Cr, Ci) int16 pairs in out.
 hipError_t launch_gemm_f8(hipStream_t stream, int which, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp, size_t m,
                           size_t n, int t_begin, int t_end, int16_t* out, size_t ldo, size_t strideO, const int16_t* r0, const int16_t* r1,
-                          size_t strideR) {
+                          size_t strideR, const int16_t* rx, const int16_t* ry) {
     F8Args a{};
     a.A = A;
     a.B = B;
@@ -382,18 +446,23 @@ hipError_t launch_gemm_f8(hipStream_t stream, int which, const int8_t* A, const 
     a.r0 = r0;
     a.r1 = r1;
     a.strideR = strideR;
+    a.rx = rx;
+    a.ry = ry;
+    const int wh = which == 3 ? 2 : which;
     for (int t = t_begin; t < t_end; ++t) {
         const int q = first_plane(t), b = t - t_begin;
         if (t < 6) {  // hi = q, lo = q+1 :  C0 = Ahi*Blo, C1 = Alo*Bhi, C2 = Alo*Blo
-            a.planeA[b] = which == 0 ? q : q + 1;
-            a.planeB[b] = which == 1 ? q : q + 1;
+            a.planeA[b] = wh == 0 ? q : q + 1;
+            a.planeB[b] = wh == 1 ? q : q + 1;
         } else {      // C0 = hi*hi, C1 = lo*lo, C2 = (hi+lo)*(hi+lo)
-            a.planeA[b] = q + which;
-            a.planeB[b] = q + which;
+            a.planeA[b] = q + wh;
+            a.planeB[b] = q + wh;
         }
     }
     fill_common(a, kp, m, n);
-    return which == 2 ? launch<EPI_FINAL>(stream, a, t_end - t_begin) : launch<EPI_PART>(stream, a, t_end - t_begin);
+    const int planes = t_end - t_begin;
+    if (which == 3) return launch<EPI_FINAL_CPLX>(stream, a, planes);
+    return which == 2 ? launch<EPI_FINAL>(stream, a, planes) : launch<EPI_PART>(stream, a, planes);
 }
 
 hipError_t launch_gemm_f8_max(hipStream_t stream, const int8_t* A, const int8_t* B, size_t kp, size_t k, size_t m, size_t n, int* rowmax,
@@ -406,6 +475,23 @@ hipError_t launch_gemm_f8_max(hipStream_t stream, const int8_t* A, const int8_t*
     a.ku = (float)(k + 1) * 0x1.0p-24f;
     fill_common(a, kp, m, n);
     return launch<EPI_FMAX>(stream, a, 1);
+}
+
+// complex accurate-mode bound, stage 1..3 (see EPI_FB*): fbuf = float scratch [n][ldf]
+hipError_t launch_gemm_f8_bound_cplx(hipStream_t stream, int stage, const int8_t* A, const int8_t* B, size_t kp, size_t k, size_t m, size_t n,
+                                     float* fbuf, size_t ldf, int* rowmax, int* colmax) {
+    F8Args a{};
+    a.A = A;
+    a.B = B;
+    a.rowmax = rowmax;
+    a.colmax = colmax;
+    a.fbuf = fbuf;
+    a.ldo = ldf;
+    a.ku = (float)(k + 1) * 0x1.0p-24f;
+    fill_common(a, kp, m, n);
+    if (stage == 1) return launch<EPI_FB1>(stream, a, 1);
+    if (stage == 2) return launch<EPI_FB2>(stream, a, 1);
+    return launch<EPI_FB3>(stream, a, 1);
 }
 
 }  // namespace oz2

@@ -33,9 +33,11 @@ hipError_t launch_gemm_i8_max(hipStream_t stream, int nseg, const int8_t* const*
 // ---- FP8 MFMA GEMM (oz2_gemm_f8.hip)
 hipError_t launch_gemm_f8(hipStream_t stream, int which, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp, size_t m,
                           size_t n, int t_begin, int t_end, int16_t* out, size_t ldo, size_t strideO, const int16_t* r0, const int16_t* r1,
-                          size_t strideR);
+                          size_t strideR, const int16_t* rx = nullptr, const int16_t* ry = nullptr);
 hipError_t launch_gemm_f8_max(hipStream_t stream, const int8_t* A, const int8_t* B, size_t kp, size_t k, size_t m, size_t n, int* rowmax,
                               int* colmax);
+hipError_t launch_gemm_f8_bound_cplx(hipStream_t stream, int stage, const int8_t* A, const int8_t* B, size_t kp, size_t k, size_t m, size_t n,
+                                     float* fbuf, size_t ldf, int* rowmax, int* colmax);
 
 // ---- scale / quantise (oz2_scale.hip).  An operand has `rows` logical rows (m for A, n for B) of
 // length k; K-major: element (r,kk) at X[r*ld+kk]; row-strided: X[kk*ld+r].  lo planes are

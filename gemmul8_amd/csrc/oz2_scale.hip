@@ -118,16 +118,31 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
     int8_t* out = a.lo + row * a.kp + k0;
     if constexpr (MODE == MODE_BOUND) {
         if (a.backend == kFP8) {
-            // e4m3 round-up of |x|*2^s (< 2^8), computed in the input precision (scaling.hpp:77-82); real types only
+            // e4m3 round-up of |x|*2^s (< 2^8), computed in the input precision (scaling.hpp:77-82); complex: planes
+            // |Re|, |Im| and fp8_e4m3_ru(|Re| - |Im|) of the two rounded values (sub_ru_8bit, scaling_accu_complex.hpp:7-10:
+            // the difference of two e4m3 numbers is exact in fp16/fp32; the helper's "+1 encoding step" is applied
+            // literally, also for negative differences)
             using U = typename E::U;
-            unsigned w = 0;
+            unsigned wr = 0, wi = 0, wd = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const U x = (U)E::re(v[e]);
                 const U sc = sizeof(U) == 8 ? (U)scalbn(fabs((double)x), s) : (U)scalbnf(fabsf((float)x), s);
-                w |= fp8_round_up<U>(sc) << (8 * e);
+                const unsigned br = fp8_round_up<U>(sc);
+                wr |= br << (8 * e);
+                if constexpr (E::cplx) {
+                    const U y = (U)E::im(v[e]);
+                    const U sd = sizeof(U) == 8 ? (U)scalbn(fabs((double)y), s) : (U)scalbnf(fabsf((float)y), s);
+                    const unsigned bi = fp8_round_up<U>(sd);
+                    wi |= bi << (8 * e);
+                    wd |= (fp8_round_up<float>(fp8_to_float(br) - fp8_to_float(bi)) & 0xFFu) << (8 * e);
+                }
             }
-            *(unsigned*)out = w;
+            *(unsigned*)out = wr;
+            if constexpr (E::cplx) {
+                *(unsigned*)(out + a.part_stride) = wi;
+                *(unsigned*)(out + 2 * a.part_stride) = wd;
+            }
             return;
         }
         unsigned wr = 0, wi = 0, wd = 0;
@@ -165,13 +180,9 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
         }
         const short(*pow2)[64] = a.backend == kINT8 ? c_pow2mod_int8 : c_pow2mod_fp8;
         if (a.backend == kFP8) {
-            // residues up to +-544 are split into 2-3 e4m3 planes of integers <= 16 (mod.hpp:159-189, 361-410); real types only
-            for (int t = a.t_begin; t < a.t_end; ++t) {
-                const ModConst mc = a.mt.mc[t];
-                int rr[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rr[e] = residue_sym(Lr[e], Er[e], nr[e], mc, pow2[t]);
-                int8_t* o = out + (size_t)(t < 6 ? 2 * t : 12 + 3 * (t - 6)) * a.plane_stride;
+            // residues up to +-544 are split into 2-3 e4m3 planes of integers <= 16 (mod.hpp:159-189, 361-410); complex:
+            // the residues of Re, Im and wrapping(Re + Im) go to the three parts
+            auto put = [&](int8_t* o, int t, const int (&rr)[4]) {
                 if (t < 6) {
                     const int sq = a.sqrtp[t];
                     const float inv = 1.0f / (float)sq;
@@ -188,6 +199,24 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
                     *(unsigned*)(o + a.plane_stride) = fp8x2_from_ints(lo[0], lo[1]) | (fp8x2_from_ints(lo[2], lo[3]) << 16);
                     *(unsigned*)(o + 2 * a.plane_stride) =
                         fp8x2_from_ints(hi[0] + lo[0], hi[1] + lo[1]) | (fp8x2_from_ints(hi[2] + lo[2], hi[3] + lo[3]) << 16);
+                }
+            };
+            for (int t = a.t_begin; t < a.t_end; ++t) {
+                const ModConst mc = a.mt.mc[t];
+                int rr[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rr[e] = residue_sym(Lr[e], Er[e], nr[e], mc, pow2[t]);
+                int8_t* o = out + (size_t)(t < 6 ? 2 * t : 12 + 3 * (t - 6)) * a.plane_stride;
+                put(o, t, rr);
+                if constexpr (E::cplx) {
+                    int ri[4], rs[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ri[e] = residue_sym(Li[e], Ei[e], ni[e], mc, pow2[t]);
+                        rs[e] = wrapping(rr[e] + ri[e], mc.p);
+                    }
+                    put(o + a.part_stride, t, ri);
+                    put(o + 2 * a.part_stride, t, rs);
                 }
             }
             return;

@@ -154,6 +154,35 @@ def test_parity_shapes_fp8(m, n, k):
     gu.parity_case(Ad, Bd, 13, False, backend=g.FP8, alpha=-1.5, beta=1.5, C0=rand((m, n), np.float64, rng))
 
 
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+@pytest.mark.parametrize("fast", [False, True])
+@pytest.mark.parametrize("N", [2, 6, 7, 13, 20])
+def test_parity_small_complex_fp8(dtype, fast, N):
+    """FP8 backend, complex types: 9 e4m3 GEMMs per modulus (gemmul8_complex.hpp:170-195), three separately inflated bound
+    products in accurate mode, interleaved int16 (Cr, Ci) planes -- bit-exact against the oracle."""
+    import gemmul8_amd as g
+    import gpu_util as gu
+    if dtype == np.complex64 and N > 13:
+        pytest.skip("float documented for N<=13")
+    rng = np.random.default_rng(700 * N + fast)
+    m, n, k = 37, 41, 300
+    A, B = rand((m, k), dtype, rng), rand((k, n), dtype, rng)
+    A[5, :] = 0
+    B[:, 7] = 0
+    gu.parity_case(A, B, N, fast, backend=g.FP8)
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 256, 256), (260, 300, 520), (1, 1, 1)])
+def test_parity_shapes_complex_fp8(m, n, k):
+    import gemmul8_amd as g
+    import gpu_util as gu
+    rng = np.random.default_rng(m + n + k + 5)
+    A, B = rand((m, k), np.complex128, rng), rand((k, n), np.complex128, rng)
+    gu.parity_case(A, B, 12, False, backend=g.FP8)
+    gu.parity_case(A, B, 8, True, backend=g.FP8, opA="C" if m == k else "N", opB="T" if n == k else "N")
+    gu.parity_case(A, B, 13, False, backend=g.FP8, alpha=-1.5 + 0.5j, beta=0.25 - 2j, C0=rand((m, n), np.complex128, rng))
+
+
 def test_kat_sample_fp8_on_gpu():
     """sample/dgemm_cuBLASLt_fp8.cu: the 4x5x3 known-answer vectors with N=13 on the FP8 backend."""
     import gemmul8_amd as g
