@@ -74,4 +74,36 @@ __device__ __forceinline__ void dma_issue(const int8_t* tA, const int8_t* tB, in
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
 }
 
+// Row maxima of a wave's 128-row accumulator block for the bound GEMM epilogues.  w[idx], idx = 16 i + r, is this lane's
+// (column-masked, non-negative) value for MFMA tile row i, accumulator register r; lanes 0-31 / 32-63 hold the same 64 idx
+// for two interleaved row sets (row = i0 + 32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  A butterfly reduce-scatter over
+// the 32 lanes of each half (62 exchanges instead of 64 x 5 for a full butterfly per row) leaves lane l with the finished
+// maxima of idx = 2 (l & 31) and 2 (l & 31) + 1, so the wave needs two fully populated atomicMax instructions instead
+// of 64 with two active lanes each.
+__device__ __forceinline__ void wave_rowmax_atomic(int (&w)[64], int* rowmax, int i0, int m, int lane) {
+    int n = 64;
+#pragma unroll
+    for (int bit = 16; bit >= 1; bit >>= 1) {
+        const int half = n >> 1;
+        const bool up = (lane & bit) != 0;  // this lane keeps the upper half of the index range
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            if (j < half) {
+                const int send = up ? w[j] : w[j + half];
+                const int keep = up ? w[j + half] : w[j];
+                const int got = __shfl_xor(send, bit);
+                w[j] = got > keep ? got : keep;
+            }
+        }
+        n = half;
+    }
+    const int khalf = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int idx = 2 * (lane & 31) + j;
+        const int row = i0 + (idx >> 4) * 32 + (idx & 3) + 8 * ((idx & 15) >> 2) + 4 * khalf;
+        if (row < m && w[j] > 0) atomicMax(rowmax + row, w[j]);
+    }
+}
+
 }  // namespace oz2

@@ -229,6 +229,7 @@ __device__ __forceinline__ void f8_epilogue_bound(v16f (&acc)[4][2], const F8Arg
             const int col = j0 + j * 32 + frow;
             if (khalf == 0 && col < args.n && cm > 0.0f) atomicMax(args.colmax + col, __float_as_int(cm));
         }
+        int w[64];  // bit patterns of non-negative floats order like ints
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -239,11 +240,9 @@ __device__ __forceinline__ void f8_epilogue_bound(v16f (&acc)[4][2], const F8Arg
                     const int col = j0 + j * 32 + frow;
                     v = fmaxf(v, (col < args.n) ? acc[i][j][r] : 0.0f);
                 }
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-                const int row = i0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                if (frow == 0 && row < args.m && v > 0.0f) atomicMax(args.rowmax + row, __float_as_int(v));
+                w[i * 16 + r] = __float_as_int(v);
             }
+        wave_rowmax_atomic(w, args.rowmax, i0, args.m, lane);
     }
 }
 

@@ -174,6 +174,7 @@ __device__ __forceinline__ void i8_epilogue(const v16i (&acc)[4][NJ], const Gemm
             if (khalf == 0 && col < args.n && cm > 0) atomicMax(args.colmax + col, cm);
         }
         // row max across the 32 lanes (columns) of each half, for each of the 64 rows this lane touches
+        int w[64];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -185,14 +186,9 @@ __device__ __forceinline__ void i8_epilogue(const v16i (&acc)[4][NJ], const Gemm
                     const int a = (col < args.n) ? acc[i][j][r] : 0;
                     v = a > v ? a : v;
                 }
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) {
-                    const int o = __shfl_xor(v, off);
-                    v = o > v ? o : v;
-                }
-                const int row = i0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                if (frow == 0 && row < args.m && v > 0) atomicMax(args.rowmax + row, v);
+                w[i * 16 + r] = v;
             }
+        wave_rowmax_atomic(w, args.rowmax, i0, args.m, lane);
     }
 }
 

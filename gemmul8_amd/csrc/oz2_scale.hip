@@ -35,6 +35,14 @@ ModTable make_mod_table(int backend) {
         T.mc[t].c18 = sym(1ll << 18);
         T.mc[t].c36 = sym(1ll << 36);
         T.mc[t].invp = 1.0f / (float)p;
+        unsigned c[7];
+        long long pw = 1;
+        for (int i = 0; i < 7; ++i) {
+            c[i] = (unsigned)(pw % p);
+            pw = (pw % p) * 256;
+        }
+        T.mc[t].cb_lo = backend == kINT8 ? (c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24)) : 0u;
+        T.mc[t].cb_hi = backend == kINT8 ? (c[4] | (c[5] << 8) | (c[6] << 16)) : 0u;
     }
     return T;
 }
@@ -162,18 +170,18 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
             *(unsigned*)(out + 2 * a.part_stride) = wd;
         }
     } else {
-        Limbs Lr[4], Li[4];
+        uint64_t Mr[4], Mi[4];
         int Er[4], Ei[4];
         bool nr[4], ni[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const ScaledInt x = trunc_scale(E::re(v[e]), s);
-            Lr[e] = make_limbs(x.M);
+            Mr[e] = x.M;
             Er[e] = x.E;
             nr[e] = x.neg;
             if constexpr (E::cplx) {
                 const ScaledInt y = trunc_scale(E::im(v[e]), s);
-                Li[e] = make_limbs(y.M);
+                Mi[e] = y.M;
                 Ei[e] = y.E;
                 ni[e] = a.conj ? !y.neg : y.neg;
             }
@@ -201,6 +209,12 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
                         fp8x2_from_ints(hi[0] + lo[0], hi[1] + lo[1]) | (fp8x2_from_ints(hi[2] + lo[2], hi[3] + lo[3]) << 16);
                 }
             };
+            Limbs Lr[4], Li[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Lr[e] = make_limbs(Mr[e]);
+                if constexpr (E::cplx) Li[e] = make_limbs(Mi[e]);
+            }
             for (int t = a.t_begin; t < a.t_end; ++t) {
                 const ModConst mc = a.mt.mc[t];
                 int rr[4];
@@ -226,10 +240,10 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
             unsigned wr = 0, wi = 0, ws = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int rr = residue_sym(Lr[e], Er[e], nr[e], mc, pow2[t]);
+                const int rr = residue_sym_bytes(Mr[e], Er[e], nr[e], mc, pow2[t]);
                 wr |= ((unsigned)rr & 0xFFu) << (8 * e);
                 if constexpr (E::cplx) {
-                    const int ri = residue_sym(Li[e], Ei[e], ni[e], mc, pow2[t]);
+                    const int ri = residue_sym_bytes(Mi[e], Ei[e], ni[e], mc, pow2[t]);
                     wi |= ((unsigned)ri & 0xFFu) << (8 * e);
                     // third plane from the int8-cast residues (mod.hpp:321-325)
                     const int rs = wrapping((int)(int8_t)rr + (int)(int8_t)ri, mc.p);

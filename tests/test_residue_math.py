@@ -52,3 +52,27 @@ def test_one_step_small(p):
     invp = np.float32(1.0) / np.float32(p)
     got = a - np.rint(a.astype(np.float32) * invp).astype(np.int64) * p
     assert np.array_equal(got, sym_exact(a, p))
+
+
+@pytest.mark.parametrize("p", INT8_MODULI)
+def test_byte_dot_residue(p):
+    """oz2_device.hpp residue_sym_bytes: sum_i byte_i(M) * (256^i mod p), one fp32 quotient step, sign applied last."""
+    rng = np.random.default_rng(1000 + p)
+    M = np.concatenate([rng.integers(0, 2 ** 53, size=400_000, dtype=np.int64), np.arange(0, 70_000, dtype=np.int64),
+                        (2 ** 53 - 1 - np.arange(0, 1000)).astype(np.int64),
+                        # rounding ties / range ends of every residue class
+                        (rng.integers(0, 2 ** 53 // p, size=3000)[:, None] * p + np.arange(-(p // 2) - 1, p // 2 + 2)[None, :]).ravel().clip(0)])
+    c = [pow(256, i, p) for i in range(7)]
+    s = np.zeros_like(M)
+    for i in range(7):
+        s += ((M >> (8 * i)) & 0xFF) * c[i]
+    assert s.max() < 2 ** 19
+    invp = np.float32(1.0) / np.float32(p)
+    r = s - np.rint(s.astype(np.float32) * invp).astype(np.int64) * p
+    want = sym_exact(M, p)
+    if p & 1:
+        assert np.array_equal(r, want)
+        assert np.array_equal(-r, sym_exact(-M, p))
+    else:  # p = 256: compare as int8 bytes (+128 and -128 are the same byte)
+        assert np.array_equal(r.astype(np.int8), want.astype(np.int8))
+        assert np.array_equal((-r).astype(np.int8), sym_exact(-M, p).astype(np.int8))
