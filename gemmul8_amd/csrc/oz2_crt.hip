@@ -9,7 +9,8 @@
 //   C  = AB | C+AB | -AB | C-AB  for host scalars alpha=+-1, beta in {0,1};
 //        otherwise fma(beta, C, alpha*AB) (complex: nested fma order of template_math.hpp:61-75);
 //   device-pointer scalars always take the general form (inverse_scaling_real.hpp:211-216).
-// Each thread handles 4 consecutive rows of one column: one dword load per residue plane.
+// Each thread handles ROWS (8 real / 4 complex) consecutive rows of one column: one vector load per residue plane, all
+// N loads issued before the first use (the plane loop is fully unrolled over the 20-moduli maximum with a uniform guard).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -53,33 +54,43 @@ __device__ __forceinline__ double crt_reduce(const CrtArgs& a, double Sh, double
 template <typename U, bool CPLX, typename MID>
 __global__ void __launch_bounds__(256) crt_kernel(const CrtArgs a) {
     constexpr int COMPS = CPLX ? 2 : 1;
-    const size_t row_groups = (a.m + 3) / 4;
+    constexpr int ROWS = CPLX ? 4 : 8;
+    constexpr int NV = ROWS * COMPS;  // values per thread and plane
+    const unsigned row_groups = (unsigned)((a.m + ROWS - 1) / ROWS);
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= row_groups * a.n) return;
+    if (gid >= (size_t)row_groups * a.n) return;
     const size_t col = gid / row_groups;
-    const size_t i0 = (gid - col * row_groups) * 4;
+    const size_t i0 = (gid - col * row_groups) * ROWS;
 
-    double Sh[4 * COMPS], Sl[4 * COMPS];
-#pragma unroll
-    for (int e = 0; e < 4 * COMPS; ++e) Sh[e] = 0.0, Sl[e] = 0.0;
-
+    // every plane's ROWS values first (planes are padded to 256 rows: the vector load never leaves the plane)
+    struct alignas(sizeof(MID) * NV) Vec {
+        MID v[NV];
+    };
     const MID* base = (const MID*)a.Cmid + (col * a.ld_mid + i0) * COMPS;
-    for (unsigned t = 0; t < a.N; ++t) {
-        MID c[4 * COMPS];
-        // 4 consecutive rows: one 4*COMPS*sizeof(MID)-byte vector load (planes are padded to 256 rows)
-        __builtin_memcpy(c, base + (size_t)t * a.plane_stride * COMPS, sizeof(c));
-        if (a.use_dd) {
-            const double qh = a.qh[t], ql = a.ql[t];
+    Vec c[20];
 #pragma unroll
-            for (int e = 0; e < 4 * COMPS; ++e) {
-                const double cd = (double)c[e];
-                Sh[e] = fma(qh, cd, Sh[e]);
-                Sl[e] = fma(ql, cd, Sl[e]);
+    for (unsigned t = 0; t < 20; ++t)
+        if (t < a.N) c[t] = *(const Vec*)(base + (size_t)t * a.plane_stride * COMPS);
+
+    double Sh[NV], Sl[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) Sh[e] = 0.0, Sl[e] = 0.0;
+#pragma unroll
+    for (unsigned t = 0; t < 20; ++t) {
+        if (t < a.N) {
+            if (a.use_dd) {
+                const double qh = a.qh[t], ql = a.ql[t];
+#pragma unroll
+                for (int e = 0; e < NV; ++e) {
+                    const double cd = (double)c[t].v[e];
+                    Sh[e] = fma(qh, cd, Sh[e]);
+                    Sl[e] = fma(ql, cd, Sl[e]);
+                }
+            } else {
+                const double q1 = a.q1[t];
+#pragma unroll
+                for (int e = 0; e < NV; ++e) Sh[e] = fma(q1, (double)c[t].v[e], Sh[e]);
             }
-        } else {
-            const double q1 = a.q1[t];
-#pragma unroll
-            for (int e = 0; e < 4 * COMPS; ++e) Sh[e] = fma(q1, (double)c[e], Sh[e]);
         }
     }
 
@@ -97,7 +108,7 @@ __global__ void __launch_bounds__(256) crt_kernel(const CrtArgs a) {
     const int sB = (int)a.sftB[col];
     U* Cc = (U*)a.C + (col * a.ldc) * COMPS;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < ROWS; ++e) {
         const size_t row = i0 + e;
         if (row >= a.m) break;
         const int sft = (int)a.sftA[row] + sB;
@@ -180,7 +191,8 @@ hipError_t launch_crt(hipStream_t stream, int dtype, int backend, unsigned N, si
             else if (ar == -1 && br == 1) a.mode = 4;
         }
     }
-    const size_t threads = ((m + 3) / 4) * n;
+    const size_t rows_per_thread = cplx ? 4 : 8;
+    const size_t threads = ((m + rows_per_thread - 1) / rows_per_thread) * n;
     dim3 grid((unsigned)((threads + 255) / 256));
 #define OZ2_CRT(U, CP, MID) hipLaunchKernelGGL((crt_kernel<U, CP, MID>), grid, dim3(256), 0, stream, a)
     if (i8) {
