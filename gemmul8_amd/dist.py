@@ -113,6 +113,8 @@ class ShardedGemm:
         self.my_planes = self.t1 - self.t0
         self.eng = engine if engine is not None else HipEngine(dtype_code, backend, m, n, k, N, fastmode, device)
         self.recv = self.eng.new_recv(self.c1 - self.c0)
+        import os
+        self.exchange_mode = os.environ.get("GEMMUL8_DIST_EXCHANGE", "p2p")  # "p2p": batch_isend_irecv, "a2a": all_to_all_single
         import numpy as np
         np_dt = {g.S: np.float32, g.D: np.float64, g.Cx: np.complex64, g.Z: np.complex128}[dtype_code]
         self._alpha = np.array([alpha], dtype=np_dt)
@@ -123,8 +125,36 @@ class ShardedGemm:
         sz = ncols * self.eng.mp * self.eng.mid_bytes
         return self.recv[t * sz:(t + 1) * sz]
 
+    def exchange_a2a(self):
+        """The same exchange as ONE all_to_all_single (GEMMUL8_DIST_EXCHANGE=a2a): the send buffer is packed
+        [dest s][my planes t][cols of s][mp]; because ranks own contiguous moduli ranges in rank order, the received
+        buffer [source r][planes of r][my cols][mp] IS the [t = 0..N-1][my cols][mp] layout the CRT reads."""
+        eng = self.eng
+        unit = eng.mp * eng.mid_bytes
+        in_splits, chunks = [], []
+        for s in range(self.world):
+            sc0, sc1 = split_range(self.n, self.world, s)
+            in_splits.append(self.my_planes * (sc1 - sc0) * unit)
+            for t in range(self.t0, self.t1):
+                if sc1 > sc0:
+                    chunks.append(eng.plane_block(t, sc0, sc1))
+        out_splits = []
+        for s in range(self.world):
+            st0, st1 = split_range(self.N, self.world, s)
+            out_splits.append((st1 - st0) * (self.c1 - self.c0) * unit)
+        send = torch.cat(chunks) if chunks else self.recv.new_empty(0)
+        stage = self.recv.is_cuda and dist.get_backend(self.group) == "gloo"
+        if stage:
+            host = torch.empty(self.recv.shape, dtype=self.recv.dtype)
+            dist.all_to_all_single(host, send.cpu(), out_splits, in_splits, group=self.group)
+            self.recv.copy_(host)
+        else:
+            dist.all_to_all_single(self.recv, send, out_splits, in_splits, group=self.group)
+
     def exchange(self):
         """Residue all-to-all: my planes' column block s -> rank s; planes of rank s for my columns <- rank s."""
+        if self.world > 1 and self.exchange_mode == "a2a":
+            return self.exchange_a2a()
         ops = []
         # gloo cannot send/recv device tensors: stage through host memory (only used by the single-GPU
         # 2-rank correctness test; the product path is NCCL/RCCL with device buffers)

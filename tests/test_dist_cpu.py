@@ -96,7 +96,8 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, N, fast, m, n, k, q):
+def _worker(rank, world, port, N, fast, m, n, k, q, exchange="p2p"):
+    os.environ["GEMMUL8_DIST_EXCHANGE"] = exchange
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -121,14 +122,14 @@ def _worker(rank, world, port, N, fast, m, n, k, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world,exchange", [(2, "p2p"), (3, "p2p"), (2, "a2a"), (3, "a2a")])
 @pytest.mark.parametrize("N,fast", [(14, False), (9, True), (2, False)])
-def test_sharded_gemm_matches_single_process(world, N, fast):
+def test_sharded_gemm_matches_single_process(world, exchange, N, fast):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     m, n, k = 19, 11, 37
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, fast, m, n, k, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, fast, m, n, k, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

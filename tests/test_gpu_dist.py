@@ -13,7 +13,8 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, N, fast, m, n, k, q):
+def _worker(rank, world, port, N, fast, m, n, k, q, exchange="p2p"):
+    os.environ["GEMMUL8_DIST_EXCHANGE"] = exchange
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -38,8 +39,9 @@ def _worker(rank, world, port, N, fast, m, n, k, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["p2p", "a2a"])
 @pytest.mark.parametrize("N,fast", [(14, False), (15, True)])
-def test_two_ranks_one_gpu_bitwise(N, fast):
+def test_two_ranks_one_gpu_bitwise(N, fast, exchange):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     s = socket.socket()
@@ -47,7 +49,7 @@ def test_two_ranks_one_gpu_bitwise(N, fast):
     port = s.getsockname()[1]
     s.close()
     m, n, k = 300, 515, 1000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, N, fast, m, n, k, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, N, fast, m, n, k, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
