@@ -299,7 +299,9 @@ __global__ void __launch_bounds__(256) stage_kmajor_kernel(const StageArgs a) {
 
 // Row-strided operand: grid (ceil(kp/TK), ceil(rows/32)), 256 threads; tile 32 rows x TK k staged RAW in LDS
 template <typename T> struct StageTile {
-    static constexpr int TR = 32;
+    // 16.6 KiB of LDS per workgroup for every type (8 workgroups per CU): 32 rows of float, 16 rows of the 8- and 16-byte
+    // types (a 16-row read segment of doubles is still one full 128-B cache line)
+    static constexpr int TR = sizeof(T) == 4 ? 32 : 16;
     static constexpr int TK = sizeof(T) == 16 ? 64 : 128;
 };
 template <typename T, int MODE>
@@ -314,12 +316,13 @@ __global__ void __launch_bounds__(256) stage_strided_kernel(const StageArgs a) {
     const size_t r0 = (size_t)blockIdx.y * TR;
     const size_t kb = (size_t)blockIdx.x * TK;
     {
-        const int rx = threadIdx.x & 31, ky = threadIdx.x >> 5;
+        constexpr int KY = 256 / TR;  // k values fetched per pass
+        const int rx = threadIdx.x % TR, ky = threadIdx.x / TR;
         const size_t row = r0 + rx;
         const T* x = (const T*)a.X + row;
 #pragma unroll 4
-        for (int it = 0; it < TK / 8; ++it) {
-            const int kk = ky + 8 * it;
+        for (int it = 0; it < TK / KY; ++it) {
+            const int kk = ky + KY * it;
             const size_t kg = kb + kk;
             tile[rx][kk] = (row < a.rows && kg < a.k) ? x[kg * a.ld] : E::zero();
         }
@@ -386,7 +389,7 @@ template <typename T, int MODE> static hipError_t launch_stage(hipStream_t strea
         dim3 grid((unsigned)a.rows);
         hipLaunchKernelGGL((stage_kmajor_kernel<T, MODE>), grid, dim3(256), 0, stream, a);
     } else {
-        dim3 grid((unsigned)(a.kp / StageTile<T>::TK), (unsigned)((a.rows + 31) / 32));
+        dim3 grid((unsigned)(a.kp / StageTile<T>::TK), (unsigned)((a.rows + StageTile<T>::TR - 1) / StageTile<T>::TR));
         hipLaunchKernelGGL((stage_strided_kernel<T, MODE>), grid, dim3(256), 0, stream, a);
     }
     return hipGetLastError();
