@@ -23,6 +23,7 @@ struct ModConst {
     float invp;   // RN(1/p)
     unsigned cb_lo;  // INT8 moduli: bytes (256^0, 256^1, 256^2, 256^3) mod p, each in [0, p)
     unsigned cb_hi;  //              bytes (256^4, 256^5, 256^6, 0) mod p
+    unsigned k56;    //              (-2^56) mod p in [0, p): correction for the 56-bit two's complement of a negative value
 };
 struct ModTable {
     ModConst mc[20];
@@ -123,6 +124,20 @@ __device__ __forceinline__ int residue_sym_bytes(uint64_t M, int E, bool neg, co
         r = s2 - __mul24((int)rintf((float)s2 * mc.invp), p);
     }
     return neg ? -r : r;
+}
+
+// The common case of the above, E = 0 (always true for num_moduli <= 15), with the sign folded in: Mt is M, or the 56-bit
+// two's complement 2^56 - M of a negative value, whose byte sum plus k56 = (-2^56 mod p) is congruent to -M.  The quotient
+// comes from ONE fma: float(s)/p + 2^23 rounds to the integer 2^23 + q (RN-even at unit spacing), whose low 24 bits are q,
+// exactly what v_mul_i32_i24 reads.  6 VALU operations: v_cndmask, 2 x v_dot4_u32_u8, v_cvt_f32_u32, v_fma_f32, v_mad_i32_i24.
+__device__ __forceinline__ int residue_sym_bytes_e0(unsigned Mt_lo, unsigned Mt_hi, bool neg, const ModConst& mc) {
+    const unsigned s = __builtin_amdgcn_udot4(Mt_lo, mc.cb_lo, __builtin_amdgcn_udot4(Mt_hi, mc.cb_hi, neg ? mc.k56 : 0u, false), false);
+    const float qf = fmaf((float)s, mc.invp, 8388608.0f);
+    // pinned to the full-rate 24-bit multiply-add: left to itself the compiler sees that only the low byte of the result is
+    // stored and picks the quarter-rate v_mul_lo_u32 / v_mad_u64_u32
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(__float_as_int(qf)), "s"(-mc.p), "v"(s));
+    return r;
 }
 
 // wrapping (mod.hpp:8-12)

@@ -43,6 +43,7 @@ ModTable make_mod_table(int backend) {
         }
         T.mc[t].cb_lo = backend == kINT8 ? (c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24)) : 0u;
         T.mc[t].cb_hi = backend == kINT8 ? (c[4] | (c[5] << 8) | (c[6] << 16)) : 0u;
+        T.mc[t].k56 = (unsigned)((p - (int)((1ull << 56) % (unsigned long long)p)) % p);
     }
     return T;
 }
@@ -183,7 +184,7 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
                 const ScaledInt y = trunc_scale(E::im(v[e]), s);
                 Mi[e] = y.M;
                 Ei[e] = y.E;
-                ni[e] = a.conj ? !y.neg : y.neg;
+                ni[e] = (a.conj && y.M != 0) ? !y.neg : y.neg;  // a zero stays +0 (two's-complement residue path)
             }
         }
         const short(*pow2)[64] = a.backend == kINT8 ? c_pow2mod_int8 : c_pow2mod_fp8;
@@ -231,6 +232,47 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
                     }
                     put(o + a.part_stride, t, ri);
                     put(o + 2 * a.part_stride, t, rs);
+                }
+            }
+            return;
+        }
+        // E > 0 (|x|*2^s >= 2^53) cannot happen for num_moduli <= 15; one wave-uniform test keeps it out of the common path
+        bool anyE = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            anyE |= Er[e] > 0;
+            if constexpr (E::cplx) anyE |= Ei[e] > 0;
+        }
+        if (!__any(anyE)) {
+            unsigned rlo[4], rhi[4], ilo[4], ihi[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint64_t mt = nr[e] ? (1ull << 56) - Mr[e] : Mr[e];
+                rlo[e] = (unsigned)mt, rhi[e] = (unsigned)(mt >> 32);
+                if constexpr (E::cplx) {
+                    const uint64_t it = ni[e] ? (1ull << 56) - Mi[e] : Mi[e];
+                    ilo[e] = (unsigned)it, ihi[e] = (unsigned)(it >> 32);
+                }
+            }
+            for (int t = a.t_begin; t < a.t_end; ++t) {
+                const ModConst mc = a.mt.mc[t];
+                unsigned wr = 0, wi = 0, ws = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int rr = residue_sym_bytes_e0(rlo[e], rhi[e], nr[e], mc);
+                    wr |= ((unsigned)rr & 0xFFu) << (8 * e);
+                    if constexpr (E::cplx) {
+                        const int ri = residue_sym_bytes_e0(ilo[e], ihi[e], ni[e], mc);
+                        wi |= ((unsigned)ri & 0xFFu) << (8 * e);
+                        const int rs = wrapping((int)(int8_t)rr + (int)(int8_t)ri, mc.p);
+                        ws |= ((unsigned)rs & 0xFFu) << (8 * e);
+                    }
+                }
+                int8_t* o = out + (size_t)t * a.plane_stride;
+                *(unsigned*)o = wr;
+                if constexpr (E::cplx) {
+                    *(unsigned*)(o + a.part_stride) = wi;
+                    *(unsigned*)(o + 2 * a.part_stride) = ws;
                 }
             }
             return;

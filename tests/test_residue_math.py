@@ -76,3 +76,31 @@ def test_byte_dot_residue(p):
     else:  # p = 256: compare as int8 bytes (+128 and -128 are the same byte)
         assert np.array_equal(r.astype(np.int8), want.astype(np.int8))
         assert np.array_equal((-r).astype(np.int8), sym_exact(-M, p).astype(np.int8))
+
+
+@pytest.mark.parametrize("p", INT8_MODULI)
+def test_byte_dot_residue_signed_fma(p):
+    """oz2_device.hpp residue_sym_bytes_e0: bytes of M or of the 56-bit two's complement 2^56 - M (negative values) plus
+    k56 = (-2^56 mod p); quotient from one fma(float(s), 1/p, 2^23) whose low 24 bits are rint(s/p)."""
+    rng = np.random.default_rng(2000 + p)
+    M = np.concatenate([rng.integers(1, 2 ** 53, size=300_000, dtype=np.int64), np.arange(1, 70_000, dtype=np.int64),
+                        (2 ** 53 - 1 - np.arange(0, 1000)).astype(np.int64),
+                        (rng.integers(1, 2 ** 53 // p, size=3000)[:, None] * p + np.arange(-(p // 2) - 1, p // 2 + 2)[None, :]).ravel()])
+    c = [pow(256, i, p) for i in range(7)]
+    k56 = (p - pow(2, 56, p)) % p
+    invp = np.float64(np.float32(1.0) / np.float32(p))
+    for neg in (False, True):
+        Mt = (2 ** 56 - M) if neg else M
+        s = np.full_like(M, k56 if neg else 0)
+        for i in range(7):
+            s += ((Mt >> (8 * i)) & 0xFF) * c[i]
+        assert s.max() < 2 ** 20
+        # fma in fp32 == exact double sum rounded once to fp32 (all operands fit)
+        qf = (s.astype(np.float64) * invp + 8388608.0).astype(np.float32)
+        q = qf.view(np.int32).astype(np.int64) & 0xFFFFFF
+        r = s - q * p
+        want = sym_exact(-M if neg else M, p)
+        if p & 1:
+            assert np.array_equal(r, want)
+        else:
+            assert np.array_equal(r.astype(np.int8), want.astype(np.int8))
