@@ -157,5 +157,50 @@ def watt():
         w.writerows(rows)
 
 
+def types():
+    """Every dtype x backend combination at 4096^3 and 8192^3: TFLOPS (complex counts 4x flops, test_flops.hpp:38-40),
+    sampled max relative error vs an 80-bit product, native GEMM of the same type alongside."""
+    rows = []
+    gen = torch.Generator(device=dev).manual_seed(11)
+    cases = [("S", torch.float32, g.INT8, 7), ("S", torch.float32, g.FP8, 6), ("D", torch.float64, g.INT8, 14), ("D", torch.float64, g.FP8, 12),
+             ("C", torch.complex64, g.INT8, 7), ("C", torch.complex64, g.FP8, 6), ("Z", torch.complex128, g.INT8, 14),
+             ("Z", torch.complex128, g.FP8, 12)]
+    for n in [4096, 8192]:
+        for name, dt, be, N in cases:
+            rdt = torch.float32 if dt in (torch.float32, torch.complex64) else torch.float64
+
+            def rnd():
+                x = torch.rand((n, n), generator=gen, dtype=rdt, device=dev) - 0.5
+                if dt.is_complex:
+                    x = torch.complex(x, torch.rand((n, n), generator=gen, dtype=rdt, device=dev) - 0.5)
+                return x.contiguous()
+            A, B = rnd(), rnd()
+            Cm = torch.zeros((n, n), dtype=dt, device=dev)
+            tot, _, _ = g.work_size(dt.is_complex, be, n, n, n, N)
+            work = torch.empty(tot, dtype=torch.uint8, device=dev)
+            fl = (4 if dt.is_complex else 1) * 2.0 * n ** 3
+            rec = {"gemm": name + "GEMM", "n": n, "backend": "INT8" if be == g.INT8 else "FP8", "num_moduli": N}
+            for fast in [False, True]:
+                ms = timed(lambda: g.gemm(A, B, N, fastmode=fast, backend=be, C_out=Cm, work=work), 5, 1)
+                rec[("fast" if fast else "accu") + "_TFLOPS"] = fl / ms * 1e-9
+            g.gemm(A, B, N, fastmode=False, backend=be, C_out=Cm, work=work)
+            rows_i = np.arange(0, n, n // 24)[:24]
+            cols_i = np.arange(5, n, n // 24)[:24]
+            hp = np.clongdouble if dt.is_complex else np.longdouble
+            ref = A[:, rows_i].cpu().numpy().T.astype(hp) @ B[cols_i, :].cpu().numpy().T.astype(hp)
+            rec["accu_max_rel_err"] = float(np.max(np.abs(Cm[cols_i][:, rows_i].cpu().numpy().T - ref) / np.abs(ref)))
+            nat_ms = timed(lambda: torch.matmul(B, A), 5, 1)
+            Cn = torch.matmul(B, A)
+            rec["native_TFLOPS"] = fl / nat_ms * 1e-9
+            rec["native_max_rel_err"] = float(np.max(np.abs(Cn[cols_i][:, rows_i].cpu().numpy().T - ref) / np.abs(ref)))
+            rows.append(rec)
+            print(rec, flush=True)
+            del A, B, Cm, Cn, work
+    with open(os.path.join(out_dir, "types_backends.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows)
+
+
 for wname in which:
-    {"accuracy": accuracy, "flops": flops, "watt": watt}[wname]()
+    {"accuracy": accuracy, "flops": flops, "watt": watt, "types": types}[wname]()
