@@ -237,13 +237,18 @@ def main():
         parallelism = "single-gpu"
     else:
         from gemmul8_amd import dist as gd
-        plan = gd.ShardedGemm(g.D, g.INT8, n, n, n, N, fastmode=args.fast, device=dev)
+        # GEMMUL8_DIST_SHARD=columns (default: output columns sharded, one all_reduce(MAX) of the row bounds, no bulk exchange)
+        # or =moduli (moduli sharded, residue all-to-all + column-block CRT); both bit-identical to the single-GPU result
+        plan = gd.make_plan(g.D, g.INT8, n, n, n, N, fastmode=args.fast, device=dev)
 
         def step(record):
             ev = plan.run(A, B, Cmat, record_gemm_events=record)
             if record and ev is not None:
                 gemm_events.append(ev)
-        parallelism = f"moduli-sharded x{world} (residue all-to-all over RCCL, column-block CRT)"
+        if isinstance(plan, gd.ColumnShardedGemm):
+            parallelism = f"output columns sharded x{world} (every rank runs all {N} moduli on n/{world} columns; all_reduce(MAX) of the row bounds over RCCL)"
+        else:
+            parallelism = f"moduli-sharded x{world} (residue all-to-all over RCCL, column-block CRT)"
 
     def barrier():
         if world > 1:
@@ -275,13 +280,15 @@ def main():
         planes_here = N if world == 1 else plan.my_planes
         gemm_ms = float(np.mean([a.elapsed_time(b) for a, b in gemm_events])) if gemm_events else None
         ops = planes_here * 2.0 * n ** 3
+        if world > 1 and isinstance(plan, gd.ColumnShardedGemm):
+            ops = N * 2.0 * n * n * plan.ncols
         peak = 5000.0  # dense INT8 MFMA TOPS (MI355X_MICROARCH.md: ~5 PF-class dense FP8/INT8)
         roof = None
         if gemm_ms:
             ach = ops / (gemm_ms * 1e-3) * 1e-12
             roof = {"bound": "mfma", "kernel": "oz2::gemm_i8_kernel<EPI_MOD> (batched over moduli)", "achieved": ach, "peak": peak,
                     "unit": "TOP/s", "frac": ach / peak, "traffic": None, "launch_ms": gemm_ms, "ops_per_launch": ops,
-                    "algorithmic_bytes_per_launch": planes_here * 3.0 * n * n}
+                    "algorithmic_bytes_per_launch": planes_here * 3.0 * n * n if world == 1 else None}
             # HBM-side bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
             # WRITE_SIZE, tools/pmc_traffic.py); only valid for the configuration that was profiled
             tf = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))

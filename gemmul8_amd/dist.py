@@ -87,6 +87,13 @@ class HipEngine:
     def sft_ptrs(self):
         return self.L.sftA, self.L.sftB
 
+    def crt_local(self, Cblk, alpha_ptr, beta_ptr):
+        """CRT of the engine's own C_mid planes into the (n, ld) tensor Cblk (column sharding: the engine IS the block)."""
+        sA, sB = self.sft_ptrs()
+        ldc = Cblk.shape[1]
+        g.check(self.lib.gemmul8_crt(self._stream(), self.dt, self.be, self.N, self.m, self.n, self.L.C_mid, self.mp, self.L.sizeC, sA, sB,
+                                     alpha_ptr, beta_ptr, Cblk.data_ptr(), ldc), "crt")
+
     def crt(self, recv, c0, c1, Cmat, alpha_ptr, beta_ptr):
         ncols = c1 - c0
         if ncols == 0:
@@ -95,6 +102,75 @@ class HipEngine:
         ldc = Cmat.shape[1]
         g.check(self.lib.gemmul8_crt(self._stream(), self.dt, self.be, self.N, self.m, ncols, recv.data_ptr(), self.mp, ncols * self.mp,
                                      sA, sB + 2 * c0, alpha_ptr, beta_ptr, Cmat.data_ptr() + c0 * ldc * self.elem_bytes, ldc), "crt")
+
+
+class ColumnShardedGemm:
+    """C[:, cols_r] = alpha*op(A)*op(B[:, cols_r]) + beta*C[:, cols_r]: the output COLUMNS are sharded, every rank runs all
+    num_moduli residue pipelines on its column block.
+
+    Column blocks are independent stripes of the path except for one thing: the accurate-mode row shifts of A depend on the
+    row maxima of the bound product over ALL columns, so the ranks all-reduce(MAX) int32[mp] between the bound phase and
+    the quantise phase (fast mode: no collective at all).  Compared with moduli sharding there is no bulk exchange
+    (7/8 * N/G * m*n residue bytes per rank) and no imbalance when num_moduli is not a multiple of the GPU count
+    (14 moduli on 8 GPUs: 2,2,2,2,2,2,1,1); the price is that every rank quantises all N planes of A.  Results are
+    bit-identical to the single-GPU call for every world size (same shifts, same per-element arithmetic).
+    A, B replicated, C column-sharded, as for ShardedGemm."""
+
+    def __init__(self, dtype_code, backend, m, n, k, N, fastmode=False, device=None, group=None, engine=None, alpha=1.0, beta=0.0,
+                 mp=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.m, self.n, self.k, self.N, self.fast = m, n, k, N, fastmode
+        self.c0, self.c1 = split_range(n, self.world, self.rank)
+        self.ncols = self.c1 - self.c0
+        self.my_planes = N
+        self.dt = dtype_code
+        self.elem_bytes = {g.S: 4, g.D: 8, g.Cx: 8, g.Z: 16}[dtype_code]
+        # engine for the (m, ncols, k) sub-problem; a rank without columns (n < world) only takes part in the all-reduce
+        self.eng = engine if engine is not None else (HipEngine(dtype_code, backend, m, self.ncols, k, N, fastmode, device) if self.ncols else None)
+        # length of the row-bound vector every rank reduces (HipEngine pads rows to 256; a plugged-in engine may not)
+        self.mp = self.eng.mp if self.eng is not None else (mp if mp is not None else (m + 255) // 256 * 256)
+        self.device = device
+        import numpy as np
+        np_dt = {g.S: np.float32, g.D: np.float64, g.Cx: np.complex64, g.Z: np.complex128}[dtype_code]
+        self._alpha = np.array([alpha], dtype=np_dt)
+        self._beta = np.array([beta], dtype=np_dt)
+
+    def run(self, A, B, Cmat, record_gemm_events=False):
+        eng = self.eng
+        Bblk = B[self.c0:self.c1] if B is not None else None      # tensor rows = matrix columns
+        Cblk = Cmat[self.c0:self.c1]
+        if not self.fast:
+            if eng is not None:
+                eng.bounds(A, Bblk, 0, self.ncols)
+                rowmax = eng.maxima()[:self.mp]
+            else:
+                rowmax = torch.zeros(self.mp, dtype=torch.int32, device=self.device if self.device is not None else "cpu")
+            if self.world > 1:
+                stage = rowmax.is_cuda and dist.get_backend(self.group) == "gloo"  # single-GPU multi-rank smoke test only
+                if stage:
+                    host = rowmax.cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
+                    rowmax.copy_(host)
+                else:
+                    dist.all_reduce(rowmax, op=dist.ReduceOp.MAX, group=self.group)
+        if eng is None:
+            return None
+        eng.finish(A, Bblk, 0, self.N)
+        ev = None
+        if record_gemm_events and torch.cuda.is_available() and Cmat.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            eng.lowprec(0, self.N)
+            e1.record()
+            ev = (e0, e1)
+        else:
+            eng.lowprec(0, self.N)
+        eng.crt_local(Cblk, self._alpha.ctypes.data, self._beta.ctypes.data)
+        return ev
+
+    gather_result = None  # bound below (same assembly as ShardedGemm)
 
 
 class ShardedGemm:
@@ -219,3 +295,14 @@ class ShardedGemm:
                 dist.broadcast(blk, src=src, group=self.group)
                 out[sc0:sc1] = blk
         return out
+
+
+ColumnShardedGemm.gather_result = ShardedGemm.gather_result
+
+
+def make_plan(dtype_code, backend, m, n, k, N, **kw):
+    """The multi-GPU plan bench.py and callers use: GEMMUL8_DIST_SHARD=columns (default) | moduli."""
+    import os
+    mode = os.environ.get("GEMMUL8_DIST_SHARD", "columns")
+    cls = {"columns": ColumnShardedGemm, "moduli": ShardedGemm}[mode]
+    return cls(dtype_code, backend, m, n, k, N, **kw)

@@ -88,6 +88,16 @@ class OracleEngine:
                              alpha_ptr, beta_ptr, blk.ctypes.data, self.m, 0)
 
 
+def _oracle_crt_local(self, Cblk, alpha_ptr, beta_ptr):
+    mid = self.C_mid.reshape(-1)
+    blk = Cblk.numpy()
+    self.lib.oz2_invscal(self.dt, 0, self.N, self.m, self.n, mid.ctypes.data, ol._p(self.sftA), ol._p(self.sftB), alpha_ptr, beta_ptr,
+                         blk.ctypes.data, self.m, 0)
+
+
+OracleEngine.crt_local = _oracle_crt_local
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -120,6 +130,50 @@ def _worker(rank, world, port, N, fast, m, n, k, q, exchange="p2p"):
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def _worker_cols(rank, world, port, N, fast, m, n, k, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gemmul8_amd as g
+        from gemmul8_amd import dist as gd
+        rng = np.random.default_rng(43)
+        A = (rng.random((m, k)) - 0.5) * np.exp(rng.standard_normal((m, k)))
+        B = (rng.random((k, n)) - 0.5) * np.exp(rng.standard_normal((k, n)))
+        C0 = rng.standard_normal((m, n))
+        c0, c1 = gd.split_range(n, world, rank)
+        eng = OracleEngine(A, B[:, c0:c1], N, fast) if c1 > c0 else None
+        plan = gd.ColumnShardedGemm(g.D, g.INT8, m, n, k, N, fastmode=fast, engine=eng, alpha=-1.5, beta=1.5, mp=m)
+        assert (plan.c0, plan.c1) == (c0, c1)
+        Cmat = torch.from_numpy(np.ascontiguousarray(C0.T))
+        plan.run(None, None, Cmat)
+        full = plan.gather_result(Cmat)
+        if rank == 0:
+            ref = ol.gemm(A, B, N, fastmode=fast, alpha=-1.5, beta=1.5, C0=C0)
+            q.put(np.ascontiguousarray(full.numpy().T).tobytes() == np.ascontiguousarray(ref).tobytes())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("N,fast,n", [(14, False, 11), (9, True, 11), (5, False, 2)])
+def test_column_sharded_gemm_matches_single_process(world, N, fast, n):
+    """Column-block sharding (the default plan): one all_reduce(MAX) of the row bounds; n = 2 with 3 ranks leaves a rank
+    without columns that still has to take part in the collective."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    m, k = 19, 37
+    procs = [ctx.Process(target=_worker_cols, args=(r, world, port, N, fast, m, n, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=10), "column-sharded result differs from the single-process oracle"
 
 
 @pytest.mark.parametrize("world,exchange", [(2, "p2p"), (3, "p2p"), (2, "a2a"), (3, "a2a")])
