@@ -8,6 +8,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -123,6 +124,31 @@ def test_parity_complex_shapes():
         A, B = rand((m, k), np.complex128, rng), rand((k, n), np.complex128, rng)
         gu.parity_case(A, B, 20, False)
         gu.parity_case(A, B, 9, True)
+
+
+@pytest.mark.parametrize("dtype,N", [(np.float64, 14), (np.complex128, 9)])
+def test_parity_long_k_int8(dtype, N):
+    """k > 65536: accumulators may exceed 2^30, so the GEMM epilogue must leave the fp32 residue path for the integer
+    multiply-high path (oz2_gemm_i8.hip RED_GENERIC) -- bit-exact against the oracle."""
+    import gpu_util as gu
+    rng = np.random.default_rng(66)
+    m, n, k = 40, 24, 66048 + 5
+    A, B = rand((m, k), dtype, rng), rand((k, n), dtype, rng)
+    gu.parity_case(A, B, N, False)
+    gu.parity_case(A, B, N, True)
+
+
+def test_fp8_rejects_k_beyond_exactness_bound():
+    """FP8 products are only exact in FP32 for k <= 65536 (src/gemmul8_real.hpp k limit): the C ABI returns E_ARG."""
+    import ctypes as C
+    import gemmul8_amd as g
+    lib = g.lib()
+    m = n = 8
+    k = 65537
+    A = torch.zeros((k, m), dtype=torch.float32, device="cuda")
+    B = torch.zeros((n, k), dtype=torch.float32, device="cuda")
+    with pytest.raises(Exception):
+        g.gemm(A, B, 6, backend=g.FP8)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
