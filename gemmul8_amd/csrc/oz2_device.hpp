@@ -21,9 +21,9 @@ struct ModConst {
     int c18;      // sym(2^18 mod p)
     int c36;      // sym(2^36 mod p)
     float invp;   // RN(1/p)
-    unsigned cb_lo;  // INT8 moduli: bytes (256^0, 256^1, 256^2, 256^3) mod p, each in [0, p)
-    unsigned cb_hi;  //              bytes (256^4, 256^5, 256^6, 0) mod p
+    unsigned cb[4];  // INT8 moduli: cb[i] = bytes (256^(4i), .., 256^(4i+3)) mod p, each in [0, p); byte 15 is 0
     unsigned k56;    //              (-2^56) mod p in [0, p): correction for the 56-bit two's complement of a negative value
+    unsigned k120;   //              (-2^120) mod p: the same for the 120-bit form used when E > 0
 };
 struct ModTable {
     ModConst mc[20];
@@ -111,27 +111,43 @@ __device__ __forceinline__ int residue_sym(const Limbs& L, int E, bool neg, cons
     return r;
 }
 
-// INT8 moduli (p <= 256): symmetric residue of +-M*2^E, M < 2^56, from the BYTES of M: sum_i b_i * (256^i mod p) < 2^19
-// by two v_dot4_u32_u8, then one fp32 quotient step that is exact -- float(s) is exact and s/p stays at least 1/(2p) away
-// from a rounding tie for odd p, so the result is the canonical representative and needs no wrap.  p = 256: the tie
-// s = 128 gives +-128, the same int8 byte either way.  9 VALU operations per modulus against 15 for the limb version.
-__device__ __forceinline__ int residue_sym_bytes(uint64_t M, int E, bool neg, const ModConst& mc, const short* pow2row) {
-    const int p = mc.p;
-    const unsigned s = __builtin_amdgcn_udot4((unsigned)M, mc.cb_lo, __builtin_amdgcn_udot4((unsigned)(M >> 32), mc.cb_hi, 0u, false), false);
-    int r = (int)s - __mul24((int)rintf((float)s * mc.invp), p);
-    if (E > 0) {  // only for num_moduli > 15 (|A'| >= 2^53)
-        const int s2 = __mul24(r, (int)pow2row[E < 63 ? E : 63]);
-        r = s2 - __mul24((int)rintf((float)s2 * mc.invp), p);
+// INT8 moduli (p <= 256): symmetric residue of +-M*2^E (M < 2^53, E < 64) from the BYTES of the 120-bit integer M*2^E
+// -- or of its two's complement 2^120 - M*2^E for a negative value, corrected by k120 = (-2^120 mod p) in the accumulator
+// input: sum_i b_i * (256^i mod p) < 2^20 by four v_dot4_u32_u8, then one quotient step from a single fma
+// (float(s)/p + 2^23 rounds to 2^23 + q; s * |RN(1/p) - 1/p| <= 1/(16p) keeps it clear of the 1/(2p) tie distance of an
+// odd p, so the result is the canonical representative; p = 256: a tie gives +-128, the same int8 byte).  No 2^E mod p
+// table, no second reduction.  Only needed for num_moduli > 15 (|A'| >= 2^53).
+struct Bytes128 {
+    unsigned w[4];
+};
+__device__ __forceinline__ Bytes128 shifted_bytes(uint64_t M, int E, bool neg) {
+    E = E < 63 ? E : 63;  // the algorithm keeps E <= ~26 (|A'| < sqrt(P)); the clamp only guards the shift itself
+    uint64_t lo = M << E;
+    uint64_t hi = E ? (M >> (64 - E)) : 0ull;
+    if (neg) {  // 2^120 - X (X != 0 whenever neg is set)
+        lo = ~lo + 1ull;
+        hi = ~hi + (lo == 0 ? 1ull : 0ull);
+        hi &= 0x00FFFFFFFFFFFFFFull;
     }
-    return neg ? -r : r;
+    return Bytes128{{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)}};
+}
+__device__ __forceinline__ int residue_sym_bytes128(const Bytes128& x, bool neg, const ModConst& mc) {
+    unsigned s = __builtin_amdgcn_udot4(x.w[3], mc.cb[3], neg ? mc.k120 : 0u, false);
+    s = __builtin_amdgcn_udot4(x.w[2], mc.cb[2], s, false);
+    s = __builtin_amdgcn_udot4(x.w[1], mc.cb[1], s, false);
+    s = __builtin_amdgcn_udot4(x.w[0], mc.cb[0], s, false);
+    const float qf = fmaf((float)s, mc.invp, 8388608.0f);
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(__float_as_int(qf)), "s"(-mc.p), "v"(s));
+    return r;
 }
 
-// The common case of the above, E = 0 (always true for num_moduli <= 15), with the sign folded in: Mt is M, or the 56-bit
+// The common case, E = 0 (always true for num_moduli <= 15): Mt is M, or the 56-bit
 // two's complement 2^56 - M of a negative value, whose byte sum plus k56 = (-2^56 mod p) is congruent to -M.  The quotient
 // comes from ONE fma: float(s)/p + 2^23 rounds to the integer 2^23 + q (RN-even at unit spacing), whose low 24 bits are q,
 // exactly what v_mul_i32_i24 reads.  6 VALU operations: v_cndmask, 2 x v_dot4_u32_u8, v_cvt_f32_u32, v_fma_f32, v_mad_i32_i24.
 __device__ __forceinline__ int residue_sym_bytes_e0(unsigned Mt_lo, unsigned Mt_hi, bool neg, const ModConst& mc) {
-    const unsigned s = __builtin_amdgcn_udot4(Mt_lo, mc.cb_lo, __builtin_amdgcn_udot4(Mt_hi, mc.cb_hi, neg ? mc.k56 : 0u, false), false);
+    const unsigned s = __builtin_amdgcn_udot4(Mt_lo, mc.cb[0], __builtin_amdgcn_udot4(Mt_hi, mc.cb[1], neg ? mc.k56 : 0u, false), false);
     const float qf = fmaf((float)s, mc.invp, 8388608.0f);
     // pinned to the full-rate 24-bit multiply-add: left to itself the compiler sees that only the low byte of the result is
     // stored and picks the quarter-rate v_mul_lo_u32 / v_mad_u64_u32

@@ -35,15 +35,21 @@ ModTable make_mod_table(int backend) {
         T.mc[t].c18 = sym(1ll << 18);
         T.mc[t].c36 = sym(1ll << 36);
         T.mc[t].invp = 1.0f / (float)p;
-        unsigned c[7];
+        unsigned c[16];
         long long pw = 1;
-        for (int i = 0; i < 7; ++i) {
-            c[i] = (unsigned)(pw % p);
+        for (int i = 0; i < 16; ++i) {
+            c[i] = i < 15 ? (unsigned)(pw % p) : 0u;
             pw = (pw % p) * 256;
         }
-        T.mc[t].cb_lo = backend == kINT8 ? (c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24)) : 0u;
-        T.mc[t].cb_hi = backend == kINT8 ? (c[4] | (c[5] << 8) | (c[6] << 16)) : 0u;
-        T.mc[t].k56 = (unsigned)((p - (int)((1ull << 56) % (unsigned long long)p)) % p);
+        for (int i = 0; i < 4; ++i)
+            T.mc[t].cb[i] = backend == kINT8 ? (c[4 * i] | (c[4 * i + 1] << 8) | (c[4 * i + 2] << 16) | (c[4 * i + 3] << 24)) : 0u;
+        auto pow2 = [p](int e) {  // 2^e mod p
+            long long r = 1;
+            for (int i = 0; i < e; ++i) r = (r * 2) % p;
+            return (int)r;
+        };
+        T.mc[t].k56 = (unsigned)((p - pow2(56)) % p);
+        T.mc[t].k120 = (unsigned)((p - pow2(120)) % p);
     }
     return T;
 }
@@ -277,15 +283,21 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
             }
             return;
         }
+        Bytes128 Xr[4], Xi[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            Xr[e] = shifted_bytes(Mr[e], Er[e], nr[e]);
+            if constexpr (E::cplx) Xi[e] = shifted_bytes(Mi[e], Ei[e], ni[e]);
+        }
         for (int t = a.t_begin; t < a.t_end; ++t) {
             const ModConst mc = a.mt.mc[t];
             unsigned wr = 0, wi = 0, ws = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int rr = residue_sym_bytes(Mr[e], Er[e], nr[e], mc, pow2[t]);
+                const int rr = residue_sym_bytes128(Xr[e], nr[e], mc);
                 wr |= ((unsigned)rr & 0xFFu) << (8 * e);
                 if constexpr (E::cplx) {
-                    const int ri = residue_sym_bytes(Mi[e], Ei[e], ni[e], mc, pow2[t]);
+                    const int ri = residue_sym_bytes128(Xi[e], ni[e], mc);
                     wi |= ((unsigned)ri & 0xFFu) << (8 * e);
                     // third plane from the int8-cast residues (mod.hpp:321-325)
                     const int rs = wrapping((int)(int8_t)rr + (int)(int8_t)ri, mc.p);

@@ -104,3 +104,35 @@ def test_byte_dot_residue_signed_fma(p):
             assert np.array_equal(r, want)
         else:
             assert np.array_equal(r.astype(np.int8), want.astype(np.int8))
+
+
+@pytest.mark.parametrize("p", INT8_MODULI)
+def test_byte_dot_residue_shifted_120bit(p):
+    """oz2_device.hpp shifted_bytes + residue_sym_bytes128: bytes of M*2^E (E < 64) or of 2^120 - M*2^E, four dot4, one fma."""
+    rng = np.random.default_rng(3000 + p)
+    c = [pow(256, i, p) for i in range(15)]
+    k120 = (p - pow(2, 120, p)) % p
+    invp = np.float64(np.float32(1.0) / np.float32(p))
+    Ms = [int(x) for x in rng.integers(1, 2 ** 53, size=4000)] + [1, 2 ** 53 - 1, 2 ** 52, p, p - 1, (p + 1) // 2, 255, 256]
+    Es = [int(x) for x in rng.integers(0, 64, size=len(Ms))]
+    Es[-8:] = [63, 63, 0, 1, 40, 26, 7, 8]
+    for neg in (False, True):
+        s_list, want = [], []
+        for M, E in zip(Ms, Es):
+            X = M << E
+            Xt = (2 ** 120 - X) if neg else X
+            s = (k120 if neg else 0) + sum(((Xt >> (8 * i)) & 0xFF) * c[i] for i in range(15))
+            s_list.append(s)
+            v = -X if neg else X
+            r = v % p
+            want.append(r - p if r > (p - 1) // 2 else r)
+        s = np.array(s_list, dtype=np.int64)
+        assert s.max() < 2 ** 20
+        qf = (s.astype(np.float64) * invp + 8388608.0).astype(np.float32)
+        q = qf.view(np.int32).astype(np.int64) & 0xFFFFFF
+        r = s - q * p
+        want = np.array(want, dtype=np.int64)
+        if p & 1:
+            assert np.array_equal(r, want)
+        else:
+            assert np.array_equal(r.astype(np.int8), want.astype(np.int8))
