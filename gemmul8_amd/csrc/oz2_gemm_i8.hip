@@ -361,7 +361,10 @@ static int num_cus() {
 }
 
 template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int planes) {
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {};  // the attribute belongs to the function on ONE device
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 0;
+    bool& attr_set = attr_set_dev[dev_];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;

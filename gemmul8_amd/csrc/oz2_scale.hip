@@ -54,14 +54,16 @@ ModTable make_mod_table(int backend) {
     return T;
 }
 
-__constant__ short c_pow2mod_int8[20][64];
 __constant__ short c_pow2mod_fp8[20][64];
 static hipError_t upload_pow2_once() {
-    static bool done = false;
+    // __constant__ memory is per device: track the upload per device of the calling thread
+    static bool done_dev[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    bool& done = done_dev[dev];
     if (done) return hipSuccess;
-    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_pow2mod_int8), GEMMUL8_POW2MOD_INT8, sizeof(GEMMUL8_POW2MOD_INT8));
-    if (e != hipSuccess) return e;
-    e = hipMemcpyToSymbol(HIP_SYMBOL(c_pow2mod_fp8), GEMMUL8_POW2MOD_FP8, sizeof(GEMMUL8_POW2MOD_FP8));
+    // only the FP8 moduli (limb residues) still need the 2^E mod p table; INT8 moduli take the byte-dot path
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_pow2mod_fp8), GEMMUL8_POW2MOD_FP8, sizeof(GEMMUL8_POW2MOD_FP8));
     if (e != hipSuccess) return e;
     done = true;
     return hipSuccess;
@@ -193,7 +195,7 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
                 ni[e] = (a.conj && y.M != 0) ? !y.neg : y.neg;  // a zero stays +0 (two's-complement residue path)
             }
         }
-        const short(*pow2)[64] = a.backend == kINT8 ? c_pow2mod_int8 : c_pow2mod_fp8;
+        const short(*pow2)[64] = c_pow2mod_fp8;  // FP8 branch only
         if (a.backend == kFP8) {
             // residues up to +-544 are split into 2-3 e4m3 planes of integers <= 16 (mod.hpp:159-189, 361-410); complex:
             // the residues of Re, Im and wrapping(Re + Im) go to the three parts
