@@ -480,9 +480,15 @@ hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajo
         const size_t ub = is_f32(dtype) ? 4 : 8;
         hipError_t e = hipMemsetAsync(scratch_amax, 0, ub * rows, stream);
         if (e != hipSuccess) return e;
-        unsigned ksplit = (unsigned)((k + 511) / 512);
-        if (ksplit > 64) ksplit = 64;
-        if (ksplit < 1) ksplit = 1;
+        // enough workgroups to fill the chip at every size (~2048), at least 16 k values per workgroup: the per-thread chain of
+        // dependent strided loads, not bandwidth, bounds this kernel when the grid is small (42 us at 1024^2 with k/512 splits)
+        const size_t row_groups = (rows + 63) / 64;
+        size_t ks = (2048 + row_groups - 1) / row_groups;
+        const size_t ks_max = (k + 15) / 16;
+        if (ks > ks_max) ks = ks_max;
+        if (ks < 1) ks = 1;
+        if (ks > 65535) ks = 65535;
+        const unsigned ksplit = (unsigned)ks;
         dim3 grid((unsigned)((rows + 63) / 64), ksplit);
         switch (dtype) {
         case kF32: hipLaunchKernelGGL(amax_strided_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, ld, rows, k, scratch_amax); break;
