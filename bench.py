@@ -238,15 +238,19 @@ def main():
         parallelism = "single-gpu"
     else:
         from gemmul8_amd import dist as gd
-        # GEMMUL8_DIST_SHARD=columns (default: output columns sharded, one all_reduce(MAX) of the row bounds, no bulk exchange)
-        # or =moduli (moduli sharded, residue all-to-all + column-block CRT); both bit-identical to the single-GPU result
+        # GEMMUL8_DIST_SHARD=blocks (default: output blocks on a rank grid, one all_reduce(MAX) of the bounds, no bulk exchange),
+        # =columns (the 1 x G special case with its own class) or =moduli (moduli sharded, residue all-to-all + column-block
+        # CRT); all bit-identical to the single-GPU result
         plan = gd.make_plan(g.D, g.INT8, n, n, n, N, fastmode=args.fast, device=dev)
 
         def step(record):
             ev = plan.run(A, B, Cmat, record_gemm_events=record)
             if record and ev is not None:
                 gemm_events.append(ev)
-        if isinstance(plan, gd.ColumnShardedGemm):
+        if isinstance(plan, gd.BlockShardedGemm):
+            parallelism = (f"output blocks sharded on a {plan.gr}x{plan.gc} rank grid (every rank runs all {N} moduli on its m/{plan.gr} x n/{plan.gc} "
+                           f"block; one all_reduce(MAX) of the row/column bounds over RCCL)")
+        elif isinstance(plan, gd.ColumnShardedGemm):
             parallelism = f"output columns sharded x{world} (every rank runs all {N} moduli on n/{world} columns; all_reduce(MAX) of the row bounds over RCCL)"
         else:
             parallelism = f"moduli-sharded x{world} (residue all-to-all over RCCL, column-block CRT)"
@@ -283,6 +287,8 @@ def main():
         ops = planes_here * 2.0 * n ** 3
         if world > 1 and isinstance(plan, gd.ColumnShardedGemm):
             ops = N * 2.0 * n * n * plan.ncols
+        if world > 1 and isinstance(plan, gd.BlockShardedGemm):
+            ops = N * 2.0 * plan.nrows * plan.ncols * n
         peak = 5000.0  # dense INT8 MFMA TOPS (MI355X_MICROARCH.md: ~5 PF-class dense FP8/INT8)
         roof = None
         if gemm_ms:

@@ -29,6 +29,21 @@ import torch.distributed as dist
 import gemmul8_amd as g
 
 
+def _ld(t):
+    """Leading dimension (elements between consecutive columns) of a column-major matrix held as a (cols, rows) tensor or as
+    a row-sliced view of one."""
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+
+
+def block_grid(world):
+    """(Gr, Gc) with Gr * Gc == world, Gr the largest divisor of world not above sqrt(world): 2 -> 1x2, 4 -> 2x2, 8 -> 2x4."""
+    gr = 1
+    for d in range(1, int(world ** 0.5) + 1):
+        if world % d == 0:
+            gr = d
+    return gr, world // gr
+
+
 def split_range(total, parts, idx):
     """Balanced contiguous split: the first (total % parts) pieces get one extra."""
     q, r = divmod(total, parts)
@@ -67,11 +82,11 @@ class HipEngine:
 
     def bounds(self, A, B, c0, c1):
         g.check(self.lib.gemmul8_scale_bounds(self._stream(), self.dt, self.be, self.opA, self.opB, self.m, self.n, self.k, A.data_ptr(),
-                                              A.shape[1], B.data_ptr(), B.shape[1], self.N, c0, c1, C.byref(self.L), 0, 0), "scale_bounds")
+                                              _ld(A), B.data_ptr(), _ld(B), self.N, c0, c1, C.byref(self.L), 0, 0), "scale_bounds")
 
     def finish(self, A, B, t0, t1):
         g.check(self.lib.gemmul8_scale_finish(self._stream(), self.dt, self.be, self.opA, self.opB, self.m, self.n, self.k, A.data_ptr(),
-                                              A.shape[1], B.data_ptr(), B.shape[1], self.N, self.fast, t0, t1, C.byref(self.L), 0, 0), "scale_finish")
+                                              _ld(A), B.data_ptr(), _ld(B), self.N, self.fast, t0, t1, C.byref(self.L), 0, 0), "scale_finish")
 
     def lowprec(self, t0, t1):
         g.check(self.lib.gemmul8_lowprec_gemm(self._stream(), self.dt, self.be, self.m, self.n, self.k, self.N, t0, t1, C.byref(self.L)), "lowprec_gemm")
@@ -90,7 +105,7 @@ class HipEngine:
     def crt_local(self, Cblk, alpha_ptr, beta_ptr):
         """CRT of the engine's own C_mid planes into the (n, ld) tensor Cblk (column sharding: the engine IS the block)."""
         sA, sB = self.sft_ptrs()
-        ldc = Cblk.shape[1]
+        ldc = _ld(Cblk)
         g.check(self.lib.gemmul8_crt(self._stream(), self.dt, self.be, self.N, self.m, self.n, self.L.C_mid, self.mp, self.L.sizeC, sA, sB,
                                      alpha_ptr, beta_ptr, Cblk.data_ptr(), ldc), "crt")
 
@@ -171,6 +186,103 @@ class ColumnShardedGemm:
         return ev
 
     gather_result = None  # bound below (same assembly as ShardedGemm)
+
+
+class BlockShardedGemm:
+    """C[rows_i, cols_j] = alpha*A[rows_i, :]*B[:, cols_j] + beta*C[rows_i, cols_j] on a Gr x Gc grid of ranks (op N/N).
+
+    Rank (i, j) runs the ordinary single-GPU phase calls on its (m/Gr, n/Gc, k) sub-problem: it reads only its row block
+    of A and its column block of B, so the replicated scaling work of the column plan (every rank quantising all of A)
+    drops by Gr, and the INT8 GEMM work is 1/G for any num_moduli.  The only coupling is the accurate mode's bound
+    maxima: a row's shift needs the row maximum over ALL columns and a column's over ALL rows, so every rank writes its
+    partial maxima into one zero-filled vector int32[M + N] (its rows, its columns) and ONE all_reduce(MAX) over all ranks
+    completes both; fast mode needs no collective.  Bit-identical to the single-GPU call for every grid."""
+
+    def __init__(self, dtype_code, backend, m, n, k, N, fastmode=False, device=None, group=None, engine=None, alpha=1.0, beta=0.0,
+                 grid=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.gr, self.gc = grid if grid is not None else block_grid(self.world)
+        assert self.gr * self.gc == self.world
+        self.m, self.n, self.k, self.N, self.fast = m, n, k, N, fastmode
+        self.ri, self.cj = divmod(self.rank, self.gc)
+        self.r0, self.r1 = split_range(m, self.gr, self.ri)
+        self.c0, self.c1 = split_range(n, self.gc, self.cj)
+        self.nrows, self.ncols = self.r1 - self.r0, self.c1 - self.c0
+        self.my_planes = N
+        self.device = device
+        empty = self.nrows == 0 or self.ncols == 0
+        self.eng = engine if engine is not None else (None if empty else HipEngine(dtype_code, backend, self.nrows, self.ncols, k, N, fastmode, device))
+        import numpy as np
+        np_dt = {g.S: np.float32, g.D: np.float64, g.Cx: np.complex64, g.Z: np.complex128}[dtype_code]
+        self._alpha = np.array([alpha], dtype=np_dt)
+        self._beta = np.array([beta], dtype=np_dt)
+        self._mx = None
+
+    def _blocks(self, A, B, Cmat):
+        Ablk = A[:, self.r0:self.r1] if A is not None else None      # (k, rows): column-major rows x k, ld = m
+        Bblk = B[self.c0:self.c1] if B is not None else None         # (cols, k): column-major k x cols
+        Cblk = Cmat[self.c0:self.c1, self.r0:self.r1]                # (cols, rows): column-major rows x cols, ld = m
+        return Ablk, Bblk, Cblk
+
+    def run(self, A, B, Cmat, record_gemm_events=False):
+        eng = self.eng
+        Ablk, Bblk, Cblk = self._blocks(A, B, Cmat)
+        if not self.fast:
+            if self.world > 1:
+                dev = Cmat.device
+                if self._mx is None:
+                    self._mx = torch.zeros(self.m + self.n, dtype=torch.int32, device=dev)
+                mx = self._mx
+                mx.zero_()
+            if eng is not None:
+                eng.bounds(Ablk, Bblk, 0, self.ncols)
+                loc = eng.maxima()
+            if self.world > 1:
+                if eng is not None:
+                    mx[self.r0:self.r1].copy_(loc[:self.nrows])
+                    mx[self.m + self.c0:self.m + self.c1].copy_(loc[eng.mp:eng.mp + self.ncols])
+                stage = mx.is_cuda and dist.get_backend(self.group) == "gloo"  # single-GPU multi-rank smoke test only
+                if stage:
+                    host = mx.cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
+                    mx.copy_(host)
+                else:
+                    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
+                if eng is not None:
+                    loc[:self.nrows].copy_(mx[self.r0:self.r1])
+                    loc[eng.mp:eng.mp + self.ncols].copy_(mx[self.m + self.c0:self.m + self.c1])
+        if eng is None:
+            return None
+        eng.finish(Ablk, Bblk, 0, self.N)
+        ev = None
+        if record_gemm_events and torch.cuda.is_available() and Cmat.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            eng.lowprec(0, self.N)
+            e1.record()
+            ev = (e0, e1)
+        else:
+            eng.lowprec(0, self.N)
+        eng.crt_local(Cblk, self._alpha.ctypes.data, self._beta.ctypes.data)
+        return ev
+
+    def gather_result(self, Cmat):
+        """All ranks: assemble the full C from the blocks (verification / callers that need it)."""
+        if self.world == 1:
+            return Cmat
+        out = Cmat.clone()
+        for s in range(self.world):
+            si, sj = divmod(s, self.gc)
+            r0, r1 = split_range(self.m, self.gr, si)
+            c0, c1 = split_range(self.n, self.gc, sj)
+            if r1 > r0 and c1 > c0:
+                blk = Cmat[c0:c1, r0:r1].contiguous()
+                src = s if self.group is None else dist.get_global_rank(self.group, s)
+                dist.broadcast(blk, src=src, group=self.group)
+                out[c0:c1, r0:r1] = blk
+        return out
 
 
 class ShardedGemm:
@@ -301,8 +413,8 @@ ColumnShardedGemm.gather_result = ShardedGemm.gather_result
 
 
 def make_plan(dtype_code, backend, m, n, k, N, **kw):
-    """The multi-GPU plan bench.py and callers use: GEMMUL8_DIST_SHARD=columns (default) | moduli."""
+    """The multi-GPU plan bench.py and callers use: GEMMUL8_DIST_SHARD=blocks (default) | columns | moduli."""
     import os
-    mode = os.environ.get("GEMMUL8_DIST_SHARD", "columns")
-    cls = {"columns": ColumnShardedGemm, "moduli": ShardedGemm}[mode]
+    mode = os.environ.get("GEMMUL8_DIST_SHARD", "blocks")
+    cls = {"blocks": BlockShardedGemm, "columns": ColumnShardedGemm, "moduli": ShardedGemm}[mode]
     return cls(dtype_code, backend, m, n, k, N, **kw)

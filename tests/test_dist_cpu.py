@@ -90,9 +90,9 @@ class OracleEngine:
 
 def _oracle_crt_local(self, Cblk, alpha_ptr, beta_ptr):
     mid = self.C_mid.reshape(-1)
-    blk = Cblk.numpy()
+    ldc = Cblk.stride(0) if Cblk.shape[0] > 1 else max(Cblk.shape[1], Cblk.stride(0))   # column-major block inside a larger C
     self.lib.oz2_invscal(self.dt, 0, self.N, self.m, self.n, mid.ctypes.data, ol._p(self.sftA), ol._p(self.sftB), alpha_ptr, beta_ptr,
-                         blk.ctypes.data, self.m, 0)
+                         C.c_void_p(Cblk.data_ptr()), ldc, 0)
 
 
 OracleEngine.crt_local = _oracle_crt_local
@@ -156,6 +156,53 @@ def _worker_cols(rank, world, port, N, fast, m, n, k, q):
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def _worker_blocks(rank, world, port, N, fast, m, n, k, q, grid):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gemmul8_amd as g
+        from gemmul8_amd import dist as gd
+        rng = np.random.default_rng(44)
+        A = (rng.random((m, k)) - 0.5) * np.exp(rng.standard_normal((m, k)))
+        B = (rng.random((k, n)) - 0.5) * np.exp(rng.standard_normal((k, n)))
+        C0 = rng.standard_normal((m, n))
+        gr, gc = grid if grid else gd.block_grid(world)
+        ri, cj = divmod(rank, gc)
+        r0, r1 = gd.split_range(m, gr, ri)
+        c0, c1 = gd.split_range(n, gc, cj)
+        eng = OracleEngine(A[r0:r1], B[:, c0:c1], N, fast) if (r1 > r0 and c1 > c0) else None
+        plan = gd.BlockShardedGemm(g.D, g.INT8, m, n, k, N, fastmode=fast, engine=eng, alpha=-1.5, beta=1.5, grid=grid)
+        assert (plan.r0, plan.r1, plan.c0, plan.c1) == (r0, r1, c0, c1)
+        Cmat = torch.from_numpy(np.ascontiguousarray(C0.T))
+        plan.run(None, None, Cmat)
+        full = plan.gather_result(Cmat)
+        if rank == 0:
+            ref = ol.gemm(A, B, N, fastmode=fast, alpha=-1.5, beta=1.5, C0=C0)
+            q.put(np.ascontiguousarray(full.numpy().T).tobytes() == np.ascontiguousarray(ref).tobytes())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,grid", [(2, None), (4, None), (4, (4, 1)), (3, None), (6, None)])
+@pytest.mark.parametrize("N,fast,m,n", [(14, False, 19, 11), (9, True, 19, 11), (5, False, 3, 2)])
+def test_block_sharded_gemm_matches_single_process(world, grid, N, fast, m, n):
+    """Rows x columns block sharding (the default plan): one all_reduce(MAX) over the combined row/column bound vector;
+    m = 3, n = 2 leaves ranks without a block that still have to take part in the collective."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    k = 37
+    procs = [ctx.Process(target=_worker_blocks, args=(r, world, port, N, fast, m, n, k, q, grid)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    assert q.get(timeout=10), "block-sharded result differs from the single-process oracle"
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _worker(rank, world, port, N, fast, m, n, k, q, exchange="p2p"):
-    os.environ["GEMMUL8_DIST_EXCHANGE"] = exchange if exchange != "columns" else "p2p"
-    os.environ["GEMMUL8_DIST_SHARD"] = "columns" if exchange == "columns" else "moduli"
+    os.environ["GEMMUL8_DIST_EXCHANGE"] = exchange if exchange in ("p2p", "a2a") else "p2p"
+    os.environ["GEMMUL8_DIST_SHARD"] = {"columns": "columns", "blocks": "blocks", "blocks_rows": "blocks"}.get(exchange, "moduli")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -27,7 +27,10 @@ def _worker(rank, world, port, N, fast, m, n, k, q, exchange="p2p"):
         A = torch.from_numpy(rng.random((k, m)) - 0.5).cuda()  # (cols, rows) = column-major m x k
         B = torch.from_numpy(rng.random((n, k)) - 0.5).cuda()
         Cm = torch.zeros((n, m), dtype=torch.float64, device="cuda")
-        plan = gd.make_plan(g.D, g.INT8, m, n, k, N, fastmode=fast, device=torch.device("cuda", 0))
+        if exchange == "blocks_rows":   # 2 x 1 grid: strided row-block views of A and C
+            plan = gd.BlockShardedGemm(g.D, g.INT8, m, n, k, N, fastmode=fast, device=torch.device("cuda", 0), grid=(2, 1))
+        else:
+            plan = gd.make_plan(g.D, g.INT8, m, n, k, N, fastmode=fast, device=torch.device("cuda", 0))
         plan.run(A, B, Cm)
         torch.cuda.synchronize()
         full = plan.gather_result(Cm)
@@ -40,7 +43,7 @@ def _worker(rank, world, port, N, fast, m, n, k, q, exchange="p2p"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["p2p", "a2a", "columns"])
+@pytest.mark.parametrize("exchange", ["p2p", "a2a", "columns", "blocks", "blocks_rows"])
 @pytest.mark.parametrize("N,fast", [(14, False), (15, True)])
 def test_two_ranks_one_gpu_bitwise(N, fast, exchange):
     ctx = mp.get_context("spawn")
