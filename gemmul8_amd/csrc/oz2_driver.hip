@@ -158,9 +158,14 @@ int gemmul8_scale_bounds(void* stream_, int dtype, int backend, int op_A, int op
     if (rc) return rc;
     const size_t np = padding256(n);
     const size_t bstrideA = cplx ? L->sizeA : 0, bstrideB = cplx ? L->sizeB : 0;
-    if (!skipA) OZ2_HIP(launch_extract(stream, dtype, backend, kmajA, conjA, m, k, A, lda, (int8_t*)L->A_bound, bstrideA, L->kp, L->sftA, amax));
-    if (!skipB) OZ2_HIP(launch_extract(stream, dtype, backend, kmajB, conjB, n, k, B, ldb, (int8_t*)L->B_bound, bstrideB, L->kp, L->sftB, amax));
-    OZ2_HIP(hipMemsetAsync(rowmax, 0, 4 * (L->mp + np), stream));
+    // one memset for the maxima arrays AND the amax scratch of the first row-strided extract (they are adjacent)
+    OZ2_HIP(hipMemsetAsync(rowmax, 0, 4 * (L->mp + np) + 8 * std::max(L->mp, np), stream));
+    bool amax_zero = true;
+    if (!skipA) {
+        OZ2_HIP(launch_extract(stream, dtype, backend, kmajA, conjA, m, k, A, lda, (int8_t*)L->A_bound, bstrideA, L->kp, L->sftA, amax, amax_zero));
+        if (!kmajA) amax_zero = false;
+    }
+    if (!skipB) OZ2_HIP(launch_extract(stream, dtype, backend, kmajB, conjB, n, k, B, ldb, (int8_t*)L->B_bound, bstrideB, L->kp, L->sftB, amax, amax_zero));
     if (col_end > col_begin) {
         const int8_t* Ab = (const int8_t*)L->A_bound;
         const int8_t* Bb = (const int8_t*)L->B_bound + col_begin * L->kp;
@@ -218,8 +223,7 @@ int gemmul8_scale_finish(void* stream_, int dtype, int backend, int op_A, int op
         void* amax;
         int rc = scale_scratch(L, n, &rowmax, &colmax, &amax);
         if (rc) return rc;
-        if (!skipA) OZ2_HIP(launch_shift_finalize(stream, backend, N, m, rowmax, L->sftA));
-        if (!skipB) OZ2_HIP(launch_shift_finalize(stream, backend, N, n, colmax, L->sftB));
+        OZ2_HIP(launch_shift_finalize(stream, backend, N, skipA ? 0 : m, rowmax, L->sftA, skipB ? 0 : n, colmax, L->sftB));
     }
     if (!skipA)
         OZ2_HIP(launch_quantise(stream, dtype, backend, N, (int)t_begin, (int)t_end, kmajA, conjA, m, k, A, lda, L->sftA, (int8_t*)L->A_lo,

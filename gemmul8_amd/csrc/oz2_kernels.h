@@ -43,8 +43,9 @@ hipError_t launch_gemm_f8_bound_cplx(hipStream_t stream, int stage, const int8_t
 // length k; K-major: element (r,kk) at X[r*ld+kk]; row-strided: X[kk*ld+r].  lo planes are
 // [rows_pad][kp] int8, zero-filled for kk in [k,kp).
 hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajor, bool conj, size_t rows, size_t k, const void* X,
-                          size_t ld, int8_t* lo, size_t part_stride, size_t kp, int16_t* sft0, void* scratch_amax);
-hipError_t launch_shift_finalize(hipStream_t stream, int backend, unsigned N, size_t rows, const int* maxv, int16_t* sft);
+                          size_t ld, int8_t* lo, size_t part_stride, size_t kp, int16_t* sft0, void* scratch_amax, bool amax_is_zero = false);
+hipError_t launch_shift_finalize(hipStream_t stream, int backend, unsigned N, size_t rowsA, const int* maxA, int16_t* sftA, size_t rowsB,
+                                 const int* maxB, int16_t* sftB);
 hipError_t launch_fast_shift(hipStream_t stream, int dtype, int backend, unsigned N, bool kmajor, size_t rows, size_t k, const void* X,
                              size_t ld, int16_t* sft);
 hipError_t launch_quantise(hipStream_t stream, int dtype, int backend, unsigned N, int t_begin, int t_end, bool kmajor, bool conj,

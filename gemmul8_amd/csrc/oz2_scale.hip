@@ -462,7 +462,7 @@ template <int MODE> static hipError_t dispatch_stage(hipStream_t stream, int dty
 }
 
 hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajor, bool conj, size_t rows, size_t k, const void* X,
-                          size_t ld, int8_t* lo, size_t part_stride, size_t kp, int16_t* sft0, void* scratch_amax) {
+                          size_t ld, int8_t* lo, size_t part_stride, size_t kp, int16_t* sft0, void* scratch_amax, bool amax_is_zero) {
     if (rows == 0) return hipSuccess;
     StageArgs a{};
     a.X = X;
@@ -478,7 +478,7 @@ hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajo
     a.conj = conj;
     if (!kmajor) {
         const size_t ub = is_f32(dtype) ? 4 : 8;
-        hipError_t e = hipMemsetAsync(scratch_amax, 0, ub * rows, stream);
+        hipError_t e = amax_is_zero ? hipSuccess : hipMemsetAsync(scratch_amax, 0, ub * rows, stream);
         if (e != hipSuccess) return e;
         // enough workgroups to fill the chip at every size (~2048), at least 16 k values per workgroup: the per-thread chain of
         // dependent strided loads, not bandwidth, bounds this kernel when the grid is small (42 us at 1024^2 with k/512 splits)
@@ -529,21 +529,28 @@ hipError_t launch_quantise(hipStream_t stream, int dtype, int backend, unsigned 
 }
 
 // ------------------------------------------------------------------ accurate-mode shift from the bound maxima
-__global__ void shift_finalize_kernel(size_t rows, const int* maxv, int16_t* sft, float log2P, int float_max) {
-    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    const int amax = maxv[r];  // INT8: int32 maximum; FP8: bit pattern of a non-negative float
+// rows of A (blocks 0 .. blocksA-1) and columns of B (the remaining blocks) in ONE launch; either count may be 0
+__global__ void shift_finalize_kernel(size_t rowsA, const int* maxA, int16_t* sftA, unsigned blocksA, size_t rowsB, const int* maxB,
+                                      int16_t* sftB, float log2P, int float_max) {
+    const bool isB = blockIdx.x >= blocksA;
+    const size_t r = (size_t)(isB ? blockIdx.x - blocksA : blockIdx.x) * blockDim.x + threadIdx.x;
+    if (r >= (isB ? rowsB : rowsA)) return;
+    const int amax = (isB ? maxB : maxA)[r];  // INT8: int32 maximum; FP8: bit pattern of a non-negative float
     int f = 0;  // all-zero row/column: the reference is undefined here (log2(0)); any shift is valid
     if (amax > 0) {
         const float l = __log2f(float_max ? __int_as_float(amax) : __int2float_rn(amax));
         f = __float2int_rd(__fmaf_rd(-0x1.000006p-1f, l, log2P));
     }
+    int16_t* sft = isB ? sftB : sftA;
     sft[r] = (int16_t)(-((int)sft[r] + f));
 }
-hipError_t launch_shift_finalize(hipStream_t stream, int backend, unsigned N, size_t rows, const int* maxv, int16_t* sft) {
-    if (rows == 0) return hipSuccess;
+hipError_t launch_shift_finalize(hipStream_t stream, int backend, unsigned N, size_t rowsA, const int* maxA, int16_t* sftA, size_t rowsB,
+                                 const int* maxB, int16_t* sftB) {
+    const unsigned bA = (unsigned)((rowsA + 255) / 256), bB = (unsigned)((rowsB + 255) / 256);
+    if (bA + bB == 0) return hipSuccess;
     const float log2P = backend == kINT8 ? GEMMUL8_LOG2P_INT8[N - 2] : GEMMUL8_LOG2P_FP8[N - 2];
-    hipLaunchKernelGGL(shift_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, rows, maxv, sft, log2P, backend == kFP8 ? 1 : 0);
+    hipLaunchKernelGGL(shift_finalize_kernel, dim3(bA + bB), dim3(256), 0, stream, rowsA, maxA, sftA, bA, rowsB, maxB, sftB, log2P,
+                       backend == kFP8 ? 1 : 0);
     return hipGetLastError();
 }
 
