@@ -295,7 +295,10 @@ def main():
             ach = ops / (gemm_ms * 1e-3) * 1e-12
             roof = {"bound": "mfma", "kernel": "oz2::gemm_i8_kernel<EPI_MOD> (batched over moduli)", "achieved": ach, "peak": peak,
                     "unit": "TOP/s", "frac": ach / peak, "traffic": None, "launch_ms": gemm_ms, "ops_per_launch": ops,
-                    "algorithmic_bytes_per_launch": planes_here * 3.0 * n * n if world == 1 else None}
+                    "algorithmic_bytes_per_launch": planes_here * 3.0 * n * n if world == 1 else None,
+                    # measured with tools/ubench/mfma_peak.hip (profiles/r01_mfma_power_ceiling.txt): a register-only MFMA loop
+                    # reaches the nominal peak on all-zero operands but is power-limited to this on random INT8 data
+                    "sustained_mfma_on_random_data_TOPs": 3426.0}
             # HBM-side bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
             # WRITE_SIZE, tools/pmc_traffic.py); only valid for the configuration that was profiled
             tf = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
