@@ -321,6 +321,19 @@ def main():
             nat, Cn = native_fp64(A, B)
             nat["max_rel_err"] = sampled_error(A, B, Cn, n)
             out["native_fp64_dgemm_same_gpu"] = nat
+            del Cn
+            # the other mode alongside (report both; the headline above is the mode selected by --fast)
+            other = not args.fast
+            for _ in range(2):
+                g.gemm(A, B, N, fastmode=other, C_out=Cmat, work=work)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                g.gemm(A, B, N, fastmode=other, C_out=Cmat, work=work)
+            torch.cuda.synchronize()
+            oms = (time.perf_counter() - t1) / 5 * 1e3
+            out["other_mode"] = {"mode": "fast" if other else "accurate", "value": flops / oms * 1e-9, "unit": "TFLOPS", "ms_per_step": oms,
+                                 "max_rel_err": sampled_error(A, B, Cmat, n)}
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline_port(N, args.fast)
             out["host_blas_dgemm"] = host_blas(n)
