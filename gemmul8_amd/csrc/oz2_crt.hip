@@ -9,7 +9,7 @@
 //   C  = AB | C+AB | -AB | C-AB  for host scalars alpha=+-1, beta in {0,1};
 //        otherwise fma(beta, C, alpha*AB) (complex: nested fma order of template_math.hpp:61-75);
 //   device-pointer scalars always take the general form (inverse_scaling_real.hpp:211-216).
-// Each thread handles ROWS (8 real / 4 complex) consecutive rows of one column: one vector load per residue plane, all
+// Each thread handles ROWS consecutive rows of one column (8 bytes of every residue plane: 8 / 4 / 4 / 2 rows): one vector load per residue plane, all
 // N loads issued before the first use (the plane loop is fully unrolled over the 20-moduli maximum with a uniform guard).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -54,7 +54,7 @@ __device__ __forceinline__ double crt_reduce(const CrtArgs& a, double Sh, double
 template <typename U, bool CPLX, typename MID>
 __global__ void __launch_bounds__(256) crt_kernel(const CrtArgs a) {
     constexpr int COMPS = CPLX ? 2 : 1;
-    constexpr int ROWS = CPLX ? 4 : 8;
+    constexpr int ROWS = 8 / (COMPS * (int)sizeof(MID));  // 8-byte residue vectors: 8 / 4 / 4 / 2 rows; wider ones cost occupancy
     constexpr int NV = ROWS * COMPS;  // values per thread and plane
     const unsigned row_groups = (unsigned)((a.m + ROWS - 1) / ROWS);
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -191,7 +191,7 @@ hipError_t launch_crt(hipStream_t stream, int dtype, int backend, unsigned N, si
             else if (ar == -1 && br == 1) a.mode = 4;
         }
     }
-    const size_t rows_per_thread = cplx ? 4 : 8;
+    const size_t rows_per_thread = 8 / ((cplx ? 2 : 1) * (i8 ? 1 : 2));
     const size_t threads = ((m + rows_per_thread - 1) / rows_per_thread) * n;
     dim3 grid((unsigned)((threads + 255) / 256));
 #define OZ2_CRT(U, CP, MID) hipLaunchKernelGGL((crt_kernel<U, CP, MID>), grid, dim3(256), 0, stream, a)

@@ -21,7 +21,9 @@ struct ModConst {
     int c18;      // sym(2^18 mod p)
     int c36;      // sym(2^36 mod p)
     float invp;   // RN(1/p)
-    unsigned cb[4];  // INT8 moduli: cb[i] = bytes (256^(4i), .., 256^(4i+3)) mod p, each in [0, p); byte 15 is 0
+    unsigned cb[4];  // cb[i] = bytes (c_{4i}, .., c_{4i+3}), c_j = 256^j mod p in [0, p) for the INT8 moduli (p <= 256), the LOW 5
+                     // bits of it for the FP8 moduli (p <= 1089); byte 15 is 0
+    unsigned cbh[4]; // FP8 moduli: the high part c_j >> 5 (< 35); 0 for INT8
     unsigned k56;    //              (-2^56) mod p in [0, p): correction for the 56-bit two's complement of a negative value
     unsigned k120;   //              (-2^120) mod p: the same for the 120-bit form used when E > 0
 };
@@ -131,29 +133,44 @@ __device__ __forceinline__ Bytes128 shifted_bytes(uint64_t M, int E, bool neg) {
     }
     return Bytes128{{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)}};
 }
-__device__ __forceinline__ int residue_sym_bytes128(const Bytes128& x, bool neg, const ModConst& mc) {
+// WIDE = false: INT8 moduli.  WIDE = true: FP8 moduli (up to 1089): the constants 256^j mod p do not fit a byte, so they are
+// split c = 32 c_hi + c_lo and the sum is s = sum b c_lo + 32 sum b c_hi < 2^23 (120-bit form; < 2^21 for 56 bits) -- still
+// exact in fp32, and s * |RN(1/p) - 1/p| <= 2^23 * 2^-24 / p < 1/(2p) keeps the single fma quotient exact for odd p.
+// p = 1024 is even: the tie -512 is moved to the reference's representative +512 ((-p/2, p/2], mod.hpp:8-12).
+template <bool WIDE> __device__ __forceinline__ int finish_residue(unsigned s, const ModConst& mc) {
+    const float qf = fmaf((float)s, mc.invp, 8388608.0f);
+    // pinned to the full-rate 24-bit multiply-add: left to itself the compiler sees that only the low bits of the result
+    // are stored and picks the quarter-rate v_mul_lo_u32 / v_mad_u64_u32
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(__float_as_int(qf)), "s"(-mc.p), "v"(s));
+    if constexpr (WIDE) {
+        if (!(mc.p & 1)) r = (r == -(mc.p >> 1)) ? (mc.p >> 1) : r;
+    }
+    return r;
+}
+template <bool WIDE> __device__ __forceinline__ int residue_sym_bytes128(const Bytes128& x, bool neg, const ModConst& mc) {
     unsigned s = __builtin_amdgcn_udot4(x.w[3], mc.cb[3], neg ? mc.k120 : 0u, false);
     s = __builtin_amdgcn_udot4(x.w[2], mc.cb[2], s, false);
     s = __builtin_amdgcn_udot4(x.w[1], mc.cb[1], s, false);
     s = __builtin_amdgcn_udot4(x.w[0], mc.cb[0], s, false);
-    const float qf = fmaf((float)s, mc.invp, 8388608.0f);
-    int r;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(__float_as_int(qf)), "s"(-mc.p), "v"(s));
-    return r;
+    if constexpr (WIDE) {
+        unsigned h = __builtin_amdgcn_udot4(x.w[3], mc.cbh[3], 0u, false);
+        h = __builtin_amdgcn_udot4(x.w[2], mc.cbh[2], h, false);
+        h = __builtin_amdgcn_udot4(x.w[1], mc.cbh[1], h, false);
+        h = __builtin_amdgcn_udot4(x.w[0], mc.cbh[0], h, false);
+        s += h << 5;
+    }
+    return finish_residue<WIDE>(s, mc);
 }
 
-// The common case, E = 0 (always true for num_moduli <= 15): Mt is M, or the 56-bit
-// two's complement 2^56 - M of a negative value, whose byte sum plus k56 = (-2^56 mod p) is congruent to -M.  The quotient
-// comes from ONE fma: float(s)/p + 2^23 rounds to the integer 2^23 + q (RN-even at unit spacing), whose low 24 bits are q,
-// exactly what v_mul_i32_i24 reads.  6 VALU operations: v_cndmask, 2 x v_dot4_u32_u8, v_cvt_f32_u32, v_fma_f32, v_mad_i32_i24.
-__device__ __forceinline__ int residue_sym_bytes_e0(unsigned Mt_lo, unsigned Mt_hi, bool neg, const ModConst& mc) {
-    const unsigned s = __builtin_amdgcn_udot4(Mt_lo, mc.cb[0], __builtin_amdgcn_udot4(Mt_hi, mc.cb[1], neg ? mc.k56 : 0u, false), false);
-    const float qf = fmaf((float)s, mc.invp, 8388608.0f);
-    // pinned to the full-rate 24-bit multiply-add: left to itself the compiler sees that only the low byte of the result is
-    // stored and picks the quarter-rate v_mul_lo_u32 / v_mad_u64_u32
-    int r;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(__float_as_int(qf)), "s"(-mc.p), "v"(s));
-    return r;
+// The common case, E = 0 (always true for num_moduli <= 15): Mt is M, or the 56-bit two's complement 2^56 - M of a negative
+// value, whose byte sum plus k56 = (-2^56 mod p) is congruent to -M.  The quotient comes from ONE fma: float(s)/p + 2^23
+// rounds to the integer 2^23 + q (RN-even at unit spacing), whose low 24 bits are q, exactly what v_mad_i32_i24 reads.
+// INT8 moduli: 6 VALU operations (v_cndmask, 2 x v_dot4_u32_u8, v_cvt_f32_u32, v_fma_f32, v_mad_i32_i24).
+template <bool WIDE> __device__ __forceinline__ int residue_sym_bytes_e0(unsigned Mt_lo, unsigned Mt_hi, bool neg, const ModConst& mc) {
+    unsigned s = __builtin_amdgcn_udot4(Mt_lo, mc.cb[0], __builtin_amdgcn_udot4(Mt_hi, mc.cb[1], neg ? mc.k56 : 0u, false), false);
+    if constexpr (WIDE) s += __builtin_amdgcn_udot4(Mt_lo, mc.cbh[0], __builtin_amdgcn_udot4(Mt_hi, mc.cbh[1], 0u, false), false) << 5;
+    return finish_residue<WIDE>(s, mc);
 }
 
 // wrapping (mod.hpp:8-12)

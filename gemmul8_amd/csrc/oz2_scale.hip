@@ -41,8 +41,16 @@ ModTable make_mod_table(int backend) {
             c[i] = i < 15 ? (unsigned)(pw % p) : 0u;
             pw = (pw % p) * 256;
         }
-        for (int i = 0; i < 4; ++i)
-            T.mc[t].cb[i] = backend == kINT8 ? (c[4 * i] | (c[4 * i + 1] << 8) | (c[4 * i + 2] << 16) | (c[4 * i + 3] << 24)) : 0u;
+        for (int i = 0; i < 4; ++i) {
+            unsigned lo = 0, hi = 0;
+            for (int j = 0; j < 4; ++j) {
+                const unsigned cj = c[4 * i + j];
+                lo |= (backend == kINT8 ? cj : (cj & 31u)) << (8 * j);
+                hi |= (backend == kINT8 ? 0u : (cj >> 5)) << (8 * j);
+            }
+            T.mc[t].cb[i] = lo;
+            T.mc[t].cbh[i] = hi;
+        }
         auto pow2 = [p](int e) {  // 2^e mod p
             long long r = 1;
             for (int i = 0; i < e; ++i) r = (r * 2) % p;
@@ -195,55 +203,6 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
                 ni[e] = (a.conj && y.M != 0) ? !y.neg : y.neg;  // a zero stays +0 (two's-complement residue path)
             }
         }
-        const short(*pow2)[64] = c_pow2mod_fp8;  // FP8 branch only
-        if (a.backend == kFP8) {
-            // residues up to +-544 are split into 2-3 e4m3 planes of integers <= 16 (mod.hpp:159-189, 361-410); complex:
-            // the residues of Re, Im and wrapping(Re + Im) go to the three parts
-            auto put = [&](int8_t* o, int t, const int (&rr)[4]) {
-                if (t < 6) {
-                    const int sq = a.sqrtp[t];
-                    const float inv = 1.0f / (float)sq;
-                    float hi[4], lo[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) fp8_split_sq(rr[e], sq, inv, hi[e], lo[e]);
-                    *(unsigned*)o = fp8x2_from_floats(hi[0], hi[1]) | (fp8x2_from_floats(hi[2], hi[3]) << 16);
-                    *(unsigned*)(o + a.plane_stride) = fp8x2_from_floats(lo[0], lo[1]) | (fp8x2_from_floats(lo[2], lo[3]) << 16);
-                } else {
-                    int hi[4], lo[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) fp8_split_kara(rr[e], hi[e], lo[e]);
-                    *(unsigned*)o = fp8x2_from_ints(hi[0], hi[1]) | (fp8x2_from_ints(hi[2], hi[3]) << 16);
-                    *(unsigned*)(o + a.plane_stride) = fp8x2_from_ints(lo[0], lo[1]) | (fp8x2_from_ints(lo[2], lo[3]) << 16);
-                    *(unsigned*)(o + 2 * a.plane_stride) =
-                        fp8x2_from_ints(hi[0] + lo[0], hi[1] + lo[1]) | (fp8x2_from_ints(hi[2] + lo[2], hi[3] + lo[3]) << 16);
-                }
-            };
-            Limbs Lr[4], Li[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                Lr[e] = make_limbs(Mr[e]);
-                if constexpr (E::cplx) Li[e] = make_limbs(Mi[e]);
-            }
-            for (int t = a.t_begin; t < a.t_end; ++t) {
-                const ModConst mc = a.mt.mc[t];
-                int rr[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rr[e] = residue_sym(Lr[e], Er[e], nr[e], mc, pow2[t]);
-                int8_t* o = out + (size_t)(t < 6 ? 2 * t : 12 + 3 * (t - 6)) * a.plane_stride;
-                put(o, t, rr);
-                if constexpr (E::cplx) {
-                    int ri[4], rs[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        ri[e] = residue_sym(Li[e], Ei[e], ni[e], mc, pow2[t]);
-                        rs[e] = wrapping(rr[e] + ri[e], mc.p);
-                    }
-                    put(o + a.part_stride, t, ri);
-                    put(o + 2 * a.part_stride, t, rs);
-                }
-            }
-            return;
-        }
         // E > 0 (|x|*2^s >= 2^53) cannot happen for num_moduli <= 15; one wave-uniform test keeps it out of the common path
         bool anyE = false;
 #pragma unroll
@@ -251,67 +210,83 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
             anyE |= Er[e] > 0;
             if constexpr (E::cplx) anyE |= Ei[e] > 0;
         }
-        if (!__any(anyE)) {
-            unsigned rlo[4], rhi[4], ilo[4], ihi[4];
+        const bool fastE = !__any(anyE);
+        unsigned rlo[4], rhi[4], ilo[4], ihi[4];  // fastE: M or its 56-bit two's complement
+        Bytes128 Xr[4], Xi[4];                    // otherwise: M*2^E or its 120-bit two's complement
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 4; ++e) {
+            if (fastE) {
                 const uint64_t mt = nr[e] ? (1ull << 56) - Mr[e] : Mr[e];
                 rlo[e] = (unsigned)mt, rhi[e] = (unsigned)(mt >> 32);
                 if constexpr (E::cplx) {
                     const uint64_t it = ni[e] ? (1ull << 56) - Mi[e] : Mi[e];
                     ilo[e] = (unsigned)it, ihi[e] = (unsigned)(it >> 32);
                 }
+            } else {
+                Xr[e] = shifted_bytes(Mr[e], Er[e], nr[e]);
+                if constexpr (E::cplx) Xi[e] = shifted_bytes(Mi[e], Ei[e], ni[e]);
             }
+        }
+        // FP8: residues up to +-544 are split into 2-3 e4m3 planes of integers <= 16 (mod.hpp:159-189, 361-410)
+        auto put_fp8 = [&](int8_t* o, int t, const int (&rr)[4]) {
+            if (t < 6) {
+                const int sq = a.sqrtp[t];
+                const float inv = 1.0f / (float)sq;
+                float hi[4], lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fp8_split_sq(rr[e], sq, inv, hi[e], lo[e]);
+                *(unsigned*)o = fp8x2_from_floats(hi[0], hi[1]) | (fp8x2_from_floats(hi[2], hi[3]) << 16);
+                *(unsigned*)(o + a.plane_stride) = fp8x2_from_floats(lo[0], lo[1]) | (fp8x2_from_floats(lo[2], lo[3]) << 16);
+            } else {
+                int hi[4], lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fp8_split_kara(rr[e], hi[e], lo[e]);
+                *(unsigned*)o = fp8x2_from_ints(hi[0], hi[1]) | (fp8x2_from_ints(hi[2], hi[3]) << 16);
+                *(unsigned*)(o + a.plane_stride) = fp8x2_from_ints(lo[0], lo[1]) | (fp8x2_from_ints(lo[2], lo[3]) << 16);
+                *(unsigned*)(o + 2 * a.plane_stride) =
+                    fp8x2_from_ints(hi[0] + lo[0], hi[1] + lo[1]) | (fp8x2_from_ints(hi[2] + lo[2], hi[3] + lo[3]) << 16);
+            }
+        };
+        // one pass over the moduli; FAST / WIDE are compile-time so the residue code is branch-free.  Complex: the residues of
+        // Re, Im and wrapping(Re + Im) go to the three parts (INT8: the sum of the int8-cast values, mod.hpp:321-325).
+        auto planes = [&]<bool FAST, bool WIDE>() {
             for (int t = a.t_begin; t < a.t_end; ++t) {
                 const ModConst mc = a.mt.mc[t];
-                unsigned wr = 0, wi = 0, ws = 0;
+                int rr[4], ri[4], rs[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int rr = residue_sym_bytes_e0(rlo[e], rhi[e], nr[e], mc);
-                    wr |= ((unsigned)rr & 0xFFu) << (8 * e);
+                    rr[e] = FAST ? residue_sym_bytes_e0<WIDE>(rlo[e], rhi[e], nr[e], mc) : residue_sym_bytes128<WIDE>(Xr[e], nr[e], mc);
                     if constexpr (E::cplx) {
-                        const int ri = residue_sym_bytes_e0(ilo[e], ihi[e], ni[e], mc);
-                        wi |= ((unsigned)ri & 0xFFu) << (8 * e);
-                        const int rs = wrapping((int)(int8_t)rr + (int)(int8_t)ri, mc.p);
-                        ws |= ((unsigned)rs & 0xFFu) << (8 * e);
+                        ri[e] = FAST ? residue_sym_bytes_e0<WIDE>(ilo[e], ihi[e], ni[e], mc) : residue_sym_bytes128<WIDE>(Xi[e], ni[e], mc);
+                        rs[e] = WIDE ? wrapping(rr[e] + ri[e], mc.p) : wrapping((int)(int8_t)rr[e] + (int)(int8_t)ri[e], mc.p);
                     }
                 }
-                int8_t* o = out + (size_t)t * a.plane_stride;
-                *(unsigned*)o = wr;
-                if constexpr (E::cplx) {
-                    *(unsigned*)(o + a.part_stride) = wi;
-                    *(unsigned*)(o + 2 * a.part_stride) = ws;
+                if constexpr (WIDE) {
+                    int8_t* o = out + (size_t)(t < 6 ? 2 * t : 12 + 3 * (t - 6)) * a.plane_stride;
+                    put_fp8(o, t, rr);
+                    if constexpr (E::cplx) {
+                        put_fp8(o + a.part_stride, t, ri);
+                        put_fp8(o + 2 * a.part_stride, t, rs);
+                    }
+                } else {
+                    auto pack = [](const int (&r)[4]) {
+                        return ((unsigned)r[0] & 0xFFu) | (((unsigned)r[1] & 0xFFu) << 8) | (((unsigned)r[2] & 0xFFu) << 16) | ((unsigned)r[3] << 24);
+                    };
+                    int8_t* o = out + (size_t)t * a.plane_stride;
+                    *(unsigned*)o = pack(rr);
+                    if constexpr (E::cplx) {
+                        *(unsigned*)(o + a.part_stride) = pack(ri);
+                        *(unsigned*)(o + 2 * a.part_stride) = pack(rs);
+                    }
                 }
             }
-            return;
-        }
-        Bytes128 Xr[4], Xi[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            Xr[e] = shifted_bytes(Mr[e], Er[e], nr[e]);
-            if constexpr (E::cplx) Xi[e] = shifted_bytes(Mi[e], Ei[e], ni[e]);
-        }
-        for (int t = a.t_begin; t < a.t_end; ++t) {
-            const ModConst mc = a.mt.mc[t];
-            unsigned wr = 0, wi = 0, ws = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int rr = residue_sym_bytes128(Xr[e], nr[e], mc);
-                wr |= ((unsigned)rr & 0xFFu) << (8 * e);
-                if constexpr (E::cplx) {
-                    const int ri = residue_sym_bytes128(Xi[e], ni[e], mc);
-                    wi |= ((unsigned)ri & 0xFFu) << (8 * e);
-                    // third plane from the int8-cast residues (mod.hpp:321-325)
-                    const int rs = wrapping((int)(int8_t)rr + (int)(int8_t)ri, mc.p);
-                    ws |= ((unsigned)rs & 0xFFu) << (8 * e);
-                }
-            }
-            int8_t* o = out + (size_t)t * a.plane_stride;
-            *(unsigned*)o = wr;
-            if constexpr (E::cplx) {
-                *(unsigned*)(o + a.part_stride) = wi;
-                *(unsigned*)(o + 2 * a.part_stride) = ws;
-            }
+        };
+        if (a.backend == kFP8) {
+            if (fastE) planes.template operator()<true, true>();
+            else planes.template operator()<false, true>();
+        } else {
+            if (fastE) planes.template operator()<true, false>();
+            else planes.template operator()<false, false>();
         }
     }
 }

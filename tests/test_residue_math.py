@@ -136,3 +136,54 @@ def test_byte_dot_residue_shifted_120bit(p):
             assert np.array_equal(r, want)
         else:
             assert np.array_equal(r.astype(np.int8), want.astype(np.int8))
+
+
+FP8_MODULI = [1089, 1024, 961, 841, 625, 529, 511, 509, 503, 499, 491, 487, 481, 479, 467, 463, 461, 457, 449, 443]
+
+
+@pytest.mark.parametrize("p", FP8_MODULI)
+def test_wide_byte_dot_residue_fp8_moduli(p):
+    """FP8 moduli (up to 1089): constants split c = 32 c_hi + c_lo, two byte sums, one fma; 56-bit (E = 0) and 120-bit forms.
+    p = 1024: the tie -512 becomes +512 (residues live in (-p/2, p/2])."""
+    rng = np.random.default_rng(4000 + p)
+    c = [pow(256, i, p) for i in range(15)]
+    invp = np.float64(np.float32(1.0) / np.float32(p))
+
+    def sym(v):
+        r = v % p
+        return r - p if r > p // 2 else r
+
+    def finish(s):
+        s = np.array(s, dtype=np.int64)
+        assert s.max() < 2 ** 23
+        qf = (s.astype(np.float64) * invp + 8388608.0).astype(np.float32)
+        q = qf.view(np.int32).astype(np.int64) & 0xFFFFFF
+        r = s - q * p
+        if p % 2 == 0:
+            r = np.where(r == -(p // 2), p // 2, r)
+        return r
+
+    Ms = [int(x) for x in rng.integers(1, 2 ** 53, size=3000)] + [1, 2 ** 53 - 1, p, p // 2, p // 2 + 1, 512, 1536, 3 * 512 * 7]
+    Ms += [int(q) * p + r for q in rng.integers(0, 2 ** 53 // p - 1, size=300) for r in (p // 2 - 1, p // 2, p // 2 + 1, p - 1, 0, 1)]
+    Ms = [m for m in Ms if 0 < m < 2 ** 53]
+    for neg in (False, True):
+        k56, k120 = (p - pow(2, 56, p)) % p, (p - pow(2, 120, p)) % p
+        # 56-bit form
+        s_list = []
+        for M in Ms:
+            Mt = (2 ** 56 - M) if neg else M
+            lo = (k56 if neg else 0) + sum(((Mt >> (8 * i)) & 0xFF) * (c[i] & 31) for i in range(7))
+            hi = sum(((Mt >> (8 * i)) & 0xFF) * (c[i] >> 5) for i in range(7))
+            s_list.append(lo + 32 * hi)
+        assert max(s_list) < 2 ** 21 + 2048
+        assert np.array_equal(finish(s_list), np.array([sym(-M if neg else M) for M in Ms]))
+        # 120-bit form
+        Es = [int(x) for x in rng.integers(0, 64, size=len(Ms))]
+        s_list = []
+        for M, E in zip(Ms, Es):
+            X = M << E
+            Xt = (2 ** 120 - X) if neg else X
+            lo = (k120 if neg else 0) + sum(((Xt >> (8 * i)) & 0xFF) * (c[i] & 31) for i in range(15))
+            hi = sum(((Xt >> (8 * i)) & 0xFF) * (c[i] >> 5) for i in range(15))
+            s_list.append(lo + 32 * hi)
+        assert np.array_equal(finish(s_list), np.array([sym(-(M << E) if neg else (M << E)) for M, E in zip(Ms, Es)]))
