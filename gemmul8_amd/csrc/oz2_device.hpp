@@ -18,8 +18,6 @@ constexpr int kFP8 = 1;
 // per-modulus constants for the limb-wise residue (built on the host, passed by value in kernargs)
 struct ModConst {
     int p;        // modulus
-    int c18;      // sym(2^18 mod p)
-    int c36;      // sym(2^36 mod p)
     float invp;   // RN(1/p)
     unsigned cb[4];  // cb[i] = bytes (c_{4i}, .., c_{4i+3}), c_j = 256^j mod p in [0, p) for the INT8 moduli (p <= 256), the LOW 5
                      // bits of it for the FP8 moduli (p <= 1089); byte 15 is 0
@@ -74,43 +72,6 @@ __device__ __forceinline__ int upper_bound_i8(double x, int sft) {
     const uint64_t fl = mant >> (-x2);
     const uint64_t has = (mant & ((1ull << (-x2)) - 1)) != 0;
     return (int)(int8_t)(fl + has);
-}
-
-// three 18-bit limbs of M (< 2^54)
-struct Limbs {
-    int l0, l1, l2;
-};
-__device__ __forceinline__ Limbs make_limbs(uint64_t M) {
-    Limbs L;
-    L.l0 = (int)(M & 0x3FFFF);
-    L.l1 = (int)((M >> 18) & 0x3FFFF);
-    L.l2 = (int)(M >> 36);
-    return L;
-}
-
-// s mod p for |s| < 2^29, result in [0, p)
-__device__ __forceinline__ int mod_small_pos(int s, int p, float invp) {
-    const float q = rintf((float)s * invp);
-    int r = s - __mul24((int)q, p);  // |r| <= 0.6 p
-    if (r < 0) r += p;
-    if (r >= p) r -= p;
-    return r;
-}
-
-// symmetric residue of +-M*2^E in (-p/2, p/2]; pow2row = GEMMUL8_POW2MOD[t] (only read when E > 0)
-__device__ __forceinline__ int residue_sym(const Limbs& L, int E, bool neg, const ModConst& mc, const short* pow2row) {
-    const int p = mc.p;
-    int s = L.l0 + __mul24(L.l1, mc.c18) + __mul24(L.l2, mc.c36);   // < 2^29
-    int r = s - __mul24((int)rintf((float)s * mc.invp), p);          // |r| <= 0.6 p
-    if (E > 0) {                                                      // only for num_moduli > 15 (|A'| >= 2^53)
-        s = __mul24(r, (int)pow2row[E < 63 ? E : 63]);
-        r = s - __mul24((int)rintf((float)s * mc.invp), p);
-    }
-    r = neg ? -r : r;
-    const int h = p >> 1;
-    r = (r > h) ? r - p : r;
-    r = (r + h < ((p & 1) ^ 1)) ? r + p : r;  // odd p: r < -(p-1)/2 ; even p: r <= -p/2 (the representative of p/2 is +p/2)
-    return r;
 }
 
 // INT8 moduli (p <= 256): symmetric residue of +-M*2^E (M < 2^53, E < 64) from the BYTES of the 120-bit integer M*2^E

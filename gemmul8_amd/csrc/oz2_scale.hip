@@ -26,14 +26,7 @@ ModTable make_mod_table(int backend) {
     ModTable T;
     for (int t = 0; t < 20; ++t) {
         const int p = backend == kINT8 ? GEMMUL8_MODULI_INT8[t] : GEMMUL8_MODULI_FP8[t];
-        auto sym = [p](long long r) {
-            r %= p;
-            if (r < 0) r += p;
-            return (int)(r > p / 2 ? r - p : r);
-        };
         T.mc[t].p = p;
-        T.mc[t].c18 = sym(1ll << 18);
-        T.mc[t].c36 = sym(1ll << 36);
         T.mc[t].invp = 1.0f / (float)p;
         unsigned c[16];
         long long pw = 1;
@@ -60,21 +53,6 @@ ModTable make_mod_table(int backend) {
         T.mc[t].k120 = (unsigned)((p - pow2(120)) % p);
     }
     return T;
-}
-
-__constant__ short c_pow2mod_fp8[20][64];
-static hipError_t upload_pow2_once() {
-    // __constant__ memory is per device: track the upload per device of the calling thread
-    static bool done_dev[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    bool& done = done_dev[dev];
-    if (done) return hipSuccess;
-    // only the FP8 moduli (limb residues) still need the 2^E mod p table; INT8 moduli take the byte-dot path
-    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_pow2mod_fp8), GEMMUL8_POW2MOD_FP8, sizeof(GEMMUL8_POW2MOD_FP8));
-    if (e != hipSuccess) return e;
-    done = true;
-    return hipSuccess;
 }
 
 // ------------------------------------------------------------------ element traits
@@ -481,8 +459,6 @@ hipError_t launch_quantise(hipStream_t stream, int dtype, int backend, unsigned 
                            size_t rows, size_t k, const void* X, size_t ld, const int16_t* sft, int8_t* lo, size_t plane_stride,
                            size_t part_stride, size_t kp) {
     if (rows == 0 || t_end <= t_begin) return hipSuccess;
-    hipError_t e = upload_pow2_once();
-    if (e != hipSuccess) return e;
     StageArgs a{};
     a.X = X;
     a.ld = ld;
