@@ -2,8 +2,8 @@
 //
 // What the reference does with compile-time unrolled templates over num_moduli
 // (GEMMul8/src/mod.hpp:638-877, scaling.hpp:237-280) is done here with ONE exact integer
-// representation of trunc(x*2^s) = +-M*2^E (M < 2^53, E >= 0) and a limb-wise residue that runs at
-// full VALU rate (24-bit multiplies + an fp32 reciprocal); num_moduli stays a run-time loop bound.
+// representation of trunc(x*2^s) = +-M*2^E (M < 2^53, E >= 0) and a byte-wise residue that runs at
+// full VALU rate (v_dot4_u32_u8 byte sums, one fma quotient, one 24-bit multiply-add); num_moduli stays a run-time loop bound.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -15,7 +15,7 @@ namespace oz2 {
 constexpr int kINT8 = 0;
 constexpr int kFP8 = 1;
 
-// per-modulus constants for the limb-wise residue (built on the host, passed by value in kernargs)
+// per-modulus constants of the byte-wise residue (built on the host, passed by value in kernargs)
 struct ModConst {
     int p;        // modulus
     float invp;   // RN(1/p)
