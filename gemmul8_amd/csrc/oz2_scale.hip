@@ -279,6 +279,38 @@ __global__ void __launch_bounds__(256) stage_kmajor_kernel(const StageArgs a) {
     int s;
     if constexpr (MODE == MODE_BOUND) {
         __shared__ U sm[4];
+        // rows that fit NC x 1024 elements stay in registers between the amax pass and the extract pass: one read of the row
+        constexpr int NC = sizeof(T) == 16 ? 4 : 8;
+        if (a.kp <= (size_t)1024 * NC) {
+            T vb[NC][4];
+            U am = 0;
+#pragma unroll
+            for (int it = 0; it < NC; ++it) {
+                const size_t k0 = (size_t)threadIdx.x * 4 + (size_t)it * 1024;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    vb[it][e] = (k0 + e < a.k) ? x[k0 + e] : E::zero();
+                    const U ar = (U)fabs(E::re(vb[it][e])), ai = (U)fabs(E::im(vb[it][e]));
+                    am = ar > am ? ar : am;
+                    am = ai > am ? ai : am;
+                }
+            }
+            am = wave_max(am);
+            if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = am;
+            __syncthreads();
+            am = sm[0];
+            am = sm[1] > am ? sm[1] : am;
+            am = sm[2] > am ? sm[2] : am;
+            am = sm[3] > am ? sm[3] : am;
+            s = (a.backend == kINT8 ? 5 : 7) - ilogb0(am);
+            if (threadIdx.x == 0) a.sft0[row] = (int16_t)s;
+#pragma unroll
+            for (int it = 0; it < NC; ++it) {
+                const size_t k0 = (size_t)threadIdx.x * 4 + (size_t)it * 1024;
+                if (k0 < a.kp) emit4<T, MODE>(a, row, k0, vb[it], s);
+            }
+            return;
+        }
         U am = 0;
         for (size_t kk = threadIdx.x; kk < a.k; kk += 256) {
             const T v = x[kk];
