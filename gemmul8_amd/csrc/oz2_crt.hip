@@ -70,7 +70,11 @@ __global__ void __launch_bounds__(256) crt_kernel(const CrtArgs a) {
     Vec c[20];
 #pragma unroll
     for (unsigned t = 0; t < 20; ++t)
-        if (t < a.N) c[t] = *(const Vec*)(base + (size_t)t * a.plane_stride * COMPS);
+        if (t < a.N) {
+            static_assert(sizeof(Vec) == 8, "8-byte residue vectors");
+            const unsigned long long raw = __builtin_nontemporal_load((const unsigned long long*)(base + (size_t)t * a.plane_stride * COMPS));
+            __builtin_memcpy(&c[t], &raw, 8);
+        }
 
     double Sh[NV], Sl[NV];
 #pragma unroll
@@ -107,36 +111,61 @@ __global__ void __launch_bounds__(256) crt_kernel(const CrtArgs a) {
     }
     const int sB = (int)a.sftB[col];
     U* Cc = (U*)a.C + (col * a.ldc) * COMPS;
+    const bool full = i0 + ROWS <= a.m;  // all ROWS rows exist: the old and new C values move as one vector per thread
+    const bool reads_c = mode == 0 || mode == 2 || mode == 4;
+    U oldc[NV], outv[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) oldc[e] = (U)0;
+    if (reads_c) {
+        if (full) {
+            __builtin_memcpy(oldc, Cc + i0 * COMPS, sizeof(oldc));
+        } else {
+#pragma unroll
+            for (int e = 0; e < NV; ++e)
+                if (i0 + e / COMPS < a.m) oldc[e] = Cc[i0 * COMPS + e];
+        }
+    }
 #pragma unroll
     for (int e = 0; e < ROWS; ++e) {
         const size_t row = i0 + e;
-        if (row >= a.m) break;
-        const int sft = (int)a.sftA[row] + sB;
-        U* cp = Cc + row * COMPS;
+        const int sft = (row < a.m ? (int)a.sftA[row] : 0) + sB;
         if constexpr (!CPLX) {
             const U AB = scalb<U>((U)crt_reduce(a, Sh[e], Sl[e]), sft);
             switch (mode) {
-            case 1: cp[0] = AB; break;
-            case 2: cp[0] = cp[0] + AB; break;
-            case 3: cp[0] = -AB; break;
-            case 4: cp[0] = cp[0] - AB; break;
-            default: cp[0] = fmaU<U>(be[0], cp[0], al[0] * AB); break;
+            case 1: outv[e] = AB; break;
+            case 2: outv[e] = oldc[e] + AB; break;
+            case 3: outv[e] = -AB; break;
+            case 4: outv[e] = oldc[e] - AB; break;
+            default: outv[e] = fmaU<U>(be[0], oldc[e], al[0] * AB); break;
             }
         } else {
             const U x = scalb<U>((U)crt_reduce(a, Sh[2 * e], Sl[2 * e]), sft);
             const U y = scalb<U>((U)crt_reduce(a, Sh[2 * e + 1], Sl[2 * e + 1]), sft);
+            const U cx = oldc[2 * e], cy = oldc[2 * e + 1];
             switch (mode) {
-            case 1: cp[0] = x, cp[1] = y; break;
-            case 2: cp[0] = cp[0] + x, cp[1] = cp[1] + y; break;
-            case 3: cp[0] = -x, cp[1] = -y; break;
-            case 4: cp[0] = cp[0] - x, cp[1] = cp[1] - y; break;
-            default: {
-                const U cx = cp[0], cy = cp[1];
-                cp[0] = fmaU<U>(-be[1], cy, fmaU<U>(be[0], cx, fmaU<U>(-al[1], y, al[0] * x)));
-                cp[1] = fmaU<U>(be[1], cx, fmaU<U>(be[0], cy, fmaU<U>(al[1], x, al[0] * y)));
-            } break;
+            case 1: outv[2 * e] = x, outv[2 * e + 1] = y; break;
+            case 2: outv[2 * e] = cx + x, outv[2 * e + 1] = cy + y; break;
+            case 3: outv[2 * e] = -x, outv[2 * e + 1] = -y; break;
+            case 4: outv[2 * e] = cx - x, outv[2 * e + 1] = cy - y; break;
+            default:
+                outv[2 * e] = fmaU<U>(-be[1], cy, fmaU<U>(be[0], cx, fmaU<U>(-al[1], y, al[0] * x)));
+                outv[2 * e + 1] = fmaU<U>(be[1], cx, fmaU<U>(be[0], cy, fmaU<U>(al[1], x, al[0] * y)));
+                break;
             }
         }
+    }
+    if (full) {
+        // streaming stores: C is written once and not re-read by this kernel
+        typedef U VecU __attribute__((ext_vector_type(NV)));
+        VecU ov;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) ov[e] = outv[e];
+        if ((reinterpret_cast<uintptr_t>(Cc + i0 * COMPS) & (sizeof(VecU) - 1)) == 0) __builtin_nontemporal_store(ov, (VecU*)(Cc + i0 * COMPS));
+        else __builtin_memcpy(Cc + i0 * COMPS, outv, sizeof(outv));
+    } else {
+#pragma unroll
+        for (int e = 0; e < NV; ++e)
+            if (i0 + e / COMPS < a.m) Cc[i0 * COMPS + e] = outv[e];
     }
 }
 
