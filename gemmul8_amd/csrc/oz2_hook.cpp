@@ -30,6 +30,61 @@
 
 #include "../../include/gemmul8_c.h"
 
+#ifdef OZ2_HOOK_SHIM
+// Preload shim for hosts that load their HIP runtime late and privately (Python/PyTorch): this library contains no device
+// code (so nothing registers with the HIP runtime when the loader maps it at process start) and binds to libgemmul8.so --
+// which does -- on the first intercepted call: by then the host's libamdhip64 is mapped; it is promoted to the global symbol
+// scope, then libgemmul8.so (found next to this file) is opened and the two C-ABI entry points the hook needs are resolved.
+#include <dlfcn.h>
+#include <string>
+namespace {
+struct Abi {
+    size_t (*work_size)(int, int, size_t, size_t, size_t, unsigned, int, int, size_t*, size_t*) = nullptr;
+    int (*gemm)(void*, int, int, int, int, size_t, size_t, size_t, const void*, const void*, size_t, const void*, size_t, const void*, void*,
+                size_t, unsigned, int, void*, void*, void*, int, int, int, int, double*) = nullptr;
+};
+const Abi& abi() {
+    static const Abi a = [] {
+        Abi r;
+        if (FILE* f = std::fopen("/proc/self/maps", "r")) {  // promote the HIP runtime the process already uses
+            char line[1024];
+            while (std::fgets(line, sizeof line, f)) {
+                if (!std::strstr(line, "libamdhip64")) continue;
+                char* path = std::strchr(line, '/');
+                if (!path) continue;
+                path[std::strcspn(path, "\n")] = 0;
+                (void)dlopen(path, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+                break;
+            }
+            std::fclose(f);
+        }
+        Dl_info info;
+        std::string dir = ".";
+        if (dladdr((const void*)&abi, &info) && info.dli_fname) {
+            dir = info.dli_fname;
+            const size_t slash = dir.rfind('/');
+            dir = slash == std::string::npos ? "." : dir.substr(0, slash);
+        }
+        void* h = dlopen((dir + "/libgemmul8.so").c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+            std::fprintf(stderr, "[GEMMUL8 HOOK] cannot open %s/libgemmul8.so: %s\n", dir.c_str(), dlerror());
+            std::abort();
+        }
+        r.work_size = (decltype(r.work_size))dlsym(h, "gemmul8_work_size");
+        r.gemm = (decltype(r.gemm))dlsym(h, "gemmul8_gemm");
+        if (!r.work_size || !r.gemm) {
+            std::fprintf(stderr, "[GEMMUL8 HOOK] libgemmul8.so lacks the C ABI entry points\n");
+            std::abort();
+        }
+        return r;
+    }();
+    return a;
+}
+}  // namespace
+#define gemmul8_work_size abi().work_size
+#define gemmul8_gemm abi().gemm
+#endif
+
 namespace {
 
 struct Cache {  // what the quantised planes in workA/workB currently hold
@@ -143,14 +198,38 @@ hipblasStatus_t grow(Buffer& b, size_t need, hipStream_t stream, const char* tag
     return HIPBLAS_STATUS_SUCCESS;
 }
 
-template <typename Fn> Fn real_fn(const char* name) { return reinterpret_cast<Fn>(dlsym(RTLD_NEXT, name)); }
+// The real hipBLAS entry point: the next definition in the global search order, or -- when the host loaded hipBLAS privately
+// (Python extension modules are dlopen'ed RTLD_LOCAL) -- the copy of libhipblas that is already mapped into the process.
+void* mapped_hipblas() {
+    static void* h = [] {
+        void* r = nullptr;
+        if (FILE* f = std::fopen("/proc/self/maps", "r")) {
+            char line[1024];
+            while (std::fgets(line, sizeof line, f)) {
+                if (!std::strstr(line, "libhipblas.so")) continue;  // not libhipblaslt
+                char* path = std::strchr(line, '/');
+                if (!path) continue;
+                path[std::strcspn(path, "\n")] = 0;
+                r = dlopen(path, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+                if (r) break;
+            }
+            std::fclose(f);
+        }
+        return r;
+    }();
+    return h;
+}
+template <typename Fn> Fn real_fn(const char* name) {
+    void* f = dlsym(RTLD_NEXT, name);
+    if (!f)
+        if (void* h = mapped_hipblas()) f = dlsym(h, name);
+    return reinterpret_cast<Fn>(f);
+}
 
 hipStream_t handle_stream(hipblasHandle_t h, hipblasStatus_t* st) {
     using Fn = hipblasStatus_t (*)(hipblasHandle_t, hipStream_t*);
     static Fn fn = [] {
-        Fn f = real_fn<Fn>("hipblasGetStream");
-        if (!f) f = reinterpret_cast<Fn>(dlsym(RTLD_DEFAULT, "hipblasGetStream"));
-        return f;
+        return real_fn<Fn>("hipblasGetStream");
     }();
     hipStream_t s = nullptr;
     *st = fn ? fn(h, &s) : HIPBLAS_STATUS_NOT_INITIALIZED;

@@ -1,0 +1,16 @@
+import os, time, torch
+n = 4096
+torch.manual_seed(0)
+A = torch.rand((n, n), dtype=torch.float64, device="cuda") - 0.5
+B = torch.rand((n, n), dtype=torch.float64, device="cuda") - 0.5
+for _ in range(3):
+    C = A @ B
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    C = A @ B
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 10
+ref = (A[:64].cpu().numpy().astype("longdouble") @ B.cpu().numpy().astype("longdouble"))
+err = float(abs(C[:64].cpu().numpy() - ref).max() / abs(ref).max())
+print(f"LD_PRELOAD={'yes' if 'gemmul8' in os.environ.get('LD_PRELOAD','') else 'no'}  torch DGEMM {n}^3: {2*n**3/dt*1e-12:.1f} TFLOPS, normwise err {err:.2e}")
