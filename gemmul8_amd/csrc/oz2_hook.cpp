@@ -1,4 +1,4 @@
-// LD_PRELOAD hipBLAS hook: hipblas{S,D,C,Z}gemm, hipblasGemmEx and hipblasDestroy are intercepted
+// LD_PRELOAD hipBLAS hook: hipblas{S,D,C,Z}gemm, hipblasGemmEx, their strided-batched forms and hipblasDestroy are intercepted
 // and routed to the Ozaki-II emulation (C ABI, gemmul8_c.h) according to the GEMMUL8_* environment
 // variables; everything else -- and every call the environment does not select -- is passed to the
 // real library found with dlsym(RTLD_NEXT).
@@ -389,6 +389,69 @@ hipblasStatus_t hipblasGemmEx(hipblasHandle_t handle, hipblasOperation_t transA,
                                    hipblasComputeType_t, hipblasGemmAlgo_t);
     static Fn real = real_fn<Fn>("hipblasGemmEx");
     return real ? real(handle, transA, transB, m, n, k, alpha, A, aType, lda, B, bType, ldb, beta, C, cType, ldc, computeType, algo)
+                : HIPBLAS_STATUS_NOT_INITIALIZED;
+}
+
+// Strided-batched entry points (not hooked by the reference; PyTorch's bmm uses them): the batch is a loop of emulated
+// GEMMs on the handle's stream.  alpha/beta are shared by the batch; element strides are in units of the matrix type.
+static bool emulate_batch(int dtype, size_t elem, hipblasHandle_t handle, hipblasOperation_t ta, hipblasOperation_t tb, int m, int n, int k,
+                          const void* alpha, const void* A, int lda, long long sa, const void* B, int ldb, long long sb, const void* beta,
+                          void* C, int ldc, long long sc, int batch, hipblasStatus_t* status) {
+    *status = HIPBLAS_STATUS_SUCCESS;
+    for (int b = 0; b < batch; ++b) {
+        hipblasStatus_t st;
+        const bool done = try_emulate(dtype, handle, ta, tb, m, n, k, alpha, (const char*)A + (size_t)b * sa * elem, lda,
+                                      (const char*)B + (size_t)b * sb * elem, ldb, beta, (char*)C + (size_t)b * sc * elem, ldc, &st);
+        if (!done) return b == 0 ? false : (*status = HIPBLAS_STATUS_INTERNAL_ERROR, true);  // not selected by the environment: pass through
+        if (st != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
+    }
+    return true;
+}
+
+#define OZ2_SB_HOOK(NAME, T, CODE)                                                                                                       \
+    hipblasStatus_t NAME(hipblasHandle_t handle, hipblasOperation_t transA, hipblasOperation_t transB, int m, int n, int k,               \
+                         const T* alpha, const T* A, int lda, long long strideA, const T* B, int ldb, long long strideB, const T* beta,  \
+                         T* C, int ldc, long long strideC, int batchCount) {                                                             \
+        hipblasStatus_t st;                                                                                                               \
+        if (m > 0 && n > 0 && k > 0 && batchCount > 0 && A && B && C && alpha && beta &&                                                  \
+            emulate_batch(CODE, sizeof(T), handle, transA, transB, m, n, k, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc,        \
+                          strideC, batchCount, &st))                                                                                      \
+            return st;                                                                                                                    \
+        using Fn = hipblasStatus_t (*)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int, const T*, const T*, int,   \
+                                       long long, const T*, int, long long, const T*, T*, int, long long, int);                          \
+        static Fn real = real_fn<Fn>(#NAME);                                                                                              \
+        return real ? real(handle, transA, transB, m, n, k, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batchCount)   \
+                    : HIPBLAS_STATUS_NOT_INITIALIZED;                                                                                     \
+    }
+OZ2_SB_HOOK(hipblasSgemmStridedBatched, float, GEMMUL8_S)
+OZ2_SB_HOOK(hipblasDgemmStridedBatched, double, GEMMUL8_D)
+OZ2_SB_HOOK(hipblasCgemmStridedBatched, hipComplex, GEMMUL8_C)
+OZ2_SB_HOOK(hipblasZgemmStridedBatched, hipDoubleComplex, GEMMUL8_Z)
+#undef OZ2_SB_HOOK
+
+hipblasStatus_t hipblasGemmStridedBatchedEx(hipblasHandle_t handle, hipblasOperation_t transA, hipblasOperation_t transB, int m, int n, int k,
+                                            const void* alpha, const void* A, hipDataType aType, int lda, hipblasStride strideA, const void* B,
+                                            hipDataType bType, int ldb, hipblasStride strideB, const void* beta, void* C, hipDataType cType,
+                                            int ldc, hipblasStride strideC, int batchCount, hipblasComputeType_t computeType,
+                                            hipblasGemmAlgo_t algo) {
+    int dtype = -1;
+    size_t elem = 0;
+    const bool same = (aType == bType && bType == cType);
+    if (same && computeType == HIPBLAS_COMPUTE_32F && aType == HIP_R_32F) dtype = GEMMUL8_S, elem = 4;
+    else if (same && computeType == HIPBLAS_COMPUTE_64F && aType == HIP_R_64F) dtype = GEMMUL8_D, elem = 8;
+    else if (same && computeType == HIPBLAS_COMPUTE_32F && aType == HIP_C_32F) dtype = GEMMUL8_C, elem = 8;
+    else if (same && computeType == HIPBLAS_COMPUTE_64F && aType == HIP_C_64F) dtype = GEMMUL8_Z, elem = 16;
+    hipblasStatus_t st;
+    if (dtype >= 0 && m > 0 && n > 0 && k > 0 && batchCount > 0 && A && B && C && alpha && beta &&
+        emulate_batch(dtype, elem, handle, transA, transB, m, n, k, alpha, A, lda, (long long)strideA, B, ldb, (long long)strideB, beta, C, ldc,
+                      (long long)strideC, batchCount, &st))
+        return st;
+    using Fn = hipblasStatus_t (*)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int, const void*, const void*,
+                                   hipDataType, int, hipblasStride, const void*, hipDataType, int, hipblasStride, const void*, void*,
+                                   hipDataType, int, hipblasStride, int, hipblasComputeType_t, hipblasGemmAlgo_t);
+    static Fn real = real_fn<Fn>("hipblasGemmStridedBatchedEx");
+    return real ? real(handle, transA, transB, m, n, k, alpha, A, aType, lda, strideA, B, bType, ldb, strideB, beta, C, cType, ldc, strideC,
+                       batchCount, computeType, algo)
                 : HIPBLAS_STATUS_NOT_INITIALIZED;
 }
 

@@ -14,3 +14,13 @@ dt = (time.perf_counter() - t0) / 10
 ref = (A[:64].cpu().numpy().astype("longdouble") @ B.cpu().numpy().astype("longdouble"))
 err = float(abs(C[:64].cpu().numpy() - ref).max() / abs(ref).max())
 print(f"LD_PRELOAD={'yes' if 'gemmul8' in os.environ.get('LD_PRELOAD','') else 'no'}  torch DGEMM {n}^3: {2*n**3/dt*1e-12:.1f} TFLOPS, normwise err {err:.2e}")
+
+# batched: torch.bmm -> hipblasDgemmStridedBatched / hipblasGemmStridedBatchedEx
+nb, b = 1024, 6
+X = torch.rand((b, nb, nb), dtype=torch.float64, device="cuda") - 0.5
+Y = torch.rand((b, nb, nb), dtype=torch.float64, device="cuda") - 0.5
+Z = torch.bmm(X, Y)
+torch.cuda.synchronize()
+refb = X[b - 1].cpu().numpy().astype("longdouble") @ Y[b - 1].cpu().numpy().astype("longdouble")
+errb = float(abs(Z[b - 1].cpu().numpy() - refb).max() / abs(refb).max())
+print(f"torch.bmm {b} x {nb}^3: bmm normwise err {errb:.2e}")
