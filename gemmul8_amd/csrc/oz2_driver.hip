@@ -349,7 +349,7 @@ int gemmul8_gemm(void* stream_, int dtype, int backend, int op_A, int op_B, size
     if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
     if (!alpha || !beta || !A || !B || !C || !work) return GEMMUL8_E_ARG;
     if (k > (size_t(1) << 17)) return GEMMUL8_E_ARG;
-    if (m == 0 || n == 0) return GEMMUL8_OK;
+    if (m == 0 || n == 0 || k == 0) return GEMMUL8_OK;  // the reference's early-out (gemmul8_real.hpp: m|n|k <= 0 -> success, C untouched)
     gemmul8_layout L;
     int rc = gemmul8_get_layout(dtype, backend, m, n, k, N, work, workA, workB, enA, enB, &L);
     if (rc) return rc;
