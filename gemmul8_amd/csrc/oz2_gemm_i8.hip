@@ -192,9 +192,17 @@ __device__ __forceinline__ void i8_epilogue(const v16i (&acc)[4][NJ], const Gemm
     }
 }
 
-// Persistent, wave-specialised kernel: one workgroup per CU (128 KiB of LDS) loops over tiles vb = blockIdx.x,
+#ifndef OZ2_PB
+#define OZ2_PB 4
+#endif
+constexpr int RING_LDS_BYTES = 5 * TILE_BYTES;  // five 32 KiB operand panels = the whole 160 KiB of LDS
+
+// Persistent, wave-specialised kernel: one workgroup per CU (all 160 KiB of LDS) loops over tiles vb = blockIdx.x,
 // blockIdx.x + gridDim.x, ...; 8 consumer waves (2 x 4, each 128 x 64 of the 256 x 256 tile) run MFMA + epilogue, 4
-// producer waves only issue LDS-DMA.  The two-stage K pipeline runs straight through tile boundaries: while the consumers
+// producer waves only issue LDS-DMA into a 2.5-stage ring of operand panels (see the producer branch): A panels are fetched
+// two K-steps ahead with their 16 instructions per wave spread evenly over the K-step, B panels one K-step ahead -- smooth
+// issue matters as much as depth (all 16 in one slot: +7 % kernel time; the ring with even issue: -6..9 % against the
+// two-stage pipeline at every k).  The K pipeline runs straight through tile boundaries: while the consumers
 // are in the last K-step and the epilogue of a tile the producers already fetch the first K-tile of the next one, the
 // epilogue's stores drain behind the next tile's MFMAs, and there is no workgroup launch / LDS re-allocation between
 // tiles -- a non-persistent version of this kernel lost ~11 us of a ~120 us tile to those three.
@@ -245,41 +253,84 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((src_) + doff[q_]),                     \
                                      (__attribute__((address_space(3))) void*)((stage_) + (pw * 16 + (q_)) * 1024), 16, 0, 0)
 
-        int vb_next = blockIdx.x;  // tile of the K-tile to fetch next
+        // 2.5-stage ring of operand panels (5 x 32 KiB = all 160 KiB of LDS): panel h = 2 g + isB lives in slot h % 5.  The slot of
+        // A(g') held B(g'-3) and the slot of B(g') held A(g'-2), so during K-step g the A producers may fetch A(g+2) and the B
+        // producers B(g+1): 96 KiB in flight per CU instead of 64 -- the 2-stage version was bound by the DMA round trip
+        // (64 KiB per ~1.5 us of L2-miss latency = 43 GB/s per CU against the 60 GB/s a full-speed K-step consumes).
+        int vb_next = blockIdx.x;  // tile of the panel to fetch next
+        bool more = true;
         PRODUCER_SET_TILE(vb_next);
         int seg = 0, kin = 0;      // its segment / K-step inside the segment (no divisions in the loop)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) PRODUCER_DMA(g0, q, smem);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int hs = isB ? 1 : 0;      // its slot
+#define PRODUCER_BEGIN()                                                                                                     \
+    do {                                                                                                                     \
+        fsrc = (seg == 0 ? g0 : seg == 1 ? g1 : g2) + (size_t)kin * BK;                                                      \
+        fdst = smem + hs * TILE_BYTES - (isB ? TILE_BYTES : 0);   /* PRODUCER_DMA adds pw * 16 KiB */                         \
+    } while (0)
+#define PRODUCER_ADVANCE()                                                                                                   \
+    do {                                                                                                                     \
+        hs = hs + 2 >= 5 ? hs - 3 : hs + 2;                                                                                  \
+        if (++kin == KT1) {                                                                                                  \
+            kin = 0;                                                                                                         \
+            if (++seg == args.nseg) {                                                                                        \
+                seg = 0;                                                                                                     \
+                vb_next += G;                                                                                                \
+                more = vb_next < total;                                                                                      \
+                if (more) PRODUCER_SET_TILE(vb_next);                                                                        \
+            }                                                                                                                \
+        }                                                                                                                    \
+    } while (0)
+#define PRODUCER_FETCH()                                                                                                     \
+    do {                                                                                                                     \
+        PRODUCER_BEGIN();                                                                                                    \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) PRODUCER_DMA(fsrc, q, fdst);                                          \
+        PRODUCER_ADVANCE();                                                                                                  \
+    } while (0)
+        const int8_t* fsrc = g0;
+        char* fdst = smem;
+        PRODUCER_FETCH();  // panel 0
+        bool ahead = false;
+        if (!isB && more) {
+            PRODUCER_FETCH();  // A(1)
+            ahead = true;
+        }
+        if (ahead) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        int g = 0;  // K-steps done (stage = g & 1)
         for (int vb = blockIdx.x; vb < total; vb += G) {
-            for (int kt = 0; kt < KT; ++kt, ++g) {
-                char* nxt = smem + ((g + 1) & 1) * STAGE_BYTES;
-                // advance (vb_next, seg, kin) to the K-tile after the current one
-                bool more = true;
-                if (++kin == KT1) {
-                    kin = 0;
-                    if (++seg == args.nseg) {
-                        seg = 0;
-                        vb_next += G;
-                        more = vb_next < total;
-                        if (more) PRODUCER_SET_TILE(vb_next);
-                    }
-                }
-                const int8_t* src = (seg == 0 ? g0 : seg == 1 ? g1 : g2) + (size_t)kin * BK;
+            for (int kt = 0; kt < KT; ++kt) {
+                // A producers: A(g+2); B producers: B(g+1); afterwards the panel needed NEXT K-step must have landed, which
+                // for the A producers means everything except the 16 instructions just issued
+                const bool issued = more;
+                if (issued) PRODUCER_BEGIN();
 #pragma unroll
                 for (int sl = 0; sl < 8; ++sl) {
-                    if (sl < PSLOTS && more) {
+                    // B (needed next K-step): 4 instructions in each of slots 0-3; A (needed in two K-steps): 2 in every slot.
+                    // Bursts cost: all 16 in slot 0 is 7 % slower than the spread issue.
+                    if (issued) {
+                        if (isB) {
+                            constexpr int PB = OZ2_PB;  // slots over which B's 16 instructions are spread
 #pragma unroll
-                        for (int q = 0; q < 16 / PSLOTS; ++q) PRODUCER_DMA(src, sl * (16 / PSLOTS) + q, nxt);
+                            for (int q = 0; q < 16; ++q)
+                                if (q * PB / 16 == sl) PRODUCER_DMA(fsrc, q, fdst);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) PRODUCER_DMA(fsrc, sl * 2 + q, fdst);
+                        }
                     }
-                    if (sl == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (sl == 7 && issued) PRODUCER_ADVANCE();
+                    if (sl == 7) {
+                        if (!isB && issued) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
                     __builtin_amdgcn_s_barrier();
                 }
             }
         }
         __builtin_amdgcn_s_barrier();
+#undef PRODUCER_FETCH
+#undef PRODUCER_BEGIN
+#undef PRODUCER_ADVANCE
 #undef PRODUCER_SET_TILE
 #undef PRODUCER_DMA
         return;
@@ -291,11 +342,11 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     const int khalf = lane >> 5;
     const int sw = (frow >> 1) & 7;
     const int a_base = (wm * 128 + frow) * BK;
-    const int b_base = TILE_BYTES + (wn * 64 + frow) * BK;
+    const int b_base = (wn * 64 + frow) * BK;
 
     __builtin_amdgcn_s_barrier();               // K-tile 0 published by the producers
     if (wm == 1) __builtin_amdgcn_s_barrier();  // trailing half: one segment behind
-    int g = 0;
+    int sA = 0;                                  // slot of A(g); B(g) sits in the next slot (mod 5)
     for (int vb = blockIdx.x; vb < total; vb += G) {
         v16i acc[4][2];
 #pragma unroll
@@ -305,16 +356,18 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
-        for (int kt = 0; kt < KT; ++kt, ++g) {
-            char* cur = smem + (g & 1) * STAGE_BYTES;
+        for (int kt = 0; kt < KT; ++kt) {
+            const char* curA = smem + sA * TILE_BYTES + a_base;
+            const char* curB = smem + (sA == 4 ? 0 : sA + 1) * TILE_BYTES + b_base;
+            sA = sA + 2 >= 5 ? sA - 3 : sA + 2;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int coff = (((ks << 1) | khalf) ^ sw) << 4;
                 v4i af[4], bf[2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = *(const v4i*)(cur + a_base + i * 32 * BK + coff);
+                for (int i = 0; i < 4; ++i) af[i] = *(const v4i*)(curA + i * 32 * BK + coff);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf[j] = *(const v4i*)(cur + b_base + j * 32 * BK + coff);
+                for (int j = 0; j < 2; ++j) bf[j] = *(const v4i*)(curB + j * 32 * BK + coff);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -366,7 +419,7 @@ template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 0;
     bool& attr_set = attr_set_dev[dev_];
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -378,7 +431,7 @@ template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int
     int grid = num_cus() & ~7;
     if (grid <= 0) grid = 8;
     if (a.total_tiles < grid) grid = a.total_tiles;
-    hipLaunchKernelGGL(gemm_i8_kernel<EPI>, dim3(grid), dim3(WS_THREADS), LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(gemm_i8_kernel<EPI>, dim3(grid), dim3(WS_THREADS), RING_LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 
