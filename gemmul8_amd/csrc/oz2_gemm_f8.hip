@@ -20,7 +20,7 @@
 // (the unscaled 32x32x16 fp8 form runs at the BF16 rate).  Its 8-VGPR fragments (A 2x8 + B 2x8 live next to the 128
 // accumulators) do not fit the 168-VGPR budget of the 12-wave INT8 layout -- that version spilled accumulators
 // inside the K loop -- so this kernel runs 8 waves (2 per SIMD, 256 VGPRs) and the consumer waves issue the
-// LDS-DMA of the next K-tile themselves in their first two LOAD segments (8 instructions per wave and K-tile).
+// LDS-DMA themselves in their LOAD segments (8 instructions per wave and operand panel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -65,6 +65,10 @@ struct F8Args {
 __device__ __forceinline__ unsigned pack16(int a, int b) { return ((unsigned)a & 0xFFFFu) | ((unsigned)b << 16); }
 
 constexpr int F8_THREADS = 512;
+#ifndef OZ2_F8_PB
+#define OZ2_F8_PB 2
+#endif
+constexpr int F8_PB = OZ2_F8_PB;  // LOAD segments (of 4) over which a B wave spreads its 8 DMA instructions
 
 // int16 residue epilogues (EPI_PART / EPI_FINAL) of a wave's 128 x 64 accumulator block.  ODD: odd modulus -- residues in
 // fp32 (accumulators are exact integers, |c| <= 2^24): q = rint(c/p) may be off by one near a rounding tie (error
@@ -259,10 +263,13 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
     const int total = args.total_tiles;
     const int G = gridDim.x;
 
-    // LDS-DMA: wave w issues instructions Q = 8w .. 8w+7 of every K-tile (1 KiB = 8 rows x 128 B each; waves 0-3 fetch A,
-    // waves 4-7 fetch B; slot layout as in oz2_gemm_i8.hip).  Per tile: a wave-uniform base pointer and 8 per-lane byte
+    // LDS-DMA: a wave issues 8 instructions per operand panel (1 KiB = 8 rows x 128 B each; rows 64 (wave & 3) .. +63 of the
+    // panel; slot layout inside a panel as in oz2_gemm_i8.hip).  Per tile: a wave-uniform base pointer and 8 per-lane byte
     // offsets (B rows clamped to the rows that exist), so the K loop issues global_load_lds with SGPR base + VGPR offset.
-    const bool isB = wave >= 4;
+    // The leading half (waves 0-3) fetches B, whose panels are needed one K-step after they are issued: it can drain them as late
+    // as the end of its last MFMA segment (one barrier before its own first LOAD of the next K-step); the trailing half
+    // (waves 4-7) fetches A two K-steps ahead.
+    const bool isB = wave < 4;
     unsigned doff[8];
     const int8_t* gsrc;
     auto uniform = [](const int8_t* ptr) {
@@ -286,14 +293,14 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
     } while (0)
 #define F8_DMA(src_, q_, stage_)                                                                                             \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((src_) + doff[q_]),                     \
-                                     (__attribute__((address_space(3))) void*)((stage_) + (wave * 8 + (q_)) * 1024), 16, 0, 0)
+                                     (__attribute__((address_space(3))) void*)((stage_) + ((wave & 3) * 8 + (q_)) * 1024), 16, 0, 0)
 
     const int wm = wave >> 2, wn = wave & 3;
     const int frow = lane & 31;
     const int khalf = lane >> 5;
     const int sw = (frow >> 1) & 7;
     const int a_base = (wm * 128 + frow) * BK;
-    const int b_base = TILE_BYTES + (wn * 64 + frow) * BK;
+    const int b_base = (wn * 64 + frow) * BK;
 
     auto frag = [&](const char* base, int c0) {  // 32 bytes = logical chunks c0, c0+1 of this lane's row
         const v4i lo = *(const v4i*)(base + ((c0 ^ sw) << 4));
@@ -302,85 +309,133 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
     };
     constexpr int UNIT = 0x7F7F7F7F;  // E8M0 scale 2^0 for every 32-element block
 
-    int vb_next = blockIdx.x, kt_next = 0;  // K-tile to fetch next
-    F8_SET_TILE(vb_next);
+    // the whole persistent loop is instantiated twice (A-fetching waves 0-3, B-fetching waves 4-7) so that the fetch schedule is
+    // branch-free inside the LOAD segments
+    auto run = [&]<bool ISB>() {
+        // 2.5-stage ring of operand panels as in oz2_gemm_i8.hip: panel h = 2 g + isB in slot h % 5 of five 32 KiB panels.  The A
+        // waves fetch A(g+2) during K-step g, two instructions in each of their four LOAD segments; the B waves fetch B(g+1), four
+        // instructions in each of their first two LOAD segments (measured: spreading B further, or issuing it all at once, loses
+        // 3-12 %).  Against the two-stage pipeline: 63.4 -> 56.2 ms on the 18 FP8 GEMMs of config 3.
+        // Fetch state = the panel fetched LAST; every K-step first advances it (at the TOP of the K-step: a branch after the
+        // LOAD/MFMA segments lets the compiler sink all MFMAs of the K-step behind it, which destroys the ping-pong) and then
+        // issues that panel.  Past the last panel the state stops advancing and the fetch repeats the last valid source into
+        // slots nobody will read, so the segments themselves stay branch-free; the wave drains everything before it exits.
+        int vb_next = blockIdx.x, kt_next = 0;
+        bool more = true;
+        int hs = ISB ? 1 : 0;  // slot of the panel to fetch
+        const int8_t* fsrc;
+        char* fdst;
+        F8_SET_TILE(vb_next);
+#define F8_FETCH_ADVANCE()                                                                                                   \
+    do {                                                                                                                     \
+        hs = hs + 2 >= 5 ? hs - 3 : hs + 2;                                                                                  \
+        if (more && ++kt_next == KT) {                                                                                       \
+            kt_next = 0;                                                                                                     \
+            vb_next += G;                                                                                                    \
+            more = vb_next < total;                                                                                          \
+            if (more) F8_SET_TILE(vb_next);                                                                                  \
+            else kt_next = KT - 1;                                                                                           \
+        }                                                                                                                    \
+    } while (0)
+#define F8_FETCH_BEGIN()                                                                                                     \
+    do {                                                                                                                     \
+        fsrc = gsrc + (size_t)kt_next * BK;                                                                                  \
+        fdst = smem + hs * TILE_BYTES;                                                                                       \
+    } while (0)
+        F8_FETCH_BEGIN();
 #pragma unroll
-    for (int q = 0; q < 8; ++q) F8_DMA(gsrc, q, smem);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();
-    // Hazards: the stage written during K-step g was last read in K-step g-1, whose LOAD segments every wave has finished
-    // (lgkmcnt(0) + barrier) before the leading half enters slot 0 of K-step g; each wave drains its own DMA (vmcnt(0)) in
-    // its last LOAD segment, one barrier before anyone reads the new stage.
-    int g = 0;
-    for (int vb = blockIdx.x; vb < total; vb += G) {
-        v16f acc[4][2];
+        for (int q = 0; q < 8; ++q) F8_DMA(fsrc, q, fdst);
+        if constexpr (!ISB) {
+            F8_FETCH_ADVANCE();
+            F8_FETCH_BEGIN();
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int q = 0; q < 8; ++q) F8_DMA(fsrc, q, fdst);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();
+        // Hazards: a panel's slot was last read two (A) / one (B) K-steps before the refill is issued, and every wave finishes a
+        // K-step's LOAD segments (lgkmcnt(0) + barrier) before the leading half enters slot 0 of the next one; each wave drains the
+        // DMA the NEXT K-step needs in its last LOAD segment (A waves: everything but the 8 instructions just issued), one barrier
+        // before anyone reads the new panels.
+        int sA = 0;  // slot of A(g); B(g) sits in the next slot (mod 5)
+        for (int vb = blockIdx.x; vb < total; vb += G) {
+            v16f acc[4][2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-        for (int kt = 0; kt < KT; ++kt, ++g) {
-            char* cur = smem + (g & 1) * STAGE_BYTES;
-            char* nxt = smem + ((g + 1) & 1) * STAGE_BYTES;
-            bool more = true;
-            if (++kt_next == KT) {
-                kt_next = 0;
-                vb_next += G;
-                more = vb_next < total;
-                if (more) F8_SET_TILE(vb_next);
-            }
-            const int8_t* src = gsrc + (size_t)kt_next * BK;
+            for (int kt = 0; kt < KT; ++kt) {
+                const char* curA = smem + sA * TILE_BYTES + a_base;
+                const char* curB = smem + (sA == 4 ? 0 : sA + 1) * TILE_BYTES + b_base;
+                sA = sA + 2 >= 5 ? sA - 3 : sA + 2;
+                F8_FETCH_ADVANCE();
+                F8_FETCH_BEGIN();
 #pragma unroll
-            for (int ks2 = 0; ks2 < 2; ++ks2) {
-                const int c0 = ks2 * 4 + khalf * 2;
-                v8i bf[2];
+                for (int ks2 = 0; ks2 < 2; ++ks2) {
+                    const int c0 = ks2 * 4 + khalf * 2;
+                    v8i bf[2];
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    v8i af[2];
-                    if (ks2 == 0 && more) {
+                    for (int half = 0; half < 2; ++half) {
+                        v8i af[2];
+                        const int seg = ks2 * 2 + half;  // LOAD segment 0..3 of this K-step
+                        if constexpr (ISB) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) F8_DMA(src, half * 4 + q, nxt);
+                            for (int q = 0; q < 8; ++q)
+                                if (q * F8_PB / 8 == seg) F8_DMA(fsrc, q, fdst);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) F8_DMA(fsrc, seg * 2 + q, fdst);
+                        }
+                        if (half == 0) {
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) bf[j] = frag(curB + j * 32 * BK, c0);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) af[i] = frag(curA + (half * 2 + i) * 32 * BK, c0);
+                        if (seg == 3 && !ISB) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[half * 2 + i][j] =
+                                    __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[i], bf[j], acc[half * 2 + i][j], 0, 0, 0, UNIT, 0, UNIT);
+                        __builtin_amdgcn_s_setprio(0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (seg == 3 && ISB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (half == 0) {
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) bf[j] = frag(cur + b_base + j * 32 * BK, c0);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) af[i] = frag(cur + a_base + (half * 2 + i) * 32 * BK, c0);
-                    if (ks2 == 1 && half == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[half * 2 + i][j] =
-                                __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[i], bf[j], acc[half * 2 + i][j], 0, 0, 0, UNIT, 0, UNIT);
-                    __builtin_amdgcn_s_setprio(0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n);
+            const int i0 = tmap.tm * BM + wm * 128, j0 = tmap.tn * BN + wn * 64;
+            if constexpr (EPI == EPI_PART || EPI == EPI_FINAL || EPI == EPI_FINAL_CPLX) {
+                if (args.moduli[args.t_begin + tmap.plane] & 1) f8_epilogue_mod<EPI, true>(acc, args, tmap.plane, i0, j0, lane);
+                else f8_epilogue_mod<EPI, false>(acc, args, tmap.plane, i0, j0, lane);
+            } else {
+                f8_epilogue_bound<EPI>(acc, args, i0, j0, lane);
+            }
         }
-        const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n);
-        const int i0 = tmap.tm * BM + wm * 128, j0 = tmap.tn * BN + wn * 64;
-        if constexpr (EPI == EPI_PART || EPI == EPI_FINAL || EPI == EPI_FINAL_CPLX) {
-            if (args.moduli[args.t_begin + tmap.plane] & 1) f8_epilogue_mod<EPI, true>(acc, args, tmap.plane, i0, j0, lane);
-            else f8_epilogue_mod<EPI, false>(acc, args, tmap.plane, i0, j0, lane);
-        } else {
-            f8_epilogue_bound<EPI>(acc, args, i0, j0, lane);
-        }
-    }
+    };
+    if (isB) run.template operator()<true>();
+    else run.template operator()<false>();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
     if (wm == 0) __builtin_amdgcn_s_barrier();
 #undef F8_SET_TILE
 #undef F8_DMA
+#undef F8_FETCH_BEGIN
+#undef F8_FETCH_ADVANCE
 }
 
 static void fill_common(F8Args& a, size_t kp, size_t m, size_t n) {
@@ -414,7 +469,7 @@ template <int EPI> static hipError_t launch(hipStream_t stream, F8Args& a, int p
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 0;
     bool& attr_set = attr_set_dev[dev_];
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_f8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_f8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * TILE_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -423,7 +478,7 @@ template <int EPI> static hipError_t launch(hipStream_t stream, F8Args& a, int p
     int grid = num_cus() & ~7;  // persistent: one workgroup per CU (see oz2_gemm_i8.hip)
     if (grid <= 0) grid = 8;
     if (a.total_tiles < grid) grid = a.total_tiles;
-    hipLaunchKernelGGL(gemm_f8_kernel<EPI>, dim3(grid), dim3(F8_THREADS), LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(gemm_f8_kernel<EPI>, dim3(grid), dim3(F8_THREADS), 5 * TILE_BYTES, stream, a);
     return hipGetLastError();
 }
 
