@@ -44,3 +44,30 @@ def test_random_case_bit_exact(seed):
         alpha, beta = alpha + 0.5j, beta - 0.25j
     C0 = _rand((m, n), dtype, rng, 0.0) if beta != 0 else None
     gu.parity_case(A, B, N, fast, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0, backend=backend)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, np.complex128])
+@pytest.mark.parametrize("fast", [False, True])
+def test_extreme_exponents_bit_exact(dtype, fast):
+    """Rows / columns scaled over (almost) the whole exponent range, subnormals, zeros and exact powers of two: the exact
+    trunc(x * 2^s) representation and the shift logic against the oracle."""
+    import gemmul8_amd as g
+    import gpu_util as gu
+    rng = np.random.default_rng(31337)
+    m, n, k = 70, 45, 200
+    is32 = np.dtype(dtype) in (np.dtype(np.float32),)
+    span = 60 if is32 else 450
+    A = _rand((m, k), dtype, rng, 1.0)
+    B = _rand((k, n), dtype, rng, 1.0)
+    A = (A * np.exp2(rng.integers(-span, span, size=(m, 1)).astype(np.float64))).astype(dtype)
+    B = (B * np.exp2(rng.integers(-span, span, size=(1, n)).astype(np.float64))).astype(dtype)
+    A[3, :] = 0
+    A[7, ::3] = 0
+    B[:, 5] = 0
+    A[11, :] = np.exp2(rng.integers(-20, 20, size=k)).astype(dtype)           # exact powers of two
+    tiny = np.finfo(np.float32 if is32 else np.float64).tiny
+    A[13, :] = (rng.random(k) * tiny).astype(dtype)                           # subnormal row
+    N = 12 if is32 else 16
+    gu.parity_case(A, B, N, fast)
+    if not is32:
+        gu.parity_case(A, B, 9, fast, backend=g.FP8)
