@@ -15,24 +15,28 @@
 // ArBi+AiBr and ArBi+AiBr+(Ar-Ai)(Br-Bi) are single GEMMs this way.
 //
 // Kernel structure (CDNA4), see DESIGN.md 3.1 for the measurements behind each choice:
-//  * 256x256 output tile per workgroup, 12 waves: 8 CONSUMER waves (2(M) x 4(N), wave tile 128x64 = 4x2
-//    v_mfma_i32_32x32x32_i8 accumulators = 128 registers/lane) + 4 PRODUCER waves (one per SIMD) that only
-//    issue the LDS-DMA (global_load_lds_dwordx4) of the next K-tile, so the matrix pipe's feeders never
-//    block on the VMEM queue.  168 VGPRs -> 3 waves/SIMD.
-//  * BK = 128 bytes (every DMA row segment is a full 128-B line: the global->LDS path does 127 GB/s/CU
-//    with 128-B segments, 68 with 64-B ones), 2 LDS stages x (32 KiB A + 32 KiB B).
+//  * PERSISTENT: one workgroup per CU loops over 256x256 output tiles.  12 waves: 8 CONSUMER waves (2(M) x 4(N), wave tile
+//    128x64 = 4x2 v_mfma_i32_32x32x32_i8 accumulators = 128 registers/lane) + 4 PRODUCER waves (one per SIMD) that only
+//    issue the LDS-DMA (global_load_lds_dwordx4, SGPR base + one VGPR offset per instruction), so the matrix pipe's feeders
+//    never block on the VMEM queue and spend no VALU cycles on addresses.  168 VGPRs -> 3 waves/SIMD.
+//  * BK = 128 bytes (every DMA row segment is a full 128-B line: the global->LDS path does 127 GB/s/CU with 128-B segments,
+//    68 with 64-B ones).  LDS = a 2.5-stage ring of five 32 KiB operand panels: panel h = 2g + isB of K-step g in slot h % 5;
+//    during K-step g the A producers fetch A(g+2), 2 instructions in every slot, the B producers B(g+1), 4 instructions in
+//    slots 0-3 (smooth issue matters as much as depth: see the producer branch).
 //  * LDS rows are 128 B; the 16-B chunk index is XOR-swizzled with (row>>1)&7 on the DMA SOURCE address
 //    (the destination must stay lane-linear) and on the ds_read_b128 address: every 16-lane read group hits
 //    16 distinct 16-B bank slots (SQ_LDS_BANK_CONFLICT = 0).
 //  * Ping-pong schedule: each consumer alternates a LOAD segment (6 ds_read_b128) and an MFMA segment
 //    (8 MFMAs, s_setprio 1), one s_barrier after each; the wm=1 half runs one segment behind the wm=0 half
-//    so on every SIMD one wave feeds the matrix pipe while its partner reads LDS.
-//      slot(wm=0: L_j(kt)) = 8kt+2j, M_j -> +1; wm=1 one slot later; producers issue tile kt+1 in slots
-//      8kt..8kt+3 and drain vmcnt(0) in slot 8kt+7.
-//      WAR: stage (kt+1)&1 is last read in wm=1's L3(kt-1) (slot 8kt-1) < first DMA of tile kt+1 (slot 8kt).
-//      RAW: the producers' vmcnt(0) + barrier closes slot 8kt+7; wm=0's L0(kt+1) opens slot 8kt+8.
-//  * Workgroup -> tile mapping is XCD-aware (contiguous tile range per XCD, 8-row tile groups): the 32 CUs
-//    of an XCD share 8+4 operand panels through their L2 (measured TCC hit rate 81 %).
+//    so on every SIMD one wave feeds the matrix pipe while its partner reads LDS.  With g counting K-steps across tiles:
+//      slot(wm=0: L_j(g)) = 8g+2j, M_j -> +1; wm=1 one slot later; the producers drain what K-step g+1 needs in slot 8g+7.
+//      WAR: the slots refilled during K-step g held panels of K-steps g-1 (-> B(g+1)) and g-2/g-1 (-> A(g+2)), last read in
+//           wm=1's L3(g-1) (slot 8g-1) < the first DMA of K-step g (slot 8g).
+//      RAW: the producers' vmcnt wait + barrier closes slot 8g+7; wm=0's L0(g+1) opens slot 8g+8.
+//  * Workgroup -> tile mapping is XCD-aware and chunked (oz2_gemm_common.hpp): the 32 CUs of an XCD share 8+4 operand
+//    panels through their L2 (measured TCC hit rate 81 %) and all XCDs work on one plane, so misses land in the Infinity Cache.
+//  * The layout is LDS-bandwidth bound: 192 KiB read + 64 KiB written per K-step = 2048 clocks of the 128 B/clk LDS = the
+//    2048 clocks of the K-step's MFMAs on one SIMD.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
