@@ -34,8 +34,9 @@ def parse():
     ap.add_argument("--moduli", type=int, default=14)
     ap.add_argument("--fast", action="store_true", help="fast mode (14 GEMMs) instead of accurate (15)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines (profiling runs)")
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
                     help="BASELINE.json config: 2 = DGEMM 8192^3 N=14 INT8 (headline, default); 3 = SGEMM 16384^3 N=6 FP8; "
+                         "4 = DGEMM 16384^3 N=16 INT8 (same code path as 2 at that size; meant for --gpus 8 under torch.distributed.run); "
                          "5 = ZGEMM 8192^3 N=20 INT8 (single GPU only; extra measurement lines, not the driver's metric)")
     return ap.parse_args()
 
@@ -185,7 +186,9 @@ def run_other_config(args):
 
 def main():
     args = parse()
-    if args.config != 2:
+    if args.config == 4:
+        args.size, args.moduli = 16384, 16
+    elif args.config != 2:
         return run_other_config(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -308,7 +311,7 @@ def main():
                     roof["traffic"] = rec["hbm_side_bytes_per_launch"]
                     roof["traffic_source"] = "profiles/" + os.path.basename(tf[-1])
         out = {
-            "metric": "emulated DGEMM TFLOPS (N=8192, moduli=14)", "value": value, "unit": "TFLOPS", "n_gpus": world,
+            "metric": f"emulated DGEMM TFLOPS (N={n}, moduli={N})", "value": value, "unit": "TFLOPS", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "int8", "dtype_detail": "int8 MFMA (i32 accumulate) + f64 CRT", "data": "synthetic U(-0.5,0.5), seeds 12345/54321",
             "config": {"workload": f"DGEMM {n}x{n}x{n}, moduli={N}, INT8 backend, {'fast' if args.fast else 'accurate'} mode "

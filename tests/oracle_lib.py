@@ -104,3 +104,24 @@ def gemm(A, B, N, fastmode=False, backend=INT8, opA="N", opB="N", alpha=1.0, bet
         inter = dict(sftA=sA, sftB=sB, A_lo=Alo, B_lo=Blo, C_mid=Cmid)
         return Cout, inter
     return Cout
+
+
+def accurate_shifts(A, B, N, backend=INT8):
+    """Accurate-mode shifts only (extract + bound GEMM + finalize, no modular planes): A (m x k), B (k x n) as stored for
+    op N/N.  Returns (sftA[m], sftB[n]) NEGATED like the workspace holds them.  Cheap for thin A or thin B."""
+    A = np.asfortranarray(A)
+    B = np.asfortranarray(B)
+    dt = A.dtype
+    m, k = A.shape
+    _, n = B.shape
+    cplx = dt.kind == "c"
+    parts = 3 if cplx else 1
+    Ab = np.zeros(parts * m * k, np.uint8)
+    Bb = np.zeros(parts * n * k, np.uint8)
+    sA = np.zeros(m, np.int16)
+    sB = np.zeros(n, np.int16)
+    L = lib()
+    L.oz2_extract(DT[dt], backend, 0, 0, m, k, _p(A), A.shape[0], _p(Ab), _p(sA))
+    L.oz2_extract(DT[dt], backend, 1, 0, n, k, _p(B), B.shape[0], _p(Bb), _p(sB))
+    L.oz2_bound_shifts(backend, int(cplx), N, m, n, k, _p(Ab), _p(Bb), _p(sA), _p(sB), 1, 1)
+    return sA, sB
