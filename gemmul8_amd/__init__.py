@@ -126,6 +126,8 @@ def gemm(A, B, num_moduli, fastmode=False, backend=INT8, opA="N", opB="N", alpha
     import torch
     assert A.is_cuda and B.is_cuda and A.is_contiguous() and B.is_contiguous()
     dt = A.dtype
+    if B.dtype != dt or (C_out is not None and (C_out.dtype != dt or not C_out.is_contiguous())):
+        raise TypeError("A, B and C_out must share one dtype and be contiguous")
     lda, ldb = A.shape[1], B.shape[1]
     m, k = (lda, A.shape[0]) if opA == "N" else (A.shape[0], lda)
     kb, n = (ldb, B.shape[0]) if opB == "N" else (B.shape[0], ldb)

@@ -158,8 +158,8 @@ int gemmul8_scale_bounds(void* stream_, int dtype, int backend, int op_A, int op
     if (rc) return rc;
     const size_t np = padding256(n);
     const size_t bstrideA = cplx ? L->sizeA : 0, bstrideB = cplx ? L->sizeB : 0;
-    // one memset for the maxima arrays AND the amax scratch of the first row-strided extract (they are adjacent)
-    OZ2_HIP(hipMemsetAsync(rowmax, 0, 4 * (L->mp + np) + 8 * std::max(L->mp, np), stream));
+    // one zero-fill launch for the maxima arrays AND the amax scratch of the first row-strided extract (they are adjacent)
+    OZ2_HIP(launch_zero(stream, rowmax, 4 * (L->mp + np) + 8 * std::max(L->mp, np)));
     bool amax_zero = true;
     if (!skipA) {
         OZ2_HIP(launch_extract(stream, dtype, backend, kmajA, conjA, m, k, A, lda, (int8_t*)L->A_bound, bstrideA, L->kp, L->sftA, amax, amax_zero));
@@ -349,7 +349,7 @@ int gemmul8_gemm(void* stream_, int dtype, int backend, int op_A, int op_B, size
     if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
     if (!alpha || !beta || !A || !B || !C || !work) return GEMMUL8_E_ARG;
     if (k > (size_t(1) << 17)) return GEMMUL8_E_ARG;
-    if (m == 0 || n == 0 || k == 0) return GEMMUL8_OK;  // the reference's early-out (gemmul8_real.hpp: m|n|k <= 0 -> success, C untouched)
+    if (m == 0 || n == 0 || k == 0) return GEMMUL8_OK;  // success, C untouched: what the reference's hook does (hook.cu:616-617); its gemm() itself has no check
     gemmul8_layout L;
     int rc = gemmul8_get_layout(dtype, backend, m, n, k, N, work, workA, workB, enA, enB, &L);
     if (rc) return rc;

@@ -42,6 +42,9 @@ hipError_t launch_gemm_f8_bound_cplx(hipStream_t stream, int stage, const int8_t
 // ---- scale / quantise (oz2_scale.hip).  An operand has `rows` logical rows (m for A, n for B) of
 // length k; K-major: element (r,kk) at X[r*ld+kk]; row-strided: X[kk*ld+r].  lo planes are
 // [rows_pad][kp] int8, zero-filled for kk in [k,kp).
+// zero `bytes` (a multiple of 4, 4-byte aligned) with a kernel: hipMemsetAsync nodes misbehave under HIP-graph replay on ROCm 7.2
+// (tests/test_gpu_graph.py), and a kernel launch is cheaper on the host than the runtime's memset path
+hipError_t launch_zero(hipStream_t stream, void* p, size_t bytes);
 hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajor, bool conj, size_t rows, size_t k, const void* X,
                           size_t ld, int8_t* lo, size_t part_stride, size_t kp, int16_t* sft0, void* scratch_amax, bool amax_is_zero = false);
 hipError_t launch_shift_finalize(hipStream_t stream, int backend, unsigned N, size_t rowsA, const int* maxA, int16_t* sftA, size_t rowsB,

@@ -446,6 +446,18 @@ template <int MODE> static hipError_t dispatch_stage(hipStream_t stream, int dty
     return hipErrorInvalidValue;
 }
 
+__global__ void __launch_bounds__(256) zero_words_kernel(unsigned* p, size_t nwords) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nwords) p[i] = 0u;
+}
+
+hipError_t launch_zero(hipStream_t stream, void* p, size_t bytes) {
+    const size_t nwords = bytes / 4;
+    if (nwords == 0) return hipSuccess;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, stream, (unsigned*)p, nwords);
+    return hipGetLastError();
+}
+
 hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajor, bool conj, size_t rows, size_t k, const void* X,
                           size_t ld, int8_t* lo, size_t part_stride, size_t kp, int16_t* sft0, void* scratch_amax, bool amax_is_zero) {
     if (rows == 0) return hipSuccess;
@@ -463,7 +475,7 @@ hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajo
     a.conj = conj;
     if (!kmajor) {
         const size_t ub = is_f32(dtype) ? 4 : 8;
-        hipError_t e = amax_is_zero ? hipSuccess : hipMemsetAsync(scratch_amax, 0, ub * rows, stream);
+        hipError_t e = amax_is_zero ? hipSuccess : launch_zero(stream, scratch_amax, ub * rows);
         if (e != hipSuccess) return e;
         // enough workgroups to fill the chip at every size (~2048), at least 16 k values per workgroup: the per-thread chain of
         // dependent strided loads, not bandwidth, bounds this kernel when the grid is small (42 us at 1024^2 with k/512 splits)

@@ -38,7 +38,7 @@ CONFIGS = {
 
 def make_inputs(n, dt):
     gen = torch.Generator(device=DEV).manual_seed(12345)
-    rdt = torch.float32 if dt == torch.float32 else torch.float64
+    rdt = torch.float32 if dt in (torch.float32, torch.complex64) else torch.float64
 
     def rnd():
         x = torch.rand((n, n), generator=gen, dtype=rdt, device=DEV) - 0.5
@@ -141,7 +141,7 @@ def test_fullsize_exact_on_small_integers(name):
     emulated result must equal the exact product in every element (native GEMM is exact on such data too)."""
     n, N, dt, be = CONFIGS[name]
     gen = torch.Generator(device=DEV).manual_seed(99)
-    rdt = torch.float32 if dt == torch.float32 else torch.float64
+    rdt = torch.float32 if dt in (torch.float32, torch.complex64) else torch.float64
 
     def rnd():
         x = torch.randint(-3, 4, (n, n), generator=gen, device=DEV).to(rdt)

@@ -138,6 +138,28 @@ def test_parity_long_k_int8(dtype, N):
     gu.parity_case(A, B, N, True)
 
 
+@pytest.mark.parametrize("m,n,k", [(0, 5, 7), (5, 0, 7), (5, 7, 0), (0, 0, 0)])
+@pytest.mark.parametrize("backend", ["INT8", "FP8"])
+def test_empty_dimensions_leave_c_untouched(m, n, k, backend):
+    """m, n or k == 0: success and C untouched -- the behaviour the reference defines at its hook (hook.cu:616-617; NOT the
+    BLAS beta*C semantics); the C ABI applies it to direct calls too."""
+    import ctypes as C
+    import gemmul8_amd as g
+    lib = g.lib()
+    be = getattr(g, backend)
+    Cm = torch.full((max(n, 1), max(m, 1)), 3.25, dtype=torch.float64, device="cuda")
+    A = torch.ones((max(k, 1), max(m, 1)), dtype=torch.float64, device="cuda")
+    B = torch.ones((max(n, 1), max(k, 1)), dtype=torch.float64, device="cuda")
+    al, bt = np.array([2.0]), np.array([0.0])
+    st = torch.cuda.current_stream().cuda_stream
+    work = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    rc = lib.gemmul8_gemm(st, g.D, be, 0, 0, m, n, k, al.ctypes.data, A.data_ptr(), max(m, 1), B.data_ptr(), max(k, 1),
+                          bt.ctypes.data, Cm.data_ptr(), max(m, 1), 14 if backend == "INT8" else 12, 0, work.data_ptr(), None, None, 0, 0, 0, 0, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert bool((Cm == 3.25).all())
+
+
 def test_fp8_rejects_k_beyond_exactness_bound():
     """FP8 products are only exact in FP32 for k <= 65536 (src/gemmul8_real.hpp k limit): the C ABI returns E_ARG."""
     import ctypes as C
@@ -220,3 +242,34 @@ def test_kat_sample_fp8_on_gpu():
     C = gu.hip_gemm(A, B, 13, backend=g.FP8)
     assert np.sqrt(((C - Cx) ** 2).sum()) < 4e-15
     gu.parity_case(A, B, 13, False, backend=g.FP8)
+
+
+@pytest.mark.parametrize("dt", ["float32", "float64", "complex64", "complex128"])
+@pytest.mark.parametrize("backend", ["INT8", "FP8"])
+@pytest.mark.parametrize("fast", [False, True])
+def test_result_independent_of_workspace_contents(dt, backend, fast):
+    """The workspace is scratch: whatever it holds on entry (the reference never clears it either), ragged shapes included,
+    the result must be the same bits as with a zeroed workspace."""
+    import gemmul8_amd as g
+    tdt = getattr(torch, dt)
+    be = getattr(g, backend)
+    N = {"float32": 6, "float64": 13, "complex64": 6, "complex128": 12}[dt]
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    for (m, n, k) in [(520, 392, 1031), (77, 300, 129), (257, 255, 640)]:
+        rdt = torch.float32 if dt in ("float32", "complex64") else torch.float64
+
+        def rnd(shape):
+            x = torch.rand(shape, generator=gen, dtype=rdt, device="cuda") - 0.5
+            if tdt.is_complex:
+                x = torch.complex(x, torch.rand(shape, generator=gen, dtype=rdt, device="cuda") - 0.5)
+            return x.contiguous()
+        A, B = rnd((k, m)), rnd((n, k))
+        tot, _, _ = g.work_size(tdt.is_complex, be, m, n, k, N)
+        C0, _, _ = g.gemm(A, B, N, fastmode=fast, backend=be, work=torch.zeros(tot, dtype=torch.uint8, device="cuda"))
+        for fill in ("ff", "a5", "random"):
+            if fill == "random":
+                w = torch.randint(0, 256, (tot,), generator=gen, dtype=torch.uint8, device="cuda")
+            else:
+                w = torch.full((tot,), int(fill, 16), dtype=torch.uint8, device="cuda")
+            C1, _, _ = g.gemm(A, B, N, fastmode=fast, backend=be, work=w)
+            assert torch.equal(C0.view(torch.uint8), C1.view(torch.uint8)), (m, n, k, fill)
