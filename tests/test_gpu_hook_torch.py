@@ -21,6 +21,7 @@ def _run(extra_env):
     m = re.search(r"TFLOPS, normwise err ([0-9.e+-]+)", out.stdout)
     mb = re.search(r"bmm normwise err ([0-9.e+-]+)", out.stdout)
     assert m and mb, out.stdout
+    assert "graph replay equals eager: True" in out.stdout, out.stdout   # the hooked call captured in a HIP graph and replayed
     return float(m.group(1)), float(mb.group(1))
 
 

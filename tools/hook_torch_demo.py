@@ -24,3 +24,20 @@ torch.cuda.synchronize()
 refb = X[b - 1].cpu().numpy().astype("longdouble") @ Y[b - 1].cpu().numpy().astype("longdouble")
 errb = float(abs(Z[b - 1].cpu().numpy() - refb).max() / abs(refb).max())
 print(f"torch.bmm {b} x {nb}^3: bmm normwise err {errb:.2e}")
+
+# HIP-graph capture of a hooked matmul (torch.cuda.graph warms nothing up by itself: run once on a side stream first)
+s = torch.cuda.Stream()
+s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(s):
+    Cg = A @ B
+torch.cuda.current_stream().wait_stream(s)
+torch.cuda.synchronize()
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph, stream=s):
+    Cg = A @ B
+A.mul_(2.0)
+graph.replay()
+torch.cuda.synchronize()
+Ce = A @ B
+torch.cuda.synchronize()
+print(f"graph replay equals eager: {bool(torch.equal(Cg, Ce))}")
