@@ -138,6 +138,26 @@ def test_parity_long_k_int8(dtype, N):
     gu.parity_case(A, B, N, True)
 
 
+@pytest.mark.parametrize("backend,dtype,N,k", [("INT8", np.float64, 15, 1 << 17), ("INT8", np.complex64, 7, 1 << 17),
+                                               ("FP8", np.float32, 7, 1 << 16), ("FP8", np.complex128, 13, 1 << 16)])
+def test_parity_at_the_k_limits(backend, dtype, N, k):
+    """The largest inner dimension each backend accepts (INT8: 2^17, the reference's int32 accumulation limit; FP8: 2^16, exact
+    FP32 accumulation of e4m3 products): one past it is E_ARG, at it the result is bit-exact against the oracle."""
+    import gemmul8_amd as g
+    import gpu_util as gu
+    rng = np.random.default_rng(k % 1000 + N)
+    m, n = 9, 6
+    A, B = rand((m, k), dtype, rng, phi=0.5), rand((k, n), dtype, rng, phi=0.5)
+    be = getattr(g, backend)
+    gu.parity_case(A, B, N, False, backend=be)
+    gu.parity_case(A, B, N, True, backend=be)
+    tdt = {np.float64: torch.float64, np.float32: torch.float32, np.complex64: torch.complex64, np.complex128: torch.complex128}[dtype]
+    A1 = torch.zeros((k + 1, m), dtype=tdt, device="cuda")
+    B1 = torch.zeros((n, k + 1), dtype=tdt, device="cuda")
+    with pytest.raises(Exception):
+        g.gemm(A1, B1, N, backend=be)
+
+
 @pytest.mark.parametrize("m,n,k", [(0, 5, 7), (5, 0, 7), (5, 7, 0), (0, 0, 0)])
 @pytest.mark.parametrize("backend", ["INT8", "FP8"])
 def test_empty_dimensions_leave_c_untouched(m, n, k, backend):
