@@ -147,17 +147,15 @@ __device__ __forceinline__ int mod_i32_sym(int a, int p, int pinv32) {
     return wrapping(rem, p);
 }
 
-// The same residue for ODD p and |a| <= 2^30 (k <= 65536) with full-rate instructions only (v_mul_hi/v_mul_lo_u32 are
-// quarter rate): two fp32 quotient steps.  Step 1: q = rint(float(a)/p) is off by at most 2 (float(a) is exact to
-// 2^-24 relative, |a|/p < 2^23 so q*p is a 24-bit multiply), leaving |r| <= 2.5 p.  Step 2 is exact: float(r) is exact
-// and r/p is at least 1/(2p) away from a rounding tie for odd p, so the result is the canonical representative in
-// [-(p-1)/2, (p-1)/2] -- identical to mod_i32_sym (checked exhaustively over residue classes in tests/test_cabi.py
-// through the oracle and bit-for-bit by the GPU parity tests).
-__device__ __forceinline__ int mod_i32_sym_odd(int a, int p, float invp) {
-    int q = (int)rintf((float)a * invp);
-    const int r = a - __mul24(q, p);
-    q = (int)rintf((float)r * invp);
-    return r - __mul24(q, p);
+// The same residue for ODD p and ANY int32 a with full-rate instructions only (v_mul_hi/v_mul_lo_u32 are quarter rate; FP64
+// VALU runs at the FP32 rate on gfx950): ONE quotient step in FP64.  a*invp is within 2^-21 of a/p, which is at least 1/(2p)
+// away from a rounding tie for odd p, so q = rint(a/p) exactly and a - q*p (integers below 2^53: the fma is exact) is the
+// canonical representative in [-(p-1)/2, (p-1)/2] -- identical to mod_i32_sym (CPU model over the whole int32 range in
+// tests/test_residue_math.py, bit-for-bit by the GPU parity tests).  Five instructions against ten for two fp32 steps.
+__device__ __forceinline__ int mod_i32_sym_odd_f64(int a, double p, double invp) {
+    const double x = (double)a;
+    const double q = rint(x * invp);
+    return (int)fma(-q, p, x);
 }
 // |a| < 2^16: one exact step
 __device__ __forceinline__ int mod_small_sym_odd(int a, int p, float invp) {

@@ -70,10 +70,9 @@ constexpr int F8_THREADS = 512;
 #endif
 constexpr int F8_PB = OZ2_F8_PB;  // LOAD segments (of 4) over which a B wave spreads its 8 DMA instructions
 
-// int16 residue epilogues (EPI_PART / EPI_FINAL) of a wave's 128 x 64 accumulator block.  ODD: odd modulus -- residues in
-// fp32 (accumulators are exact integers, |c| <= 2^24): q = rint(c/p) may be off by one near a rounding tie (error
-// 2^-23 * 2^24/p against a tie distance of 1/2p), a second step on |r| <= 1.5 p is exact; the combined value (|v| < 2^18)
-// needs one step.  p = 1024 (even: the tie +-512 must keep the reference's representative) takes the integer path.
+// int16 residue epilogues (EPI_PART / EPI_FINAL) of a wave's 128 x 64 accumulator block.  ODD: odd modulus -- the accumulators are
+// exact integers (|c| <= 2^24): one exact FP64 quotient step (five full-rate instructions); the combined value (|v| < 2^18)
+// needs one fp32 step.  p = 1024 (even: the tie +-512 must keep the reference's representative) takes the integer path.
 template <int EPI, bool ODD>
 __device__ __forceinline__ void f8_epilogue_mod(const v16f (&acc)[4][2], const F8Args& args, int plane, int i0, int j0, int lane) {
     const int frow = lane & 31;
@@ -86,12 +85,11 @@ __device__ __forceinline__ void f8_epilogue_mod(const v16f (&acc)[4][2], const F
     const int k1 = t < 6 ? k0 : -15;
     const int k2 = t < 6 ? 1 : 16;
     const float pf = (float)p, invp = 1.0f / pf;
+    const double pd = (double)p, invpd = 1.0 / pd;
     auto red_acc = [&](float c) -> int {
         if constexpr (ODD) {
-            float q = rintf(c * invp);
-            const float r = fmaf(-q, pf, c);
-            q = rintf(r * invp);
-            return (int)fmaf(-q, pf, r);
+            const double x = (double)c;  // one exact FP64 quotient step (oz2_device.hpp, mod_i32_sym_odd_f64)
+            return (int)fma(-rint(x * invpd), pd, x);
         } else {
             return mod_i32_sym(__float2int_rn(c), p, pinv);
         }

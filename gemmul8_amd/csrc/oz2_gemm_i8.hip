@@ -73,12 +73,18 @@ struct GemmArgs {
 // Epilogues on a wave's 128 x (32*NJ) accumulator block (first row i0, first column j0).  Accumulator map of
 // v_mfma_i32_32x32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); MFMA rows <-> C rows i (A_lo rows),
 // MFMA cols <-> C cols j.
+#ifndef OZ2_PROBE_LDS
+#define OZ2_PROBE_LDS 0  // timing probes on REAL data (wrong results; tools/README.md): bit 0/1 B/A fragments re-read at ks == 0 only, bit 2 DMA in the
+                        // first tile only, bit 3 no epilogue; 0 in every shipped build
+#endif
 #ifndef OZ2_ABL_EPI
 #define OZ2_ABL_EPI 0  // 1: no stores, 2: every plane takes the p = 256 path (timing ablations only)
 #endif
 enum { RED_GENERIC = 0, RED_ODD = 1, RED_256 = 2 };
 // RED selects how an accumulator is reduced (uniform per plane): RED_256: p = 256, the symmetric residue IS the low byte;
-// RED_ODD: odd p and k <= 65536, two-step fp32 quotient (full-rate VALU only); RED_GENERIC: 32-bit multiply-high.
+// RED_ODD: odd p, ONE exact FP64 quotient step for any int32 accumulator (5 full-rate instructions: FP64 VALU runs at the FP32
+// rate on gfx950; the two-step fp32 form it replaced cost 10 and 12 % of the kernel time at k = 1024); RED_GENERIC: 32-bit
+// multiply-high (even p other than 256: no INT8 modulus, kept for completeness).
 template <int EPI, int NJ, int RED>
 __device__ __forceinline__ void i8_epilogue_mod(const v16i (&acc)[4][NJ], const GemmArgs& args, int plane, int i0, int j0, int lane) {
     const int frow = lane & 31;
@@ -87,9 +93,10 @@ __device__ __forceinline__ void i8_epilogue_mod(const v16i (&acc)[4][NJ], const 
     const int p = args.moduli[t];
     const int pinv = args.pinv32[t];
     const float invp = 1.0f / (float)p;
+    [[maybe_unused]] const double pd = (double)p, invpd = 1.0 / (double)p;
     auto red = [&](int x) {
         if constexpr (RED == RED_256) return x;
-        else if constexpr (RED == RED_ODD) return mod_i32_sym_odd(x, p, invp);
+        else if constexpr (RED == RED_ODD) return mod_i32_sym_odd_f64(x, pd, invpd);
         else return mod_i32_sym(x, p, pinv);
     };
     auto red_small = [&](int x) {
@@ -157,7 +164,7 @@ __device__ __forceinline__ void i8_epilogue(const v16i (&acc)[4][NJ], const Gemm
     if constexpr (EPI == EPI_MOD || EPI == EPI_CPLX) {
         const int p = args.moduli[args.t_begin + plane];
         if (p == 256 || OZ2_ABL_EPI == 2) i8_epilogue_mod<EPI, NJ, RED_256>(acc, args, plane, i0, j0, lane);
-        else if ((p & 1) && args.kp * args.nseg <= 65536) i8_epilogue_mod<EPI, NJ, RED_ODD>(acc, args, plane, i0, j0, lane);
+        else if (p & 1) i8_epilogue_mod<EPI, NJ, RED_ODD>(acc, args, plane, i0, j0, lane);
         else i8_epilogue_mod<EPI, NJ, RED_GENERIC>(acc, args, plane, i0, j0, lane);
     } else {
         // column max over this lane's 64 rows (masked to valid rows), then across the two lane halves
@@ -305,7 +312,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
             for (int kt = 0; kt < KT; ++kt) {
                 // A producers: A(g+2); B producers: B(g+1); afterwards the panel needed NEXT K-step must have landed, which
                 // for the A producers means everything except the 16 instructions just issued
-                const bool issued = more;
+                const bool issued = more && (!(OZ2_PROBE_LDS & 4) || vb == (int)blockIdx.x);  // probe bit 2: DMA during the first tile only
                 if (issued) PRODUCER_BEGIN();
 #pragma unroll
                 for (int sl = 0; sl < 8; ++sl) {
@@ -364,14 +371,21 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
             const char* curA = smem + sA * TILE_BYTES + a_base;
             const char* curB = smem + (sA == 4 ? 0 : sA + 1) * TILE_BYTES + b_base;
             sA = sA + 2 >= 5 ? sA - 3 : sA + 2;
+#if OZ2_PROBE_LDS
+            v4i af[4], bf[2];  // timing probe only (wrong results): fragments re-read only at ks == 0 (bit 0: B, bit 1: A)
+#endif
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int coff = (((ks << 1) | khalf) ^ sw) << 4;
+#if !OZ2_PROBE_LDS
                 v4i af[4], bf[2];
+#endif
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = *(const v4i*)(curA + i * 32 * BK + coff);
+                for (int i = 0; i < 4; ++i)
+                    if (!(OZ2_PROBE_LDS & 2) || ks == 0) af[i] = *(const v4i*)(curA + i * 32 * BK + coff);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf[j] = *(const v4i*)(curB + j * 32 * BK + coff);
+                for (int j = 0; j < 2; ++j)
+                    if (!(OZ2_PROBE_LDS & 1) || ks == 0) bf[j] = *(const v4i*)(curB + j * 32 * BK + coff);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -388,7 +402,15 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
             }
         }
         const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n);
+#if OZ2_PROBE_LDS & 8
+        (void)tmap;  // probe bit 3: no epilogue; the accumulators stay live
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+#else
         i8_epilogue<EPI, 2>(acc, args, tmap.plane, tmap.tm * BM + wm * 128, tmap.tn * BN + wn * 64, lane);
+#endif
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();
 }

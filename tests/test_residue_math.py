@@ -1,6 +1,6 @@
-"""CPU model of the full-rate fp32 residue reduction used by the INT8 GEMM epilogue (oz2_device.hpp: mod_i32_sym_odd,
-mod_small_sym_odd) checked against exact integer arithmetic.  numpy float32 multiply / rint are the same IEEE operations
-the kernel is compiled to (-ffp-contract=off, v_mul_f32 + v_rndne_f32)."""
+"""CPU model of the floating-point residue reductions used by the GEMM epilogues and the quantise kernels (oz2_device.hpp:
+mod_i32_sym_odd_f64, mod_small_sym_odd, residue_sym_bytes*) checked against exact integer arithmetic.  numpy float32 / float64
+multiply, rint and fma-free differences are the same IEEE operations the kernels are compiled to (-ffp-contract=off)."""
 import numpy as np
 import pytest
 
@@ -13,12 +13,13 @@ def sym_exact(a, p):
 
 
 def model_odd(a, p):
-    invp = np.float32(1.0) / np.float32(p)
-    q = np.rint(a.astype(np.float32) * invp).astype(np.int64)
-    assert np.all(np.abs(q) < 2 ** 23), "24-bit multiply operand out of range"
-    r = a - q * p
-    q2 = np.rint(r.astype(np.float32) * invp).astype(np.int64)
-    return r - q2 * p
+    """mod_i32_sym_odd_f64: ONE FP64 quotient step, exact for every int32 (v_cvt_f64_i32, v_mul_f64, v_rndne_f64, v_fma_f64)."""
+    invp = np.float64(1.0) / np.float64(p)
+    x = a.astype(np.float64)
+    q = np.rint(x * invp)
+    r = x - q * np.float64(p)          # = fma(-q, p, x): both are exact here (integers below 2^53)
+    assert np.all(r == np.rint(r))
+    return r.astype(np.int64)
 
 
 def test_moduli_table_matches():
@@ -31,9 +32,9 @@ def test_moduli_table_matches():
 
 
 @pytest.mark.parametrize("p", [m for m in INT8_MODULI if m & 1])
-def test_two_step_fp32_reduction_is_exact(p):
+def test_one_step_fp64_reduction_is_exact(p):
     rng = np.random.default_rng(p)
-    lim = 2 ** 30
+    lim = 2 ** 31 - 1
     parts = [rng.integers(-lim, lim + 1, size=2_000_000, dtype=np.int64),
              np.arange(-lim, -lim + 70_000, dtype=np.int64), np.arange(lim - 70_000, lim + 1, dtype=np.int64),
              np.arange(-70_000, 70_000, dtype=np.int64)]
