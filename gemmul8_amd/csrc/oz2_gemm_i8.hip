@@ -35,8 +35,8 @@
 //      RAW: the producers' vmcnt wait + barrier closes slot 8g+7; wm=0's L0(g+1) opens slot 8g+8.
 //  * Workgroup -> tile mapping is XCD-aware and chunked (oz2_gemm_common.hpp): the 32 CUs of an XCD share 8+4 operand
 //    panels through their L2 (measured TCC hit rate 81 %) and all XCDs work on one plane, so misses land in the Infinity Cache.
-//  * The layout is LDS-bandwidth bound: 192 KiB read + 64 KiB written per K-step = 2048 clocks of the 128 B/clk LDS = the
-//    2048 clocks of the K-step's MFMAs on one SIMD.
+//  * Cost split measured with real-data probes (OZ2_PROBE_LDS): MFMA + barriers alone run at the board's
+//    power-limited 3.3-3.4 POP/s; the L2 -> LDS operand path costs 12 %, the epilogue 6 %, the LDS reads 4 %.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -82,9 +82,11 @@ struct GemmArgs {
 #endif
 enum { RED_GENERIC = 0, RED_ODD = 1, RED_256 = 2 };
 // RED selects how an accumulator is reduced (uniform per plane): RED_256: p = 256, the symmetric residue IS the low byte;
-// RED_ODD: odd p, ONE exact FP64 quotient step for any int32 accumulator (5 full-rate instructions: FP64 VALU runs at the FP32
-// rate on gfx950; the two-step fp32 form it replaced cost 10 and 12 % of the kernel time at k = 1024); RED_GENERIC: 32-bit
-// multiply-high (even p other than 256: no INT8 modulus, kept for completeness).
+// RED_ODD: odd p, ONE exact FP64 quotient step for any int32 accumulator (v_cvt_f64_i32, v_mul_f64, v_rndne_f64, v_fma_f64,
+// v_cvt_i32_f64: FP64 VALU runs at the FP32 rate on gfx950); the two-step fp32 form it replaced cost 10 instructions and 12 % of
+// the kernel time at k = 1024.  (Reading the quotient from the low dword of fma(a, 1/p, 1.5 * 2^52) and finishing with
+// v_mad_i32_i24 -- three instructions -- measured 10 % SLOWER at k = 1024: the dependent FP64 chains no longer overlap.)
+// RED_GENERIC: 32-bit multiply-high (even p other than 256: no INT8 modulus, kept for completeness).
 template <int EPI, int NJ, int RED>
 __device__ __forceinline__ void i8_epilogue_mod(const v16i (&acc)[4][NJ], const GemmArgs& args, int plane, int i0, int j0, int lane) {
     const int frow = lane & 31;
@@ -104,6 +106,11 @@ __device__ __forceinline__ void i8_epilogue_mod(const v16i (&acc)[4][NJ], const 
         else if constexpr (RED == RED_ODD) return mod_small_sym_odd(x, p, invp);
         else return mod_i32_sym(x, p, pinv);
     };
+    // one 64-bit element offset per lane for the whole block (first of 16 consecutive rows of column j0 + frow); the (i, j) sub-tiles
+    // add i * 32 and j * 32 * ldo -- no per-store multiplies (v_mul_lo_u32 / v_mad_u64_u32 are quarter rate)
+    const size_t e00 = (size_t)(j0 + frow) * args.ldo + i0 + khalf * 16;
+    const size_t po = (size_t)__builtin_amdgcn_readfirstlane(plane) * args.strideO, pr = (size_t)__builtin_amdgcn_readfirstlane(plane) * args.strideR;  // wave-uniform: scalar multiplies
+    const size_t ejs = (size_t)32 * args.ldo;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int col = j0 + j * 32 + frow;
@@ -112,25 +119,25 @@ __device__ __forceinline__ void i8_epilogue_mod(const v16i (&acc)[4][NJ], const 
             unsigned d[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                unsigned w = 0;
+                int r[4];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int r = red(acc[i][j][q * 4 + b]);
-                    w |= ((unsigned)r & 0xFFu) << (8 * b);
-                }
-                d[q] = w;
+                for (int b = 0; b < 4; ++b) r[b] = red(acc[i][j][q * 4 + b]);
+                // low bytes of four residues -> one dword with two v_perm_b32 and an OR (selector bytes: 0-3 = second operand,
+                // 4-7 = first operand, 0x0c = zero)
+                d[q] = __builtin_amdgcn_perm((unsigned)r[1], (unsigned)r[0], 0x0c0c0400u) |
+                       __builtin_amdgcn_perm((unsigned)r[3], (unsigned)r[2], 0x04000c0cu);
             }
             // lane-half h owns rows 8q+4h..+3.  Exchange so that h=0 owns rows 0..15 and h=1 rows 16..31.
             auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
             auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
             const unsigned z[4] = {s0[0], s0[1], s1[0], s1[1]};
             if (col < args.n && !(OZ2_ABL_EPI == 1 && args.kp > 0)) {
-                const size_t e = (size_t)col * args.ldo + i0 + i * 32 + khalf * 16;  // first of 16 consecutive rows
+                const size_t e = e00 + j * ejs + i * 32;  // first of 16 consecutive rows
                 if constexpr (EPI == EPI_MOD) {
-                    *(uint4*)(args.out + (size_t)plane * args.strideO + e) = make_uint4(z[0], z[1], z[2], z[3]);
+                    *(uint4*)(args.out + po + e) = make_uint4(z[0], z[1], z[2], z[3]);
                 } else {
-                    const uint4 x4 = *(const uint4*)(args.rx + (size_t)plane * args.strideR + e);
-                    const uint4 y4 = *(const uint4*)(args.ry + (size_t)plane * args.strideR + e);
+                    const uint4 x4 = *(const uint4*)(args.rx + pr + e);
+                    const uint4 y4 = *(const uint4*)(args.ry + pr + e);
                     const unsigned xs[4] = {x4.x, x4.y, x4.z, x4.w}, ys[4] = {y4.x, y4.y, y4.z, y4.w};
                     unsigned o[8];
 #pragma unroll
@@ -147,7 +154,7 @@ __device__ __forceinline__ void i8_epilogue_mod(const v16i (&acc)[4][NJ], const 
                         o[2 * w4] = lo;
                         o[2 * w4 + 1] = hi;
                     }
-                    uint4* dst = (uint4*)(args.out + (size_t)plane * args.strideO + 2 * e);
+                    uint4* dst = (uint4*)(args.out + po + 2 * e);
                     dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
                     dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
                 }

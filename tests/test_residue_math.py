@@ -188,3 +188,4 @@ def test_wide_byte_dot_residue_fp8_moduli(p):
             hi = sum(((Xt >> (8 * i)) & 0xFF) * (c[i] >> 5) for i in range(15))
             s_list.append(lo + 32 * hi)
         assert np.array_equal(finish(s_list), np.array([sym(-(M << E) if neg else (M << E)) for M, E in zip(Ms, Es)]))
+
