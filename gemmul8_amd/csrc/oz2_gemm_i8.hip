@@ -73,9 +73,12 @@ struct GemmArgs {
 // Epilogues on a wave's 128 x (32*NJ) accumulator block (first row i0, first column j0).  Accumulator map of
 // v_mfma_i32_32x32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); MFMA rows <-> C rows i (A_lo rows),
 // MFMA cols <-> C cols j.
+#ifndef OZ2_DMA_AUX
+#define OZ2_DMA_AUX 0  // cache-policy bits of the LDS-DMA loads (1 = sc0, 2 = nt, 16 = sc1): sc0/sc1 measured neutral, nt 10 % slower
+#endif
 #ifndef OZ2_PROBE_LDS
 #define OZ2_PROBE_LDS 0  // timing probes on REAL data (wrong results; tools/README.md): bit 0/1 B/A fragments re-read at ks == 0 only, bit 2 DMA in the
-                        // first tile only, bit 3 no epilogue; 0 in every shipped build
+                        // first tile only, bit 3 no epilogue, bit 4 operands from the first 8 K-steps only (L2 hits); 0 in every shipped build
 #endif
 #ifndef OZ2_ABL_EPI
 #define OZ2_ABL_EPI 0  // 1: no stores, 2: every plane takes the p = 256 path (timing ablations only)
@@ -269,7 +272,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     } while (0)
 #define PRODUCER_DMA(src_, q_, stage_)                                                                                       \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((src_) + doff[q_]),                     \
-                                     (__attribute__((address_space(3))) void*)((stage_) + (pw * 16 + (q_)) * 1024), 16, 0, 0)
+                                     (__attribute__((address_space(3))) void*)((stage_) + (pw * 16 + (q_)) * 1024), 16, 0, OZ2_DMA_AUX)
 
         // 2.5-stage ring of operand panels (5 x 32 KiB = all 160 KiB of LDS): panel h = 2 g + isB lives in slot h % 5.  The slot of
         // A(g') held B(g'-3) and the slot of B(g') held A(g'-2), so during K-step g the A producers may fetch A(g+2) and the B
@@ -282,7 +285,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
         int hs = isB ? 1 : 0;      // its slot
 #define PRODUCER_BEGIN()                                                                                                     \
     do {                                                                                                                     \
-        fsrc = (seg == 0 ? g0 : seg == 1 ? g1 : g2) + (size_t)kin * BK;                                                      \
+        fsrc = (seg == 0 ? g0 : seg == 1 ? g1 : g2) + (size_t)((OZ2_PROBE_LDS & 16) ? (kin & 7) : kin) * BK; /* probe bit 4: L2-resident operands */ \
         fdst = smem + hs * TILE_BYTES - (isB ? TILE_BYTES : 0);   /* PRODUCER_DMA adds pw * 16 KiB */                         \
     } while (0)
 #define PRODUCER_ADVANCE()                                                                                                   \
