@@ -58,7 +58,6 @@ struct F8Args {
     float ku;             // (k+1) * 2^-24
     int total_tiles;      // planes * tiles_m * tiles_n
     int moduli[20];
-    int pinv32[20];
     int sqrtp[6];
 };
 
@@ -72,14 +71,13 @@ constexpr int F8_PB = OZ2_F8_PB;  // LOAD segments (of 4) over which a B wave sp
 
 // int16 residue epilogues (EPI_PART / EPI_FINAL) of a wave's 128 x 64 accumulator block.  ODD: odd modulus -- the accumulators are
 // exact integers (|c| <= 2^24): one exact FP64 quotient step (five full-rate instructions); the combined value (|v| < 2^18)
-// needs one fp32 step.  p = 1024 (even: the tie +-512 must keep the reference's representative) takes the integer path.
+// needs one fp32 step.  p = 1024 (the only even FP8 modulus; the tie +-512 keeps the reference's representative +512): ((a + 511) & 1023) - 511.
 template <int EPI, bool ODD>
 __device__ __forceinline__ void f8_epilogue_mod(const v16f (&acc)[4][2], const F8Args& args, int plane, int i0, int j0, int lane) {
     const int frow = lane & 31;
     const int khalf = lane >> 5;
     const int t = args.t_begin + plane;
     const int p = args.moduli[t];
-    const int pinv = args.pinv32[t];
     // value = k0*R0 + k1*R1 + k2*R2:  square moduli s*(R0+R1) + R2;  Karatsuba 256*R0 + 16*(R2-R0-R1) + R1
     const int k0 = t < 6 ? args.sqrtp[t < 6 ? t : 0] : 240;
     const int k1 = t < 6 ? k0 : -15;
@@ -91,7 +89,7 @@ __device__ __forceinline__ void f8_epilogue_mod(const v16f (&acc)[4][2], const F
             const double x = (double)c;  // one exact FP64 quotient step (oz2_device.hpp, mod_i32_sym_odd_f64)
             return (int)fma(-rint(x * invpd), pd, x);
         } else {
-            return mod_i32_sym(__float2int_rn(c), p, pinv);
+            return ((__float2int_rn(c) + 511) & 1023) - 511;  // p = 1024, representative in (-512, 512]
         }
     };
     auto red_small = [&](int v) -> int {
@@ -99,7 +97,7 @@ __device__ __forceinline__ void f8_epilogue_mod(const v16f (&acc)[4][2], const F
             const float vf = (float)v;
             return (int)fmaf(-rintf(vf * invp), pf, vf);
         } else {
-            return mod_i32_sym(v, p, pinv);
+            return ((v + 511) & 1023) - 511;
         }
     };
 #pragma unroll
@@ -445,7 +443,6 @@ static void fill_common(F8Args& a, size_t kp, size_t m, size_t n) {
     for (int t = 0; t < 20; ++t) {
         const int p = GEMMUL8_MODULI_FP8[t];
         a.moduli[t] = p;
-        a.pinv32[t] = (int)(4294967296ull / (unsigned long long)p);
     }
     for (int t = 0; t < 6; ++t) a.sqrtp[t] = GEMMUL8_SQRT_MODULI_FP8[t];
 }
