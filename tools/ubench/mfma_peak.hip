@@ -13,24 +13,34 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-template <bool F8> __global__ void __launch_bounds__(512) spin(int iters, int zero, int* sink) {
+template <bool F8, bool AG = false, bool ROT = false> __global__ void __launch_bounds__(512) spin(int iters, int zero, int* sink) {
     unsigned s = zero ? 0u : (threadIdx.x * 2654435761u + blockIdx.x * 40503u) | 1u;
     auto rnd = [&]() {
         s ^= s << 13, s ^= s >> 17, s ^= s << 5;
         return (int)(zero ? 0u : (F8 ? (s & 0x3F3F3F3Fu) : s));   // FP8: keep the e4m3 bytes finite and small
     };
     if constexpr (!F8) {
-        v4i a[4], b[2];
-        for (auto& x : a) x = v4i{rnd(), rnd(), rnd(), rnd()};
-        for (auto& x : b) x = v4i{rnd(), rnd(), rnd(), rnd()};
+        // ROT: four operand sets used in turn (like the four sub-steps of a K-step): the operand buses toggle as in a real GEMM
+        constexpr int SETS = ROT ? 4 : 1;
+        v4i as[SETS][4], bs[SETS][2];
+        for (auto& st : as)
+            for (auto& x : st) x = v4i{rnd(), rnd(), rnd(), rnd()};
+        for (auto& st : bs)
+            for (auto& x : st) x = v4i{rnd(), rnd(), rnd(), rnd()};
         v16i acc[4][2] = {};
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u) {
+                const v4i(&a)[4] = as[ROT ? u : 0];
+                const v4i(&b)[2] = bs[ROT ? u : 0];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) {
+                        if constexpr (AG) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(a[i]), "v"(b[j]));  // accumulators in AccVGPRs
+                        else acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+                    }
+            }
         }
         int t = 0;
         for (int i = 0; i < 4; ++i)
@@ -61,6 +71,8 @@ int main(int argc, char** argv) {
     const double secs = argc > 1 ? atof(argv[1]) : 3.0;
     const bool f8 = argc > 2 && !strcmp(argv[2], "f8");
     const int zero = argc > 3 && !strcmp(argv[3], "zero");
+    const bool rot = argc > 3 && !strcmp(argv[3], "rot");     // i8 only: four rotating operand sets
+    const bool agpr = argc > 3 && !strcmp(argv[3], "agpr");   // i8 only: accumulators in AccVGPRs (random operands)
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     int* sink;
@@ -69,6 +81,8 @@ int main(int argc, char** argv) {
     const double ops_per_launch = (double)p.multiProcessorCount * 8 * iters * (f8 ? 16.0 * 2 * 32 * 32 * 64 : 32.0 * 2 * 32 * 32 * 32);
     auto launch = [&]() {
         if (f8) hipLaunchKernelGGL(spin<true>, dim3(p.multiProcessorCount), dim3(512), 0, 0, iters, zero, sink);
+        else if (agpr) hipLaunchKernelGGL((spin<false, true>), dim3(p.multiProcessorCount), dim3(512), 0, 0, iters, zero, sink);
+        else if (rot) hipLaunchKernelGGL((spin<false, false, true>), dim3(p.multiProcessorCount), dim3(512), 0, 0, iters, zero, sink);
         else hipLaunchKernelGGL(spin<false>, dim3(p.multiProcessorCount), dim3(512), 0, 0, iters, zero, sink);
     };
     launch();
