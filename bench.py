@@ -3,8 +3,10 @@
 
 One "step" = one whole emulated DGEMM C = A*B (8192^3, FP64 in/out, 14 moduli, INT8 MFMA backend,
 accurate mode = the reference's default: 15 INT8 GEMMs) with A, B already resident in HBM.
-N>1: the moduli are sharded over the ranks (gemmul8_amd.dist), residue planes are exchanged over
-RCCL and every rank finishes the columns it owns ("strong" scaling: the problem is fixed).
+N>1 (one process per GPU under torch.distributed.run, RCCL): the output is sharded in blocks over a rank grid
+(gemmul8_amd.dist.BlockShardedGemm: every rank runs all moduli on its block; one all_reduce(MAX) of the row/column
+bounds); GEMMUL8_DIST_SHARD=moduli selects the moduli-sharded plan with a residue all-to-all instead.  "strong"
+scaling: the problem is fixed, value = 2*n^3 / (max over ranks of the step time).
 
 Prints ONE JSON line (rank 0) with the driver's contract keys plus `roofline` (dominant kernel =
 the batched INT8 MFMA GEMM, events recorded on the launch stream inside the timed region),
@@ -20,6 +22,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's host driver only supports dmabuf IPC (RCCL needs it)
 
 import numpy as np
 import torch
