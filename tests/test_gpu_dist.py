@@ -60,3 +60,31 @@ def test_two_ranks_one_gpu_bitwise(N, fast, exchange):
         p.join(300)
         assert p.exitcode == 0
     assert q.get(timeout=10)
+
+
+@pytest.mark.parametrize("shard,ranks", [("blocks", 2), ("moduli", 2), ("blocks", 8)])
+def test_bench_multi_rank_contract(shard, ranks):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per process), here with 2 or 8 ranks sharing
+    the box's single GPU over gloo (GEMMUL8_DIST_BACKEND: NCCL refuses duplicate devices): one JSON line from rank 0 with the
+    contract keys, the right rank count and an accurate result."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, GEMMUL8_DIST_BACKEND="gloo", GEMMUL8_DIST_SHARD=shard)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1",
+                          "--size", "1024"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == ranks and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["max_rel_err"] < 1e-9
