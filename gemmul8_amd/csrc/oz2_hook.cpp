@@ -392,6 +392,92 @@ hipblasStatus_t hipblasGemmEx(hipblasHandle_t handle, hipblasOperation_t transA,
                 : HIPBLAS_STATUS_NOT_INITIALIZED;
 }
 
+// ROCm 7 also exports ILP64 twins (`_64`, int64_t dimensions) and hipblasGemmExWithFlags of the entry points above; the
+// reference's CUDA-side hook predates them.  Same emulation when every dimension fits an int, the native routine otherwise.
+static inline bool fits_int(int64_t a, int64_t b, int64_t c, int64_t d, int64_t e, int64_t f) {
+    const int64_t lim = 2147483647;
+    return a <= lim && b <= lim && c <= lim && d <= lim && e <= lim && f <= lim;
+}
+#define OZ2_GEMM_HOOK_64(NAME, T, CODE)                                                                                                  \
+    hipblasStatus_t NAME(hipblasHandle_t handle, hipblasOperation_t transA, hipblasOperation_t transB, int64_t m, int64_t n, int64_t k,   \
+                         const T* alpha, const T* A, int64_t lda, const T* B, int64_t ldb, const T* beta, T* C, int64_t ldc) {            \
+        OZ2_EARLY_OUT()                                                                                                                   \
+        hipblasStatus_t st;                                                                                                               \
+        if (fits_int(m, n, k, lda, ldb, ldc) &&                                                                                           \
+            try_emulate(CODE, handle, transA, transB, (int)m, (int)n, (int)k, alpha, A, (int)lda, B, (int)ldb, beta, C, (int)ldc, &st))   \
+            return st;                                                                                                                    \
+        using Fn = hipblasStatus_t (*)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int64_t, int64_t, int64_t, const T*,      \
+                                       const T*, int64_t, const T*, int64_t, const T*, T*, int64_t);                                      \
+        static Fn real = real_fn<Fn>(#NAME);                                                                                              \
+        return real ? real(handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc) : HIPBLAS_STATUS_NOT_INITIALIZED;        \
+    }
+OZ2_GEMM_HOOK_64(hipblasSgemm_64, float, GEMMUL8_S)
+OZ2_GEMM_HOOK_64(hipblasDgemm_64, double, GEMMUL8_D)
+OZ2_GEMM_HOOK_64(hipblasCgemm_64, hipComplex, GEMMUL8_C)
+OZ2_GEMM_HOOK_64(hipblasZgemm_64, hipDoubleComplex, GEMMUL8_Z)
+#undef OZ2_GEMM_HOOK_64
+
+static int gemm_ex_dtype(hipDataType aType, hipDataType bType, hipDataType cType, hipblasComputeType_t computeType) {
+    const bool same = (aType == bType && bType == cType);  // same (computeType, A/B/C type) dispatch as hook.cu:961-1030
+    if (same && computeType == HIPBLAS_COMPUTE_32F && aType == HIP_R_32F) return GEMMUL8_S;
+    if (same && computeType == HIPBLAS_COMPUTE_64F && aType == HIP_R_64F) return GEMMUL8_D;
+    if (same && computeType == HIPBLAS_COMPUTE_32F && aType == HIP_C_32F) return GEMMUL8_C;
+    if (same && computeType == HIPBLAS_COMPUTE_64F && aType == HIP_C_64F) return GEMMUL8_Z;
+    return -1;
+}
+
+hipblasStatus_t hipblasGemmExWithFlags(hipblasHandle_t handle, hipblasOperation_t transA, hipblasOperation_t transB, int m, int n, int k,
+                                       const void* alpha, const void* A, hipDataType aType, int lda, const void* B, hipDataType bType, int ldb,
+                                       const void* beta, void* C, hipDataType cType, int ldc, hipblasComputeType_t computeType,
+                                       hipblasGemmAlgo_t algo, hipblasGemmFlags_t flags) {
+    OZ2_EARLY_OUT()
+    const int dtype = gemm_ex_dtype(aType, bType, cType, computeType);
+    hipblasStatus_t st;
+    if (dtype >= 0 && try_emulate(dtype, handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, &st)) return st;
+    using Fn = hipblasStatus_t (*)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int, const void*, const void*,
+                                   hipDataType, int, const void*, hipDataType, int, const void*, void*, hipDataType, int,
+                                   hipblasComputeType_t, hipblasGemmAlgo_t, hipblasGemmFlags_t);
+    static Fn real = real_fn<Fn>("hipblasGemmExWithFlags");
+    return real ? real(handle, transA, transB, m, n, k, alpha, A, aType, lda, B, bType, ldb, beta, C, cType, ldc, computeType, algo, flags)
+                : HIPBLAS_STATUS_NOT_INITIALIZED;
+}
+
+hipblasStatus_t hipblasGemmEx_64(hipblasHandle_t handle, hipblasOperation_t transA, hipblasOperation_t transB, int64_t m, int64_t n, int64_t k,
+                                 const void* alpha, const void* A, hipDataType aType, int64_t lda, const void* B, hipDataType bType,
+                                 int64_t ldb, const void* beta, void* C, hipDataType cType, int64_t ldc, hipblasComputeType_t computeType,
+                                 hipblasGemmAlgo_t algo) {
+    OZ2_EARLY_OUT()
+    const int dtype = gemm_ex_dtype(aType, bType, cType, computeType);
+    hipblasStatus_t st;
+    if (dtype >= 0 && fits_int(m, n, k, lda, ldb, ldc) &&
+        try_emulate(dtype, handle, transA, transB, (int)m, (int)n, (int)k, alpha, A, (int)lda, B, (int)ldb, beta, C, (int)ldc, &st))
+        return st;
+    using Fn = hipblasStatus_t (*)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int64_t, int64_t, int64_t, const void*,
+                                   const void*, hipDataType, int64_t, const void*, hipDataType, int64_t, const void*, void*, hipDataType,
+                                   int64_t, hipblasComputeType_t, hipblasGemmAlgo_t);
+    static Fn real = real_fn<Fn>("hipblasGemmEx_64");
+    return real ? real(handle, transA, transB, m, n, k, alpha, A, aType, lda, B, bType, ldb, beta, C, cType, ldc, computeType, algo)
+                : HIPBLAS_STATUS_NOT_INITIALIZED;
+}
+
+hipblasStatus_t hipblasGemmExWithFlags_64(hipblasHandle_t handle, hipblasOperation_t transA, hipblasOperation_t transB, int64_t m, int64_t n,
+                                          int64_t k, const void* alpha, const void* A, hipDataType aType, int64_t lda, const void* B,
+                                          hipDataType bType, int64_t ldb, const void* beta, void* C, hipDataType cType, int64_t ldc,
+                                          hipblasComputeType_t computeType, hipblasGemmAlgo_t algo, hipblasGemmFlags_t flags) {
+    OZ2_EARLY_OUT()
+    const int dtype = gemm_ex_dtype(aType, bType, cType, computeType);
+    hipblasStatus_t st;
+    if (dtype >= 0 && fits_int(m, n, k, lda, ldb, ldc) &&
+        try_emulate(dtype, handle, transA, transB, (int)m, (int)n, (int)k, alpha, A, (int)lda, B, (int)ldb, beta, C, (int)ldc, &st))
+        return st;
+    using Fn = hipblasStatus_t (*)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int64_t, int64_t, int64_t, const void*,
+                                   const void*, hipDataType, int64_t, const void*, hipDataType, int64_t, const void*, void*, hipDataType,
+                                   int64_t, hipblasComputeType_t, hipblasGemmAlgo_t, hipblasGemmFlags_t);
+    static Fn real = real_fn<Fn>("hipblasGemmExWithFlags_64");
+    return real ? real(handle, transA, transB, m, n, k, alpha, A, aType, lda, B, bType, ldb, beta, C, cType, ldc, computeType, algo, flags)
+                : HIPBLAS_STATUS_NOT_INITIALIZED;
+}
+
 // Strided-batched entry points (not hooked by the reference; PyTorch's bmm uses them): the batch is a loop of emulated
 // GEMMs on the handle's stream.  alpha/beta are shared by the batch; element strides are in units of the matrix type.
 static bool emulate_batch(int dtype, size_t elem, hipblasHandle_t handle, hipblasOperation_t ta, hipblasOperation_t tb, int m, int n, int k,

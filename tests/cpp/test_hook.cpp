@@ -63,7 +63,8 @@ int main() {
     hipMemcpy(ref.data(), C2, ref.size() * 8, hipMemcpyDeviceToHost);
 
     // the sequence of test_hijack.cu: D, D (same pointers -> skip-scaling cache), S, D on another stream, GemmEx
-    for (int rep = 0; rep < 5; ++rep) {
+    // reps 5-8: the ILP64 twins and the WithFlags variants that ROCm 7's hipBLAS exports as well
+    for (int rep = 0; rep < 9; ++rep) {
         if (rep == 2) CHECK(hipblasSgemm(handle, HIPBLAS_OP_N, HIPBLAS_OP_N, m, n, k, &onef, sA, m, sB, k, &zerof, sC, m) == HIPBLAS_STATUS_SUCCESS);
         if (rep == 3) hipblasSetStream(handle, s1);
         hipMemset(C1, 0, hC.size() * 8);
@@ -71,6 +72,20 @@ int main() {
         if (rep == 4)
             CHECK(hipblasGemmEx(handle, HIPBLAS_OP_N, HIPBLAS_OP_N, m, n, k, &one, A, HIP_R_64F, m, B, HIP_R_64F, k, &zero, C1, HIP_R_64F, m,
                                 HIPBLAS_COMPUTE_64F, HIPBLAS_GEMM_DEFAULT) == HIPBLAS_STATUS_SUCCESS);
+        else if (rep == 5)
+            CHECK(hipblasDgemm_64(handle, HIPBLAS_OP_N, HIPBLAS_OP_N, (int64_t)m, (int64_t)n, (int64_t)k, &one, A, (int64_t)m, B, (int64_t)k, &zero,
+                                  C1, (int64_t)m) == HIPBLAS_STATUS_SUCCESS);
+        else if (rep == 6)
+            CHECK(hipblasGemmEx_64(handle, HIPBLAS_OP_N, HIPBLAS_OP_N, (int64_t)m, (int64_t)n, (int64_t)k, &one, A, HIP_R_64F, (int64_t)m, B,
+                                   HIP_R_64F, (int64_t)k, &zero, C1, HIP_R_64F, (int64_t)m, HIPBLAS_COMPUTE_64F, HIPBLAS_GEMM_DEFAULT) ==
+                  HIPBLAS_STATUS_SUCCESS);
+        else if (rep == 7)
+            CHECK(hipblasGemmExWithFlags(handle, HIPBLAS_OP_N, HIPBLAS_OP_N, m, n, k, &one, A, HIP_R_64F, m, B, HIP_R_64F, k, &zero, C1,
+                                         HIP_R_64F, m, HIPBLAS_COMPUTE_64F, HIPBLAS_GEMM_DEFAULT, HIPBLAS_GEMM_FLAGS_NONE) == HIPBLAS_STATUS_SUCCESS);
+        else if (rep == 8)
+            CHECK(hipblasGemmExWithFlags_64(handle, HIPBLAS_OP_N, HIPBLAS_OP_N, (int64_t)m, (int64_t)n, (int64_t)k, &one, A, HIP_R_64F, (int64_t)m,
+                                            B, HIP_R_64F, (int64_t)k, &zero, C1, HIP_R_64F, (int64_t)m, HIPBLAS_COMPUTE_64F, HIPBLAS_GEMM_DEFAULT,
+                                            HIPBLAS_GEMM_FLAGS_NONE) == HIPBLAS_STATUS_SUCCESS);
         else
             CHECK(hipblasDgemm(handle, HIPBLAS_OP_N, HIPBLAS_OP_N, m, n, k, &one, A, m, B, k, &zero, C1, m) == HIPBLAS_STATUS_SUCCESS);
         hipDeviceSynchronize();
@@ -81,7 +96,7 @@ int main() {
                 return 1;
             }
     }
-    std::printf("hooked hipblasDgemm/GemmEx == direct gemmul8_gemm (bitwise), incl. skip-scaling and stream switch\n");
+    std::printf("hooked hipblasDgemm/GemmEx (+ _64, WithFlags) == direct gemmul8_gemm (bitwise), incl. skip-scaling and stream switch\n");
 
     // float result sanity (S path emulated with GEMMUL8_NUM_MOD_S from the environment)
     std::vector<float> gs(fC.size());
