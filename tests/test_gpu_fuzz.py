@@ -1,12 +1,16 @@
 """-m gpu: seeded random sweep over dtype x backend x mode x op x shape x num_moduli x (alpha, beta) through the C ABI,
 each case bit-exact against the oracle (gpu_util.parity_case).  Shapes straddle the 256 x 256 tile, the 128-byte K-step
 and the 256-padding of k; sizes are kept small enough for the scalar oracle."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-DIMS_MN = [1, 2, 31, 255, 256, 257, 300]
+N_SEEDS = int(os.environ.get("GEMMUL8_FUZZ_SEEDS", "96"))  # the suite runs 96; longer one-off sweeps: GEMMUL8_FUZZ_SEEDS=1000
+
+DIMS_MN = [1, 2, 31, 255, 256, 257, 300, 513]
 DIMS_K = [1, 5, 127, 128, 129, 255, 256, 257, 400]
 
 
@@ -17,7 +21,7 @@ def _rand(shape, dtype, rng, phi):
     return x.astype(dtype)
 
 
-@pytest.mark.parametrize("seed", range(96))
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_case_bit_exact(seed):
     import gemmul8_amd as g
     import gpu_util as gu
