@@ -200,7 +200,10 @@ def main():
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # GEMMUL8_BENCH_FORCE_PLAN=1: take the multi-GPU code path (process group, plan, barrier, max-over-ranks timing, gather) even
+    # with ONE rank, so that it can be exercised on the real RCCL backend of a single-GPU box (tests/test_gpu_dist.py)
+    multi = world > 1 or os.environ.get("GEMMUL8_BENCH_FORCE_PLAN", "0") == "1"
+    if multi:
         import torch.distributed as dist
         # RCCL ("nccl") is the product path; GEMMUL8_DIST_BACKEND=gloo only exists to smoke-test this file with
         # several ranks sharing one GPU (host-staged exchange), where NCCL refuses duplicate devices.
@@ -221,7 +224,7 @@ def main():
     zero = np.array([0.0])
     gemm_events = []
 
-    if world == 1:
+    if not multi:
         tot, _, _ = g.work_size(False, g.INT8, n, n, n, N)
         work = torch.empty(tot, dtype=torch.uint8, device=dev)
         L = g.Layout()
@@ -262,7 +265,7 @@ def main():
             parallelism = f"moduli-sharded x{world} (residue all-to-all over RCCL, column-block CRT)"
 
     def barrier():
-        if world > 1:
+        if multi:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -275,7 +278,7 @@ def main():
         step(True)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -288,12 +291,12 @@ def main():
         ms = dt / args.steps * 1e3
         flops = 2.0 * n ** 3
         value = flops / (ms * 1e-3) * 1e-12
-        planes_here = N if world == 1 else plan.my_planes
+        planes_here = N if not multi else plan.my_planes
         gemm_ms = float(np.mean([a.elapsed_time(b) for a, b in gemm_events])) if gemm_events else None
         ops = planes_here * 2.0 * n ** 3
-        if world > 1 and isinstance(plan, gd.ColumnShardedGemm):
+        if multi and isinstance(plan, gd.ColumnShardedGemm):
             ops = N * 2.0 * n * n * plan.ncols
-        if world > 1 and isinstance(plan, gd.BlockShardedGemm):
+        if multi and isinstance(plan, gd.BlockShardedGemm):
             ops = N * 2.0 * plan.nrows * plan.ncols * n
         peak = 5000.0  # dense INT8 MFMA TOPS (MI355X_MICROARCH.md: ~5 PF-class dense FP8/INT8)
         roof = None
@@ -301,14 +304,14 @@ def main():
             ach = ops / (gemm_ms * 1e-3) * 1e-12
             roof = {"bound": "mfma", "kernel": "oz2::gemm_i8_kernel<EPI_MOD> (batched over moduli)", "achieved": ach, "peak": peak,
                     "unit": "TOP/s", "frac": ach / peak, "traffic": None, "launch_ms": gemm_ms, "ops_per_launch": ops,
-                    "algorithmic_bytes_per_launch": planes_here * 3.0 * n * n if world == 1 else None,
+                    "algorithmic_bytes_per_launch": planes_here * 3.0 * n * n if not multi else None,
                     # measured with tools/ubench/mfma_peak.hip (profiles/r01_mfma_power_ceiling.txt): a register-only MFMA loop
                     # reaches the nominal peak on all-zero operands but is power-limited to this on random INT8 data
                     "sustained_mfma_on_random_data_TOPs": 3426.0}
             # HBM-side bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
             # WRITE_SIZE, tools/pmc_traffic.py); only valid for the configuration that was profiled
             tf = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
-            if tf and world == 1 and n == 8192 and N == 14:
+            if tf and not multi and n == 8192 and N == 14:
                 rec = json.load(open(tf[-1])).get("oz2::gemm_i8_kernel<0>")
                 if rec:
                     roof["traffic"] = rec["hbm_side_bytes_per_launch"]
@@ -323,7 +326,7 @@ def main():
             "roofline": roof,
         }
         out["max_rel_err"] = sampled_error(A, B, Cfull, n)
-        if world == 1:
+        if not multi:
             nat, Cn = native_fp64(A, B)
             nat["max_rel_err"] = sampled_error(A, B, Cn, n)
             out["native_fp64_dgemm_same_gpu"] = nat
@@ -340,11 +343,11 @@ def main():
             oms = (time.perf_counter() - t1) / 5 * 1e3
             out["other_mode"] = {"mode": "fast" if other else "accurate", "value": flops / oms * 1e-9, "unit": "TFLOPS", "ms_per_step": oms,
                                  "max_rel_err": sampled_error(A, B, Cmat, n)}
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu and not multi:
             out["cpu_baseline"] = cpu_baseline_port(N, args.fast)
             out["host_blas_dgemm"] = host_blas(n)
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

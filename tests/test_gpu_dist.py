@@ -88,3 +88,68 @@ def test_bench_multi_rank_contract(shard, ranks):
         assert key in d, key
     assert d["n_gpus"] == ranks and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong" and d["value"] > 0
     assert d["max_rel_err"] < 1e-9
+
+
+def _rccl_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        mx = torch.arange(-5, 1019, dtype=torch.int32, device=dev)
+        ref = mx.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)                      # the bound exchange of the block / column plans
+        blk = torch.rand((64, 48), dtype=torch.float64, device=dev)
+        dist.broadcast(blk, src=0)                                     # gather_result
+        send = torch.randint(0, 256, (4096,), dtype=torch.uint8, device=dev)
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send)                             # residue exchange of the moduli plan (a2a)
+        t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                       # bench.py's max-over-ranks timing
+        dist.barrier()
+        torch.cuda.synchronize()
+        q.put(bool(torch.equal(mx, ref)) and bool(torch.equal(recv, send)) and float(t.item()) == 1.5)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_used_by_the_plans_world1():
+    """The RCCL calls the multi-GPU plans and bench.py make (int32 all_reduce(MAX), broadcast, all_to_all_single, barrier) on the real
+    backend with the one GPU this box has: proves the library, the device_id init and the dtype/op combinations work here."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    assert q.get(timeout=10)
+
+
+@pytest.mark.parametrize("shard", ["blocks", "columns", "moduli"])
+def test_bench_plan_path_on_real_rccl_one_rank(shard):
+    """bench.py's multi-GPU code path (nccl process group with device_id, plan, barrier, max-over-ranks timing, gather) on the REAL RCCL
+    backend with the single rank this box allows (GEMMUL8_BENCH_FORCE_PLAN=1)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, GEMMUL8_BENCH_FORCE_PLAN="1", GEMMUL8_DIST_SHARD=shard)
+    env.pop("GEMMUL8_DIST_BACKEND", None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--size", "2048"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 10 and d["max_rel_err"] < 1e-9 and d["roofline"]["achieved"] > 0
