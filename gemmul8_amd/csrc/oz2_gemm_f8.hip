@@ -67,6 +67,9 @@ constexpr int F8_THREADS = 512;
 #ifndef OZ2_F8_PB
 #define OZ2_F8_PB 2
 #endif
+#ifndef OZ2_F8_PROBE_L2
+#define OZ2_F8_PROBE_L2 0
+#endif
 constexpr int F8_PB = OZ2_F8_PB;  // LOAD segments (of 4) over which a B wave spreads its 8 DMA instructions
 
 // int16 residue epilogues (EPI_PART / EPI_FINAL) of a wave's 128 x 64 accumulator block.  ODD: odd modulus -- the accumulators are
@@ -335,7 +338,7 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
     } while (0)
 #define F8_FETCH_BEGIN()                                                                                                     \
     do {                                                                                                                     \
-        fsrc = gsrc + (size_t)kt_next * BK;                                                                                  \
+        fsrc = gsrc + (size_t)(OZ2_F8_PROBE_L2 ? (kt_next & 7) : kt_next) * BK; /* probe: operands from the first 8 K-steps (L2 hits) */ \
         fdst = smem + hs * TILE_BYTES;                                                                                       \
     } while (0)
         F8_FETCH_BEGIN();
