@@ -3,9 +3,9 @@
 
 One "step" = one whole emulated DGEMM C = A*B (8192^3, FP64 in/out, 14 moduli, INT8 MFMA backend,
 accurate mode = the reference's default: 15 INT8 GEMMs) with A, B already resident in HBM.
-N>1 (one process per GPU under torch.distributed.run, RCCL): the output is sharded in blocks over a rank grid
-(gemmul8_amd.dist.BlockShardedGemm: every rank runs all moduli on its block; one all_reduce(MAX) of the row/column
-bounds); GEMMUL8_DIST_SHARD=moduli selects the moduli-sharded plan with a residue all-to-all instead.  "strong"
+N>1 (one process per GPU under torch.distributed.run, RCCL): A and B replicated on every rank, the output sharded in blocks
+over a rank grid by the C++ plans behind include/gemmul8_dist.h (every rank runs all moduli on its block; one
+all_reduce(MAX) of the row/column bounds); GEMMUL8_DIST_SHARD=moduli | fp64sum select the moduli-sharded plans.  "strong"
 scaling: the problem is fixed, value = 2*n^3 / (max over ranks of the step time).
 
 Prints ONE JSON line (rank 0) with the driver's contract keys plus `roofline` (dominant kernel =
@@ -247,22 +247,26 @@ def main():
         parallelism = "single-gpu"
     else:
         from gemmul8_amd import dist as gd
-        # GEMMUL8_DIST_SHARD=blocks (default: output blocks on a rank grid, one all_reduce(MAX) of the bounds, no bulk exchange),
-        # =columns (the 1 x G special case with its own class) or =moduli (moduli sharded, residue all-to-all + column-block
-        # CRT); all bit-identical to the single-GPU result
-        plan = gd.make_plan(g.D, g.INT8, n, n, n, N, fastmode=args.fast, device=dev)
+        # The sharded path lives in C++ behind include/gemmul8_dist.h; this file only creates the transport and the plan.
+        # GEMMUL8_DIST_SHARD = blocks (default: output blocks on a rank grid, one all_reduce(MAX) of the bounds, no bulk exchange),
+        # columns (its 1 x G grid), moduli (moduli sharded, INT8 residue exchange + column-block CRT; bit-identical too) or
+        # fp64sum (moduli sharded, FP64 partial sums + reduce-scatter: the exchange north_star names; last-bit differences).
+        # Placement: A and B are REPLICATED on every rank (same seeds), every rank updates its block of a full-size C.
+        comm = gd.RcclComm() if backend == "nccl" else gd.TorchTransport(device=True)
+        plan = gd.make_plan(comm, g.D, g.INT8, n, n, n, N, fastmode=args.fast)
+        ev_pool = []
 
         def step(record):
-            ev = plan.run(A, B, Cmat, record_gemm_events=record)
-            if record and ev is not None:
-                gemm_events.append(ev)
-        if isinstance(plan, gd.BlockShardedGemm):
-            parallelism = (f"output blocks sharded on a {plan.gr}x{plan.gc} rank grid (every rank runs all {N} moduli on its m/{plan.gr} x n/{plan.gc} "
-                           f"block; one all_reduce(MAX) of the row/column bounds over RCCL)")
-        elif isinstance(plan, gd.ColumnShardedGemm):
-            parallelism = f"output columns sharded x{world} (every rank runs all {N} moduli on n/{world} columns; all_reduce(MAX) of the row bounds over RCCL)"
-        else:
-            parallelism = f"moduli-sharded x{world} (residue all-to-all over RCCL, column-block CRT)"
+            if record:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                e1.record(stream)   # creates the handles; the plan re-records both around its low-precision GEMM launch
+                plan.set_events(e0, e1)
+                gemm_events.append((e0, e1))
+            else:
+                plan.set_events(None, None)
+            plan.run(A, B, Cmat)
+        parallelism = plan.describe()
 
     def barrier():
         if multi:
@@ -294,10 +298,8 @@ def main():
         planes_here = N if not multi else plan.my_planes
         gemm_ms = float(np.mean([a.elapsed_time(b) for a, b in gemm_events])) if gemm_events else None
         ops = planes_here * 2.0 * n ** 3
-        if multi and isinstance(plan, gd.ColumnShardedGemm):
-            ops = N * 2.0 * n * n * plan.ncols
-        if multi and isinstance(plan, gd.BlockShardedGemm):
-            ops = N * 2.0 * plan.nrows * plan.ncols * n
+        if multi:
+            ops = planes_here * 2.0 * plan.work_rows * plan.work_cols * n   # this rank's share of the low-precision GEMMs
         peak = 5000.0  # dense INT8 MFMA TOPS (MI355X_MICROARCH.md: ~5 PF-class dense FP8/INT8)
         roof = None
         if gemm_ms:
@@ -350,6 +352,8 @@ def main():
     if multi:
         import torch.distributed as dist
         dist.barrier()
+        plan.close()
+        comm.close()
         dist.destroy_process_group()
 
 

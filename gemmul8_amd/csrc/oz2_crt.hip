@@ -169,6 +169,204 @@ __global__ void __launch_bounds__(256) crt_kernel(const CrtArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Multi-GPU exchange variant (A) of BASELINE.json's north_star / SURVEY.md 8(e): each rank accumulates the CRT sum over ITS
+// moduli only and the ranks add the FP64 partials (RCCL reduce-scatter, sum) before the mod-P reduction.
+//   crt_partial: (Sh, Sl)[j][i] = sum over t in [t_begin, t_end) of fma(q_t, double(C_mid[t][j][i]), .) in ascending t, the same
+//                two chains as crt_kernel restricted to the rank's moduli; the hi chain is error-free by construction of the
+//                tables (every partial sum of hi parts is exact), the lo chain (and the single chain of the TP = double case)
+//                is rounded, so its value depends on how the moduli are grouped -- the only place variant (A) can differ from
+//                the single-GPU result.  Output planes: out_hi / out_lo, element (i, j) at j * ld_out + i (complex: 2 values).
+//   crt_finish : R = crt_reduce(Sh, Sl) on the summed partials, then scalbn + axpby exactly as crt_kernel.
+template <bool CPLX, typename MID>
+__global__ void __launch_bounds__(256) crt_partial_kernel(const CrtArgs a, unsigned t_begin, unsigned t_end, double* out_hi, double* out_lo,
+                                                          size_t ld_out, size_t col_block, size_t block_stride) {
+    constexpr int COMPS = CPLX ? 2 : 1;
+    constexpr int ROWS = 8 / (COMPS * (int)sizeof(MID));
+    constexpr int NV = ROWS * COMPS;
+    const unsigned row_groups = (unsigned)((a.m + ROWS - 1) / ROWS);
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)row_groups * a.n) return;
+    const size_t col = gid / row_groups;
+    const size_t i0 = (gid - col * row_groups) * ROWS;
+    struct alignas(sizeof(MID) * NV) Vec {
+        MID v[NV];
+    };
+    const MID* base = (const MID*)a.Cmid + (col * a.ld_mid + i0) * COMPS;
+    double Sh[NV], Sl[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) Sh[e] = 0.0, Sl[e] = 0.0;
+    for (unsigned t = t_begin; t < t_end; ++t) {
+        Vec c;
+        const unsigned long long raw = *(const unsigned long long*)(base + (size_t)(t - t_begin) * a.plane_stride * COMPS);
+        __builtin_memcpy(&c, &raw, 8);
+        if (a.use_dd) {
+            const double qh = a.qh[t], ql = a.ql[t];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) {
+                const double cd = (double)c.v[e];
+                Sh[e] = fma(qh, cd, Sh[e]);
+                Sl[e] = fma(ql, cd, Sl[e]);
+            }
+        } else {
+            const double q1 = a.q1[t];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) Sh[e] = fma(q1, (double)c.v[e], Sh[e]);
+        }
+    }
+    // destination: column blocks of col_block columns, block b at b * block_stride doubles (the reduce-scatter unit of a rank)
+    const size_t blk = col / col_block, cin = col - blk * col_block;
+    double* oh = out_hi + blk * block_stride + (cin * ld_out + i0) * COMPS;
+    double* ol = out_lo + blk * block_stride + (cin * ld_out + i0) * COMPS;
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+        if (i0 + e / COMPS < a.m) oh[e] = Sh[e], ol[e] = Sl[e];
+}
+
+template <typename U, bool CPLX>
+__global__ void __launch_bounds__(256) crt_finish_kernel(const CrtArgs a, const double* in_hi, const double* in_lo, size_t ld_in) {
+    constexpr int COMPS = CPLX ? 2 : 1;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= a.m * a.n) return;
+    const size_t col = gid / a.m, row = gid - col * a.m;
+    U al[2] = {(U)a.alpha[0], (U)a.alpha[1]}, be[2] = {(U)a.beta[0], (U)a.beta[1]};
+    int mode = a.mode;
+    if (mode == 5) {
+        al[0] = ((const U*)a.alpha_dev)[0];
+        be[0] = ((const U*)a.beta_dev)[0];
+        if (CPLX) al[1] = ((const U*)a.alpha_dev)[1], be[1] = ((const U*)a.beta_dev)[1];
+        mode = 0;
+    }
+    const int sft = (int)a.sftA[row] + (int)a.sftB[col];
+    U* Cc = (U*)a.C + (col * a.ldc + row) * COMPS;
+    const double* ph = in_hi + (col * ld_in + row) * COMPS;
+    const double* pl = in_lo + (col * ld_in + row) * COMPS;
+    const bool reads_c = mode == 0 || mode == 2 || mode == 4;
+    if constexpr (!CPLX) {
+        const U AB = scalb<U>((U)crt_reduce(a, ph[0], pl[0]), sft);
+        const U old = reads_c ? Cc[0] : (U)0;
+        U o;
+        switch (mode) {
+        case 1: o = AB; break;
+        case 2: o = old + AB; break;
+        case 3: o = -AB; break;
+        case 4: o = old - AB; break;
+        default: o = fmaU<U>(be[0], old, al[0] * AB); break;
+        }
+        Cc[0] = o;
+    } else {
+        const U x = scalb<U>((U)crt_reduce(a, ph[0], pl[0]), sft);
+        const U y = scalb<U>((U)crt_reduce(a, ph[1], pl[1]), sft);
+        const U cx = reads_c ? Cc[0] : (U)0, cy = reads_c ? Cc[1] : (U)0;
+        U ox, oy;
+        switch (mode) {
+        case 1: ox = x, oy = y; break;
+        case 2: ox = cx + x, oy = cy + y; break;
+        case 3: ox = -x, oy = -y; break;
+        case 4: ox = cx - x, oy = cy - y; break;
+        default:
+            ox = fmaU<U>(-be[1], cy, fmaU<U>(be[0], cx, fmaU<U>(-al[1], y, al[0] * x)));
+            oy = fmaU<U>(be[1], cx, fmaU<U>(be[0], cy, fmaU<U>(al[1], x, al[0] * y)));
+            break;
+        }
+        Cc[0] = ox, Cc[1] = oy;
+    }
+}
+
+static void fill_crt_tables(CrtArgs& a, int dtype, int backend, unsigned N) {
+    const bool f32 = is_f32(dtype);
+    const int pdbl = backend == kINT8 ? 6 : 5;
+    a.N = N;
+    a.use_dd = !(f32 || (int)N <= pdbl);
+    const bool i8 = backend == kINT8;
+    a.Phi = (i8 ? GEMMUL8_PNEG_HI_INT8 : GEMMUL8_PNEG_HI_FP8)[N - 2];
+    a.Plo = (i8 ? GEMMUL8_PNEG_LO_INT8 : GEMMUL8_PNEG_LO_FP8)[N - 2];
+    a.invP = (i8 ? GEMMUL8_INVP_INT8 : GEMMUL8_INVP_FP8)[N - 2];
+    for (unsigned t = 0; t < N; ++t) {
+        a.q1[t] = (i8 ? GEMMUL8_QPI1_INT8 : GEMMUL8_QPI1_FP8)[N - 2][t];
+        a.qh[t] = (i8 ? GEMMUL8_QPI2_HI_INT8 : GEMMUL8_QPI2_HI_FP8)[N - 2][t];
+        a.ql[t] = (i8 ? GEMMUL8_QPI2_LO_INT8 : GEMMUL8_QPI2_LO_FP8)[N - 2][t];
+    }
+}
+static void fill_crt_scalars(CrtArgs& a, int dtype, const void* alpha, const void* beta, bool scalars_on_device) {
+    const bool f32 = is_f32(dtype), cplx = is_complex(dtype);
+    if (scalars_on_device) {
+        a.mode = 5;
+        a.alpha_dev = alpha;
+        a.beta_dev = beta;
+        return;
+    }
+    double ar, ai = 0, br, bi = 0;
+    if (f32) {
+        ar = ((const float*)alpha)[0];
+        br = ((const float*)beta)[0];
+        if (cplx) ai = ((const float*)alpha)[1], bi = ((const float*)beta)[1];
+    } else {
+        ar = ((const double*)alpha)[0];
+        br = ((const double*)beta)[0];
+        if (cplx) ai = ((const double*)alpha)[1], bi = ((const double*)beta)[1];
+    }
+    a.alpha[0] = ar, a.alpha[1] = ai, a.beta[0] = br, a.beta[1] = bi;
+    a.mode = 0;
+    if (ai == 0 && bi == 0) {
+        if (ar == 1 && br == 0) a.mode = 1;
+        else if (ar == 1 && br == 1) a.mode = 2;
+        else if (ar == -1 && br == 0) a.mode = 3;
+        else if (ar == -1 && br == 1) a.mode = 4;
+    }
+}
+
+hipError_t launch_crt_partial(hipStream_t stream, int dtype, int backend, unsigned N, unsigned t_begin, unsigned t_end, size_t m, size_t n,
+                              const void* Cmid, size_t ld_mid, size_t plane_stride, double* out_hi, double* out_lo, size_t ld_out,
+                              size_t col_block, size_t block_stride) {
+    if (m == 0 || n == 0) return hipSuccess;
+    CrtArgs a{};
+    a.Cmid = Cmid;
+    a.ld_mid = ld_mid;
+    a.plane_stride = plane_stride;
+    a.m = m;
+    a.n = n;
+    fill_crt_tables(a, dtype, backend, N);
+    const bool cplx = is_complex(dtype), i8 = backend == kINT8;
+    const size_t rows_per_thread = 8 / ((cplx ? 2 : 1) * (i8 ? 1 : 2));
+    const size_t threads = ((m + rows_per_thread - 1) / rows_per_thread) * n;
+    dim3 grid((unsigned)((threads + 255) / 256));
+#define OZ2_CRTP(CP, MID) hipLaunchKernelGGL((crt_partial_kernel<CP, MID>), grid, dim3(256), 0, stream, a, t_begin, t_end, out_hi, out_lo, ld_out, col_block, block_stride)
+    if (i8) {
+        if (cplx) OZ2_CRTP(true, int8_t);
+        else OZ2_CRTP(false, int8_t);
+    } else {
+        if (cplx) OZ2_CRTP(true, int16_t);
+        else OZ2_CRTP(false, int16_t);
+    }
+#undef OZ2_CRTP
+    return hipGetLastError();
+}
+
+hipError_t launch_crt_finish(hipStream_t stream, int dtype, int backend, unsigned N, size_t m, size_t n, const double* in_hi,
+                             const double* in_lo, size_t ld_in, const int16_t* sftA, const int16_t* sftB, const void* alpha,
+                             const void* beta, bool scalars_on_device, void* C, size_t ldc) {
+    if (m == 0 || n == 0) return hipSuccess;
+    CrtArgs a{};
+    a.m = m;
+    a.n = n;
+    a.sftA = sftA;
+    a.sftB = sftB;
+    a.C = C;
+    a.ldc = ldc;
+    fill_crt_tables(a, dtype, backend, N);
+    fill_crt_scalars(a, dtype, alpha, beta, scalars_on_device);
+    dim3 grid((unsigned)((m * n + 255) / 256));
+    switch (dtype) {
+    case kF32: hipLaunchKernelGGL((crt_finish_kernel<float, false>), grid, dim3(256), 0, stream, a, in_hi, in_lo, ld_in); break;
+    case kF64: hipLaunchKernelGGL((crt_finish_kernel<double, false>), grid, dim3(256), 0, stream, a, in_hi, in_lo, ld_in); break;
+    case kC32: hipLaunchKernelGGL((crt_finish_kernel<float, true>), grid, dim3(256), 0, stream, a, in_hi, in_lo, ld_in); break;
+    case kC64: hipLaunchKernelGGL((crt_finish_kernel<double, true>), grid, dim3(256), 0, stream, a, in_hi, in_lo, ld_in); break;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_crt(hipStream_t stream, int dtype, int backend, unsigned N, size_t m, size_t n, const void* Cmid, size_t ld_mid,
                       size_t plane_stride, const int16_t* sftA, const int16_t* sftB, const void* alpha, const void* beta,
                       bool scalars_on_device, void* C, size_t ldc) {
@@ -183,43 +381,9 @@ hipError_t launch_crt(hipStream_t stream, int dtype, int backend, unsigned N, si
     a.sftB = sftB;
     a.C = C;
     a.ldc = ldc;
-    a.N = N;
-    const bool f32 = is_f32(dtype), cplx = is_complex(dtype);
-    const int pdbl = backend == kINT8 ? 6 : 5;
-    a.use_dd = !(f32 || (int)N <= pdbl);
-    const bool i8 = backend == kINT8;
-    a.Phi = (i8 ? GEMMUL8_PNEG_HI_INT8 : GEMMUL8_PNEG_HI_FP8)[N - 2];
-    a.Plo = (i8 ? GEMMUL8_PNEG_LO_INT8 : GEMMUL8_PNEG_LO_FP8)[N - 2];
-    a.invP = (i8 ? GEMMUL8_INVP_INT8 : GEMMUL8_INVP_FP8)[N - 2];
-    for (unsigned t = 0; t < N; ++t) {
-        a.q1[t] = (i8 ? GEMMUL8_QPI1_INT8 : GEMMUL8_QPI1_FP8)[N - 2][t];
-        a.qh[t] = (i8 ? GEMMUL8_QPI2_HI_INT8 : GEMMUL8_QPI2_HI_FP8)[N - 2][t];
-        a.ql[t] = (i8 ? GEMMUL8_QPI2_LO_INT8 : GEMMUL8_QPI2_LO_FP8)[N - 2][t];
-    }
-    if (scalars_on_device) {
-        a.mode = 5;
-        a.alpha_dev = alpha;
-        a.beta_dev = beta;
-    } else {
-        double ar, ai = 0, br, bi = 0;
-        if (f32) {
-            ar = ((const float*)alpha)[0];
-            br = ((const float*)beta)[0];
-            if (cplx) ai = ((const float*)alpha)[1], bi = ((const float*)beta)[1];
-        } else {
-            ar = ((const double*)alpha)[0];
-            br = ((const double*)beta)[0];
-            if (cplx) ai = ((const double*)alpha)[1], bi = ((const double*)beta)[1];
-        }
-        a.alpha[0] = ar, a.alpha[1] = ai, a.beta[0] = br, a.beta[1] = bi;
-        a.mode = 0;
-        if (ai == 0 && bi == 0) {
-            if (ar == 1 && br == 0) a.mode = 1;
-            else if (ar == 1 && br == 1) a.mode = 2;
-            else if (ar == -1 && br == 0) a.mode = 3;
-            else if (ar == -1 && br == 1) a.mode = 4;
-        }
-    }
+    fill_crt_tables(a, dtype, backend, N);
+    fill_crt_scalars(a, dtype, alpha, beta, scalars_on_device);
+    const bool cplx = is_complex(dtype), i8 = backend == kINT8;
     const size_t rows_per_thread = 8 / ((cplx ? 2 : 1) * (i8 ? 1 : 2));
     const size_t threads = ((m + rows_per_thread - 1) / rows_per_thread) * n;
     dim3 grid((unsigned)((threads + 255) / 256));

@@ -39,25 +39,33 @@ inline size_t mid_size(int backend, bool cplx) { return (backend == kINT8 ? 1 : 
         if (e__ != hipSuccess) return (int)e__; \
     } while (0)
 
+// Phase-timer events: one set per (host thread, device) -- an event may only be recorded on a stream of the device it was
+// created on, and one host thread may drive several GPUs through this API.
 struct Timer {
-    hipEvent_t ev[5];
-    bool ok = false;
-    Timer() {
-        ok = true;
-        for (auto& e : ev)
-            if (hipEventCreate(&e) != hipSuccess) ok = false;
-    }
+    hipEvent_t ev[4];
+    bool made = false, ok = false;
 };
-Timer& thread_timer() {
-    static thread_local Timer t;
-    return t;
+Timer* thread_timer() {
+    constexpr int kMaxDev = 64;
+    static thread_local Timer t[kMaxDev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+    Timer& T = t[dev];
+    if (!T.made) {
+        T.made = T.ok = true;
+        for (auto& e : T.ev)
+            if (hipEventCreate(&e) != hipSuccess) T.ok = false;
+    }
+    return T.ok ? &T : nullptr;
 }
 
 }  // namespace
 
+static bool scalars_on_device(const void* alpha);
+
 extern "C" {
 
-const char* gemmul8_version(void) { return "gemmul8-mi355x 0.1 (gfx950; INT8 MFMA_I32_32x32x32_I8, fused epilogues)"; }
+const char* gemmul8_version(void) { return "gemmul8-mi355x 0.2 (gfx950; INT8 MFMA_I32_32x32x32_I8, fused epilogues)"; }
 
 size_t gemmul8_work_size(int is_complex, int backend, size_t m, size_t n, size_t k, unsigned N, int enA, int enB, size_t* wA,
                          size_t* wB) {
@@ -115,15 +123,11 @@ int gemmul8_get_layout(int dtype, int backend, size_t m, size_t n, size_t k, uns
     L->sftA = reinterpret_cast<int16_t*>(sftA);
     L->sftB = reinterpret_cast<int16_t*>(sftB);
     L->C_mid = C_mid;
-    // scratch: the larger of the C_hi region and the unused tail of the 32 MiB BLAS-workspace block
-    const size_t tail = native_sz - midsz * L->sizeC;
-    if (hi_bytes >= tail) {
-        L->scratch = C_hi;
-        L->scratch_bytes = hi_bytes;
-    } else {
-        L->scratch = work_native + midsz * L->sizeC;
-        L->scratch_bytes = tail;
-    }
+    // scratch: the unused tail of the 32 MiB BLAS-workspace block and the C_hi region behind it are one contiguous range
+    // (so that tall-skinny problems, whose C_hi region alone is smaller than the row-maxima arrays, still fit)
+    const size_t tail = (native_sz - midsz * L->sizeC) & ~size_t(255);
+    L->scratch = C_hi - tail;
+    L->scratch_bytes = tail + hi_bytes;
     return GEMMUL8_OK;
 }
 
@@ -329,14 +333,36 @@ int gemmul8_crt(void* stream_, int dtype, int backend, unsigned N, size_t m, siz
     hipStream_t stream = (hipStream_t)stream_;
     if (!C_mid || !sftA || !sftB || !alpha || !beta || !C) return GEMMUL8_E_ARG;
     if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
+    OZ2_HIP(launch_crt(stream, dtype, backend, N, m, n, C_mid, ld_mid, plane_stride, sftA, sftB, alpha, beta, scalars_on_device(alpha), C, ldc));
+    return GEMMUL8_OK;
+}
+
+static bool scalars_on_device(const void* alpha) {
     hipPointerAttribute_t attr{};
-    bool on_device = false;
-    if (hipPointerGetAttributes(&attr, alpha) == hipSuccess) {
-        on_device = (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged || attr.type == hipMemoryTypeArray);
-    } else {
-        (void)hipGetLastError();  // unregistered host pointer: clear the sticky error
-    }
-    OZ2_HIP(launch_crt(stream, dtype, backend, N, m, n, C_mid, ld_mid, plane_stride, sftA, sftB, alpha, beta, on_device, C, ldc));
+    if (hipPointerGetAttributes(&attr, alpha) == hipSuccess)
+        return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged || attr.type == hipMemoryTypeArray;
+    (void)hipGetLastError();  // unregistered host pointer: clear the sticky error
+    return false;
+}
+
+int gemmul8_crt_partial(void* stream_, int dtype, int backend, unsigned N, unsigned t_begin, unsigned t_end, size_t m, size_t n,
+                        const void* C_mid, size_t ld_mid, size_t plane_stride, double* out_hi, double* out_lo, size_t ld_out,
+                        size_t col_block, size_t block_stride) {
+    if (!C_mid || !out_hi || !out_lo || col_block == 0) return GEMMUL8_E_ARG;
+    if (dtype < 0 || dtype > 3 || backend < 0 || backend > 1) return GEMMUL8_E_ARG;
+    if (N < 2 || N > 20 || t_end > N || t_begin > t_end) return GEMMUL8_E_NUM_MODULI;
+    OZ2_HIP(launch_crt_partial((hipStream_t)stream_, dtype, backend, N, t_begin, t_end, m, n, C_mid, ld_mid, plane_stride, out_hi, out_lo,
+                               ld_out, col_block, block_stride));
+    return GEMMUL8_OK;
+}
+
+int gemmul8_crt_finish(void* stream_, int dtype, int backend, unsigned N, size_t m, size_t n, const double* in_hi, const double* in_lo,
+                       size_t ld_in, const int16_t* sftA, const int16_t* sftB, const void* alpha, const void* beta, void* C, size_t ldc) {
+    if (!in_hi || !in_lo || !sftA || !sftB || !alpha || !beta || !C) return GEMMUL8_E_ARG;
+    if (dtype < 0 || dtype > 3 || backend < 0 || backend > 1) return GEMMUL8_E_ARG;
+    if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
+    OZ2_HIP(launch_crt_finish((hipStream_t)stream_, dtype, backend, N, m, n, in_hi, in_lo, ld_in, sftA, sftB, alpha, beta,
+                              scalars_on_device(alpha), C, ldc));
     return GEMMUL8_OK;
 }
 
@@ -354,9 +380,13 @@ int gemmul8_gemm(void* stream_, int dtype, int backend, int op_A, int op_B, size
     int rc = gemmul8_get_layout(dtype, backend, m, n, k, N, work, workA, workB, enA, enB, &L);
     if (rc) return rc;
     const bool skipA = skip_scalA && enA, skipB = skip_scalB && enB;
-    Timer* T = timers_ns ? &thread_timer() : nullptr;
-    if (T && !T->ok) T = nullptr;
-    if (T) OZ2_HIP(hipEventRecord(T->ev[0], stream));
+    // timers are a convenience: if the events cannot be used (e.g. the stream belongs to another device than the current
+    // one) the GEMM still runs, untimed, and the four slots stay 0
+    Timer* T = timers_ns ? thread_timer() : nullptr;
+    if (T && hipEventRecord(T->ev[0], stream) != hipSuccess) {
+        (void)hipGetLastError();
+        T = nullptr;
+    }
     rc = gemmul8_scale(stream, dtype, backend, op_A, op_B, m, n, k, A, lda, B, ldb, N, fastmode, 0, N, &L, skipA, skipB);
     if (rc) return rc;
     if (T) OZ2_HIP(hipEventRecord(T->ev[1], stream));

@@ -1,5 +1,5 @@
 // Shared pieces of the low-precision MFMA GEMM kernels (INT8: oz2_gemm_i8.hip, FP8: oz2_gemm_f8.hip):
-// tile constants, XCD-aware workgroup->tile mapping and the LDS-DMA producer-wave loop.
+// tile constants, XCD-aware workgroup->tile mapping and the row-maxima reduction of the bound-GEMM epilogues.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -10,15 +10,8 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 256, BN = 256, BK = 128;
-constexpr int TILE_BYTES = BM * BK;          // 32 KiB per operand per stage
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // A + B
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;   // two stages = 128 KiB
-constexpr int WS_THREADS = 768;              // 8 consumer + 4 producer waves
-#ifndef OZ2_PSLOTS
-#define OZ2_PSLOTS 4
-#endif
-constexpr int PSLOTS = OZ2_PSLOTS;  // slots (of 8 per K-step) over which a producer spreads its 16 DMA instructions
-
+constexpr int TILE_BYTES = BM * BK;  // 32 KiB per operand panel
+constexpr int WS_THREADS = 768;      // 8 consumer + 4 producer waves
 
 struct TileMap {
     int plane, tm, tn;
@@ -59,21 +52,6 @@ __device__ __forceinline__ TileMap map_tile(int bid, int nwg, int tiles_m, int t
     return t;
 }
 
-// One LDS-DMA instruction of a K-tile: instruction Q = 0..63 moves the 64 16-byte slots p = Q*64 + lane of a stage
-// (4096 slots: slot p <-> operand (p>=2048: B), row = (p&2047)>>3, physical chunk = p&7,
-// logical chunk = physical ^ ((row>>1)&7)).  tA/tB: this workgroup's first row at the K offset of the tile.
-__device__ __forceinline__ void dma_issue(const int8_t* tA, const int8_t* tB, int Q, char* stage, int kp, int nB_valid, int lane) {
-    const int p = Q * 64 + lane;
-    const bool isB = p >= 2048;
-    const int pp = p & 2047;
-    int row = pp >> 3;
-    const int c = (pp & 7) ^ ((row >> 1) & 7);
-    if (isB) row = row < nB_valid ? row : nB_valid - 1;  // B planes have exactly n rows: clamp instead of padding
-    const int8_t* src = (isB ? tB : tA) + (size_t)row * kp + c * 16;
-    char* dst = stage + (Q * 64) * 16;  // wave-uniform; the hardware adds lane*16
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-}
-
 // Row maxima of a wave's 128-row accumulator block for the bound GEMM epilogues.  w[idx], idx = 16 i + r, is this lane's
 // (column-masked, non-negative) value for MFMA tile row i, accumulator register r; lanes 0-31 / 32-63 hold the same 64 idx
 // for two interleaved row sets (row = i0 + 32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  A butterfly reduce-scatter over
@@ -102,6 +80,36 @@ __device__ __forceinline__ void wave_rowmax_atomic(int (&w)[64], int* rowmax, in
     for (int j = 0; j < 2; ++j) {
         const int idx = 2 * (lane & 31) + j;
         const int row = i0 + (idx >> 4) * 32 + (idx & 3) + 8 * ((idx & 15) >> 2) + 4 * khalf;
+        if (row < m && w[j] > 0) atomicMax(rowmax + row, w[j]);
+    }
+}
+
+// The same for the 16x16 accumulator tiles of v_mfma_i32_16x16x64_i8 (INT8 kernel): a wave's 128 rows are 8 tiles of 16, lane l
+// holds rows 4 (l >> 4) + r (r = 0..3) of every tile for column l & 15.  w[idx], idx = 4 ti + r, is this lane's (column-masked,
+// non-negative) value; the 16 lanes of a quad q = l >> 4 hold the same 32 idx.  Butterfly reduce-scatter over the 16 lanes of each
+// quad (30 exchanges) leaves lane l with the finished maxima of idx = 2 (l & 15) and 2 (l & 15) + 1: two fully populated atomicMax.
+__device__ __forceinline__ void wave_rowmax_atomic16(int (&w)[32], int* rowmax, int i0, int m, int lane) {
+    int n = 32;
+#pragma unroll
+    for (int bit = 8; bit >= 1; bit >>= 1) {
+        const int half = n >> 1;
+        const bool up = (lane & bit) != 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j < half) {
+                const int send = up ? w[j] : w[j + half];
+                const int keep = up ? w[j + half] : w[j];
+                const int got = __shfl_xor(send, bit);
+                w[j] = got > keep ? got : keep;
+            }
+        }
+        n = half;
+    }
+    const int q = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int idx = 2 * (lane & 15) + j;
+        const int row = i0 + (idx >> 2) * 16 + 4 * q + (idx & 3);
         if (row < m && w[j] > 0) atomicMax(rowmax + row, w[j]);
     }
 }

@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "oz2_gemm_common.hpp"
 #include "oz2_kernels.h"
 
@@ -462,14 +464,15 @@ static int num_cus() {
 }
 
 template <int EPI> static hipError_t launch(hipStream_t stream, F8Args& a, int planes) {
-    static bool attr_set_dev[64] = {};  // the attribute belongs to the function on ONE device
+    // the attribute belongs to the function on ONE device; setting it is idempotent, so concurrent first calls from several host
+    // threads only need the flag itself to be race-free
+    static std::atomic<bool> attr_set_dev[64];
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 0;
-    bool& attr_set = attr_set_dev[dev_];
-    if (!attr_set) {
+    if (!attr_set_dev[dev_].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_f8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * TILE_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set_dev[dev_].store(true, std::memory_order_release);
     }
     a.total_tiles = planes * a.tiles_m * a.tiles_n;
     if (a.total_tiles <= 0) return hipSuccess;

@@ -40,6 +40,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "oz2_gemm_common.hpp"
 #include "oz2_kernels.h"
 
@@ -90,10 +92,10 @@ enum { RED_GENERIC = 0, RED_ODD = 1, RED_256 = 2 };
 // the kernel time at k = 1024.  (Reading the quotient from the low dword of fma(a, 1/p, 1.5 * 2^52) and finishing with
 // v_mad_i32_i24 -- three instructions -- measured 10 % SLOWER at k = 1024: the dependent FP64 chains no longer overlap.)
 // RED_GENERIC: 32-bit multiply-high (even p other than 256: no INT8 modulus, kept for completeness).
-template <int EPI, int NJ, int RED>
-__device__ __forceinline__ void i8_epilogue_mod(const v16i (&acc)[4][NJ], const GemmArgs& args, int plane, int i0, int j0, int lane) {
-    const int frow = lane & 31;
-    const int khalf = lane >> 5;
+template <int EPI, int RED>
+__device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const GemmArgs& args, int plane, int i0, int j0, int lane) {
+    const int c16 = lane & 15;
+    const int q = lane >> 4;
     const int t = args.t_begin + plane;
     const int p = args.moduli[t];
     const int pinv = args.pinv32[t];
@@ -109,33 +111,37 @@ __device__ __forceinline__ void i8_epilogue_mod(const v16i (&acc)[4][NJ], const 
         else if constexpr (RED == RED_ODD) return mod_small_sym_odd(x, p, invp);
         else return mod_i32_sym(x, p, pinv);
     };
-    // one 64-bit element offset per lane for the whole block (first of 16 consecutive rows of column j0 + frow); the (i, j) sub-tiles
-    // add i * 32 and j * 32 * ldo -- no per-store multiplies (v_mul_lo_u32 / v_mad_u64_u32 are quarter rate)
-    const size_t e00 = (size_t)(j0 + frow) * args.ldo + i0 + khalf * 16;
+    // After the 4 x 4 dword transpose below lane (q, c16) owns the 16 consecutive rows i0 + 64 tg + 16 q .. + 15 of column
+    // j0 + 16 tj + c16: one 64-bit element offset per lane for the whole block, the (tg, tj) sub-blocks add 64 tg and 16 tj * ldo --
+    // no per-store multiplies (v_mul_lo_u32 / v_mad_u64_u32 are quarter rate)
+    const size_t e00 = (size_t)(j0 + c16) * args.ldo + i0 + q * 16;
     const size_t po = (size_t)__builtin_amdgcn_readfirstlane(plane) * args.strideO, pr = (size_t)__builtin_amdgcn_readfirstlane(plane) * args.strideR;  // wave-uniform: scalar multiplies
-    const size_t ejs = (size_t)32 * args.ldo;
+    const size_t ejs = (size_t)16 * args.ldo;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int col = j0 + j * 32 + frow;
+    for (int tj = 0; tj < 4; ++tj) {
+        const int col = j0 + tj * 16 + c16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int tg = 0; tg < 2; ++tg) {
             unsigned d[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int ti = 0; ti < 4; ++ti) {
                 int r[4];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) r[b] = red(acc[i][j][q * 4 + b]);
+                for (int b = 0; b < 4; ++b) r[b] = red(acc[tg * 4 + ti][tj][b]);
                 // low bytes of four residues -> one dword with two v_perm_b32 and an OR (selector bytes: 0-3 = second operand,
                 // 4-7 = first operand, 0x0c = zero)
-                d[q] = __builtin_amdgcn_perm((unsigned)r[1], (unsigned)r[0], 0x0c0c0400u) |
-                       __builtin_amdgcn_perm((unsigned)r[3], (unsigned)r[2], 0x04000c0cu);
+                d[ti] = __builtin_amdgcn_perm((unsigned)r[1], (unsigned)r[0], 0x0c0c0400u) |
+                        __builtin_amdgcn_perm((unsigned)r[3], (unsigned)r[2], 0x04000c0cu);
             }
-            // lane-half h owns rows 8q+4h..+3.  Exchange so that h=0 owns rows 0..15 and h=1 rows 16..31.
-            auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
-            auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
-            const unsigned z[4] = {s0[0], s0[1], s1[0], s1[1]};
+            // lane quad q holds rows 4 q .. 4 q + 3 of the four 16-row tiles ti.  4 x 4 transpose over the quads (lane bits 5, 4) so
+            // that quad q holds all 16 rows of tile ti = q: bit 5 with v_permlane32_swap, bit 4 with v_permlane16_swap.
+            const auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);  // [0]: tile 2 qh, rows of quad (0, ql); [1]: of quad (1, ql)
+            const auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);  // the same for tile 2 qh + 1
+            const auto w01 = __builtin_amdgcn_permlane16_swap(s0[0], s1[0], false, false);  // tile q: rows 0-3, rows 4-7
+            const auto w23 = __builtin_amdgcn_permlane16_swap(s0[1], s1[1], false, false);  //         rows 8-11, rows 12-15
+            const unsigned z[4] = {w01[0], w01[1], w23[0], w23[1]};
             if (col < args.n && !(OZ2_ABL_EPI == 1 && args.kp > 0)) {
-                const size_t e = e00 + j * ejs + i * 32;  // first of 16 consecutive rows
+                const size_t e = e00 + tj * ejs + tg * 64;  // first of 16 consecutive rows
                 if constexpr (EPI == EPI_MOD) {
                     *(uint4*)(args.out + po + e) = make_uint4(z[0], z[1], z[2], z[3]);
                 } else {
@@ -166,50 +172,52 @@ __device__ __forceinline__ void i8_epilogue_mod(const v16i (&acc)[4][NJ], const 
     }
 }
 
-template <int EPI, int NJ>
-__device__ __forceinline__ void i8_epilogue(const v16i (&acc)[4][NJ], const GemmArgs& args, int plane, int i0, int j0, int lane) {
-    const int frow = lane & 31;
-    const int khalf = lane >> 5;
+template <int EPI>
+__device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmArgs& args, int plane, int i0, int j0, int lane) {
+    const int c16 = lane & 15;
+    const int q = lane >> 4;
 
     if constexpr (EPI == EPI_MOD || EPI == EPI_CPLX) {
         const int p = args.moduli[args.t_begin + plane];
-        if (p == 256 || OZ2_ABL_EPI == 2) i8_epilogue_mod<EPI, NJ, RED_256>(acc, args, plane, i0, j0, lane);
-        else if (p & 1) i8_epilogue_mod<EPI, NJ, RED_ODD>(acc, args, plane, i0, j0, lane);
-        else i8_epilogue_mod<EPI, NJ, RED_GENERIC>(acc, args, plane, i0, j0, lane);
+        if (p == 256 || OZ2_ABL_EPI == 2) i8_epilogue_mod<EPI, RED_256>(acc, args, plane, i0, j0, lane);
+        else if (p & 1) i8_epilogue_mod<EPI, RED_ODD>(acc, args, plane, i0, j0, lane);
+        else i8_epilogue_mod<EPI, RED_GENERIC>(acc, args, plane, i0, j0, lane);
     } else {
-        // column max over this lane's 64 rows (masked to valid rows), then across the two lane halves
+        // column max over this lane's 32 rows (masked to valid rows), then across the four lane quads
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
+        for (int tj = 0; tj < 4; ++tj) {
             int cm = 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int ti = 0; ti < 8; ++ti)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = i0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    const int v = (row < args.m) ? acc[i][j][r] : 0;
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i0 + ti * 16 + 4 * q + r;
+                    const int v = (row < args.m) ? acc[ti][tj][r] : 0;
                     cm = v > cm ? v : cm;
                 }
-            const int other = __shfl_xor(cm, 32);
+            int other = __shfl_xor(cm, 16);
             cm = other > cm ? other : cm;
-            const int col = j0 + j * 32 + frow;
-            if (khalf == 0 && col < args.n && cm > 0) atomicMax(args.colmax + col, cm);
+            other = __shfl_xor(cm, 32);
+            cm = other > cm ? other : cm;
+            const int col = j0 + tj * 16 + c16;
+            if (q == 0 && col < args.n && cm > 0) atomicMax(args.colmax + col, cm);
         }
-        // row max across the 32 lanes (columns) of each half, for each of the 64 rows this lane touches
-        int w[64];
+        // row max across the 16 lanes (columns) of each quad, for each of the 32 rows this lane touches
+        int w[32];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int ti = 0; ti < 8; ++ti)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 4; ++r) {
                 int v = 0;
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int col = j0 + j * 32 + frow;
-                    const int a = (col < args.n) ? acc[i][j][r] : 0;
+                for (int tj = 0; tj < 4; ++tj) {
+                    const int col = j0 + tj * 16 + c16;
+                    const int a = (col < args.n) ? acc[ti][tj][r] : 0;
                     v = a > v ? a : v;
                 }
-                w[i * 16 + r] = v;
+                w[ti * 4 + r] = v;
             }
-        wave_rowmax_atomic(w, args.rowmax, i0, args.m, lane);
+        wave_rowmax_atomic16(w, args.rowmax, i0, args.m, lane);
     }
 }
 
@@ -358,68 +366,83 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     }
 
     // ------------------------------ consumer waves
+    // Matrix instruction: v_mfma_i32_16x16x64_i8 (A / B operand: lane l = row l & 15, K bytes 16 (l >> 4) .. + 15 of a 64-byte K
+    // slice; result: column l & 15, rows 4 (l >> 4) + r).  At the board's power cap it sustains 3.95-3.98 POP/s on uniformly
+    // distributed residues where v_mfma_i32_32x32x32_i8 holds 3.45 (tools/ubench/mfma_shapes.hip, profiles/r02_mfma_shapes.txt):
+    // the same MACs with a quarter of the accumulator registers read and written per instruction.  Wave tile 128 x 64 = 8 x 4
+    // accumulator tiles (128 registers); a K-step (128 bytes) is four segments (K half ks2) x (row half ah) of 16 MFMAs: the B
+    // fragments of a K half are loaded in its first segment and kept for the second, the A fragments of 64 rows per segment.
     const int wm = wave >> 2, wn = wave & 3;
-    const int frow = lane & 31;
-    const int khalf = lane >> 5;
-    const int sw = (frow >> 1) & 7;
-    const int a_base = (wm * 128 + frow) * BK;
-    const int b_base = (wn * 64 + frow) * BK;
+    const int r16 = lane & 15;
+    const int q = lane >> 4;
+    const int sw = (r16 >> 1) & 7;
+    const int a_base = (wm * 128 + r16) * BK;
+    const int b_base = (wn * 64 + r16) * BK;
 
     __builtin_amdgcn_s_barrier();               // K-tile 0 published by the producers
     if (wm == 1) __builtin_amdgcn_s_barrier();  // trailing half: one segment behind
     int sA = 0;                                  // slot of A(g); B(g) sits in the next slot (mod 5)
     for (int vb = blockIdx.x; vb < total; vb += G) {
-        v16i acc[4][2];
+        v4i acc[8][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0;
 
         for (int kt = 0; kt < KT; ++kt) {
             const char* curA = smem + sA * TILE_BYTES + a_base;
             const char* curB = smem + (sA == 4 ? 0 : sA + 1) * TILE_BYTES + b_base;
             sA = sA + 2 >= 5 ? sA - 3 : sA + 2;
 #if OZ2_PROBE_LDS
-            v4i af[4], bf[2];  // timing probe only (wrong results): fragments re-read only at ks == 0 (bit 0: B, bit 1: A)
+            v4i af[4], bf[4];  // timing probe only (wrong results): fragments re-read only in the first segment (bit 0: B, bit 1: A)
 #endif
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int coff = (((ks << 1) | khalf) ^ sw) << 4;
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                const int coff = (((ks2 << 2) | q) ^ sw) << 4;
 #if !OZ2_PROBE_LDS
-                v4i af[4], bf[2];
+                v4i bf[4];
 #endif
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (!(OZ2_PROBE_LDS & 2) || ks == 0) af[i] = *(const v4i*)(curA + i * 32 * BK + coff);
+                for (int ah = 0; ah < 2; ++ah) {
+#if !OZ2_PROBE_LDS
+                    v4i af[4];
+#endif
+                    if (ah == 0) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    if (!(OZ2_PROBE_LDS & 1) || ks == 0) bf[j] = *(const v4i*)(curB + j * 32 * BK + coff);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
+                        for (int j = 0; j < 4; ++j)
+                            if (!(OZ2_PROBE_LDS & 1) || ks2 == 0) bf[j] = *(const v4i*)(curB + j * 16 * BK + coff);
+                    }
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i)
+                        if (!(OZ2_PROBE_LDS & 2) || (ks2 == 0 && ah == 0)) af[i] = *(const v4i*)(curA + (ah * 4 + i) * 16 * BK + coff);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[ah * 4 + i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[ah * 4 + i][j], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n);
 #if OZ2_PROBE_LDS & 8
         (void)tmap;  // probe bit 3: no epilogue; the accumulators stay live
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-        i8_epilogue<EPI, 2>(acc, args, tmap.plane, tmap.tm * BM + wm * 128, tmap.tn * BN + wn * 64, lane);
+        i8_epilogue<EPI>(acc, args, tmap.plane, tmap.tm * BM + wm * 128, tmap.tn * BN + wn * 64, lane);
 #endif
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();
@@ -450,14 +473,15 @@ static int num_cus() {
 }
 
 template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int planes) {
-    static bool attr_set_dev[64] = {};  // the attribute belongs to the function on ONE device
+    // the attribute belongs to the function on ONE device; setting it is idempotent, so concurrent first calls from several host
+    // threads only need the flag itself to be race-free
+    static std::atomic<bool> attr_set_dev[64];
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 0;
-    bool& attr_set = attr_set_dev[dev_];
-    if (!attr_set) {
+    if (!attr_set_dev[dev_].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set_dev[dev_].store(true, std::memory_order_release);
     }
     a.total_tiles = planes * a.tiles_m * a.tiles_n;
     if (a.total_tiles <= 0) return hipSuccess;

@@ -96,6 +96,7 @@ struct Cache {  // what the quantised planes in workA/workB currently hold
     void *workA = nullptr, *workB = nullptr;
     int dtype = -1, backend = 0;
     bool fastmode = false;
+    bool enA = false, enB = false;  // the skip switches move the workspace carving (extra bound plane): part of the key
 };
 
 struct Buffer {
@@ -284,21 +285,30 @@ bool try_emulate(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, hipbl
 
     const Cache& c = sp->last;
     bool skipA = false, skipB = false;
-    if (c.valid && c.num_moduli == N && c.k == (size_t)k && c.dtype == dtype && c.fastmode == fastmode && c.backend == backend) {
+    if (c.valid && c.num_moduli == N && c.k == (size_t)k && c.dtype == dtype && c.fastmode == fastmode && c.backend == backend &&
+        c.enA == enA && c.enB == enB) {
         skipA = enA && c.workA == sp->wA.ptr && c.A == A && c.m == (size_t)m && c.lda == (size_t)lda && c.op_A == (int)ta;
         skipB = enB && c.workB == sp->wB.ptr && c.B == B && c.n == (size_t)n && c.ldb == (size_t)ldb && c.op_B == (int)tb;
     }
+    sp->last.valid = false;  // the call below overwrites the planes; the cache is re-validated only if it succeeds
     const int rc = gemmul8_gemm(stream, dtype, backend, (int)ta, (int)tb, (size_t)m, (size_t)n, (size_t)k, alpha, A, (size_t)lda, B,
                                 (size_t)ldb, beta, C, (size_t)ldc, N, fastmode, sp->wC.ptr, sp->wA.ptr, sp->wB.ptr, enA, enB, skipA, skipB,
                                 nullptr);
-    if (rc == GEMMUL8_E_UNSUPPORTED) {
-        static bool warned = false;
-        if (!warned) std::fprintf(stderr, "[GEMMUL8 HOOK] requested emulation (type %d, backend %d) is not built: using the native routine\n", dtype, backend), warned = true;
+    if (rc < 0) {
+        // a GEMMUL8_E_* status means "this call is outside what the emulator accepts" (k > 2^17, FP8 with k > 65536, a
+        // combination that is not built, ...): nothing has been written to C yet, so the application's call is still valid
+        // for the native routine -- pass it through instead of failing a call that works without the hook
+        static std::once_flag warned;
+        std::call_once(warned, [&] {
+            std::fprintf(stderr, "[GEMMUL8 HOOK] emulation declined a call (status %d; type %d, backend %d, m=%d n=%d k=%d): using the native routine for such calls\n",
+                         rc, dtype, backend, m, n, k);
+        });
         return false;
     }
-    if (rc != 0) return *status = (rc > 0 ? HIPBLAS_STATUS_INTERNAL_ERROR : HIPBLAS_STATUS_INVALID_VALUE), true;
+    if (rc != 0) return *status = HIPBLAS_STATUS_INTERNAL_ERROR, true;  // positive: a hipError_t from the runtime
     Cache& u = sp->last;
     u.valid = true;
+    u.enA = enA, u.enB = enB;
     u.num_moduli = N;
     u.op_A = (int)ta, u.op_B = (int)tb;
     u.m = m, u.n = n, u.k = k, u.lda = lda, u.ldb = ldb;

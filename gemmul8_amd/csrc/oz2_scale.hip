@@ -338,7 +338,8 @@ __global__ void __launch_bounds__(256) stage_kmajor_kernel(const StageArgs a) {
     }
 }
 
-// Row-strided operand: grid (ceil(kp/TK), ceil(rows/32)), 256 threads; tile 32 rows x TK k staged RAW in LDS
+// Row-strided operand: 1-D grid of ceil(kp/TK) * ceil(rows/TR) workgroups, the k-tile index fastest (a 2-D grid would cap the
+// row-tile count at 65535, i.e. operands of ~1M rows); 256 threads; tile TR rows x TK k staged RAW in LDS
 template <typename T> struct StageTile {
     // 16.6 KiB of LDS per workgroup for every type (8 workgroups per CU): 32 rows of float, 16 rows of the 8- and 16-byte
     // types (a 16-row read segment of doubles is still one full 128-B cache line)
@@ -354,8 +355,10 @@ __global__ void __launch_bounds__(256) stage_strided_kernel(const StageArgs a) {
     constexpr int CH = TK / 4;                                          // 4-wide k chunks per row
     constexpr int RPP = 256 / CH;                                       // rows per pass
     __shared__ __attribute__((aligned(16))) T tile[TR][PITCH];
-    const size_t r0 = (size_t)blockIdx.y * TR;
-    const size_t kb = (size_t)blockIdx.x * TK;
+    const unsigned nkt = (unsigned)(a.kp / TK);
+    const unsigned rt = blockIdx.x / nkt, kt = blockIdx.x - rt * nkt;
+    const size_t r0 = (size_t)rt * TR;
+    const size_t kb = (size_t)kt * TK;
     {
         constexpr int KY = 256 / TR;  // k values fetched per pass
         const int rx = threadIdx.x % TR, ky = threadIdx.x / TR;
@@ -382,7 +385,7 @@ __global__ void __launch_bounds__(256) stage_strided_kernel(const StageArgs a) {
             U am;
             __builtin_memcpy(&am, &bits, sizeof(U));
             s = (a.backend == kINT8 ? 5 : 7) - ilogb0(am);
-            if (blockIdx.x == 0 && c == 0) a.sft0[row] = (int16_t)s;
+            if (kt == 0 && c == 0) a.sft0[row] = (int16_t)s;
         } else {
             s = -(int)a.sft[row];
         }
@@ -430,7 +433,9 @@ template <typename T, int MODE> static hipError_t launch_stage(hipStream_t strea
         dim3 grid((unsigned)a.rows);
         hipLaunchKernelGGL((stage_kmajor_kernel<T, MODE>), grid, dim3(256), 0, stream, a);
     } else {
-        dim3 grid((unsigned)(a.kp / StageTile<T>::TK), (unsigned)((a.rows + StageTile<T>::TR - 1) / StageTile<T>::TR));
+        const size_t blocks = (a.kp / StageTile<T>::TK) * ((a.rows + StageTile<T>::TR - 1) / StageTile<T>::TR);
+        if (blocks > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
+        dim3 grid((unsigned)blocks);
         hipLaunchKernelGGL((stage_strided_kernel<T, MODE>), grid, dim3(256), 0, stream, a);
     }
     return hipGetLastError();

@@ -113,6 +113,19 @@ GEMMUL8_API int gemmul8_crt(void *stream, int dtype, int backend, unsigned num_m
                 size_t ld_mid, size_t plane_stride, const int16_t *sftA, const int16_t *sftB, const void *alpha,
                 const void *beta, void *C, size_t ldc);
 
+/* Multi-GPU exchange variant (A) of the moduli-sharded plan (include/gemmul8_dist.h): the rank's FP64 partial CRT sums over its
+ * moduli [t_begin, t_end) -- C_mid points at plane t_begin -- as two double planes (hi: error-free chain, lo: rounded chain;
+ * same FMAs and order as gemmul8_crt restricted to those moduli), written in column blocks of col_block columns, block b at
+ * out + b * block_stride doubles, column c of a block at c * ld_out (the reduce-scatter unit of rank b); and the finish on the
+ * SUMMED partials: mod-P reduction, scalbn, axpby as in gemmul8_crt.  No counterpart in the reference (it has no multi-GPU code);
+ * the arithmetic is src/inverse_scaling_real.hpp:8-89 split at the accumulator. */
+GEMMUL8_API int gemmul8_crt_partial(void *stream, int dtype, int backend, unsigned num_moduli, unsigned t_begin, unsigned t_end, size_t m,
+                        size_t n, const void *C_mid, size_t ld_mid, size_t plane_stride, double *out_hi, double *out_lo,
+                        size_t ld_out, size_t col_block, size_t block_stride);
+GEMMUL8_API int gemmul8_crt_finish(void *stream, int dtype, int backend, unsigned num_moduli, size_t m, size_t n, const double *in_hi,
+                       const double *in_lo, size_t ld_in, const int16_t *sftA, const int16_t *sftB, const void *alpha,
+                       const void *beta, void *C, size_t ldc);
+
 /* Library identification (build arch, version) */
 GEMMUL8_API const char *gemmul8_version(void);
 

@@ -325,6 +325,45 @@ void oz2_bound_maxima_i8(int cplx, size_t m, size_t n, size_t k, const uint8_t *
             if (v > cmax[j]) cmax[j] = v;
         }
 }
+/* FP8 bound GEMM restricted to columns [c0,c1) (find_max.hpp:82-96 and the complex FP8 overloads; scaling_accu_complex.hpp:150-175):
+ * products of e4m3 values accumulated in fp32 by the engine (exact integers are not guaranteed: bound entries go up to 256
+ * with 3-bit mantissas), each entry inflated by (k+1)*2^-24 rounding up.  Here: accumulate in double (exact) and round to
+ * float once per entry, which is what an exact-product / fp32-accumulate engine returns when no rounding occurs; the
+ * inflation covers the engine's rounding either way.  rmax/cmax: zero-initialised by the caller, max-combined. */
+void oz2_bound_maxima_f8(int cplx, size_t m, size_t n, size_t k, const uint8_t *Abar, const uint8_t *Bbar, size_t c0, size_t c1,
+                         float *rmax, float *cmax) {
+    const size_t pa = m * k, pb = n * k;
+    f8_lut_init();
+    const float ku = (float)(k + 1) * 0x1.0p-24f;
+    for (size_t j = c0; j < c1; ++j)
+        for (size_t i = 0; i < m; ++i) {
+            float v;
+            if (!cplx) {
+                double s = 0;
+                for (size_t kk = 0; kk < k; ++kk) s += F8_DBL_LUT[Abar[i * k + kk]] * F8_DBL_LUT[Bbar[j * k + kk]];
+                float t = (float)s;
+                v = fmaf_dir(ku, t, t, FE_UPWARD);
+            } else {
+                const uint8_t *ar = Abar + i * k, *ai = ar + pa, *ad = ai + pa;
+                const uint8_t *br = Bbar + j * k, *bi = br + pb, *bd = bi + pb;
+                double cc0 = 0, cc1 = 0, cc2 = 0;
+                for (size_t kk = 0; kk < k; ++kk) {
+                    cc1 += F8_DBL_LUT[ar[kk]] * F8_DBL_LUT[bi[kk]];
+                    cc2 += F8_DBL_LUT[ai[kk]] * F8_DBL_LUT[br[kk]];
+                    cc0 += F8_DBL_LUT[ad[kk]] * F8_DBL_LUT[bd[kk]];
+                }
+                float ArBi = (float)cc1, AiBr = (float)cc2, AriBri = (float)cc0;
+                float ArBi_up = fmaf_dir(ku, ArBi, ArBi, FE_UPWARD);
+                float AiBr_up = fmaf_dir(ku, AiBr, AiBr, FE_UPWARD);
+                float s12 = addf_dir(ArBi_up, AiBr_up, FE_UPWARD);
+                float AriBri_up = fmaf_dir(ku, AriBri, AriBri, FE_UPWARD);
+                float s0 = addf_dir(AriBri_up, s12, FE_UPWARD);
+                v = s0 > s12 ? s0 : s12;
+            }
+            if (v > rmax[i]) rmax[i] = v;
+            if (v > cmax[j]) cmax[j] = v;
+        }
+}
 /* sft: in sft0 (oz2_extract), out NEGATED final shift = -(sft0 + f(max)) */
 void oz2_shift_finalize_i8(int backend, unsigned N, size_t rows, const int32_t *maxv, int16_t *sft) {
     const float log2P = log2P_of(backend, N);
@@ -335,7 +374,6 @@ void oz2_shift_finalize_i8(int backend, unsigned N, size_t rows, const int32_t *
 void oz2_bound_shifts(int backend, int cplx, unsigned N, size_t m, size_t n, size_t k, const uint8_t *Abar,
                       const uint8_t *Bbar, int16_t *sftA, int16_t *sftB, int update_A, int update_B) {
     const float log2P = log2P_of(backend, N);
-    const size_t pa = m * k, pb = n * k;
     if (backend == OZ_INT8) {
         int32_t *rmax = calloc(m, 4), *cmax = calloc(n, 4);
         oz2_bound_maxima_i8(cplx, m, n, k, Abar, Bbar, 0, n, rmax, cmax);
@@ -344,42 +382,8 @@ void oz2_bound_shifts(int backend, int cplx, unsigned N, size_t m, size_t n, siz
         free(rmax);
         free(cmax);
     } else {
-        /* FP8: products of e4m3 values accumulated in fp32 (exact integers here are not guaranteed:
-           bound entries go up to 256 with 3-bit mantissas; the reference inflates by (k+1)*2^-24,
-           find_max.hpp:82-96).  Accumulate in double (exact) and round to float once per entry,
-           which is what an exact-product / fp32-accumulate engine returns when no rounding occurs;
-           the inflation covers the engine's rounding either way. */
-        f8_lut_init();
         float *rmax = calloc(m, 4), *cmax = calloc(n, 4);
-        const float ku = (float)(k + 1) * 0x1.0p-24f;
-        for (size_t j = 0; j < n; ++j)
-            for (size_t i = 0; i < m; ++i) {
-                float v;
-                if (!cplx) {
-                    double s = 0;
-                    for (size_t kk = 0; kk < k; ++kk) s += F8_DBL_LUT[Abar[i * k + kk]] * F8_DBL_LUT[Bbar[j * k + kk]];
-                    float t = (float)s;
-                    v = fmaf_dir(ku, t, t, FE_UPWARD);
-                } else {
-                    const uint8_t *ar = Abar + i * k, *ai = ar + pa, *ad = ai + pa;
-                    const uint8_t *br = Bbar + j * k, *bi = br + pb, *bd = bi + pb;
-                    double c0 = 0, c1 = 0, c2 = 0;
-                    for (size_t kk = 0; kk < k; ++kk) {
-                        c1 += F8_DBL_LUT[ar[kk]] * F8_DBL_LUT[bi[kk]];
-                        c2 += F8_DBL_LUT[ai[kk]] * F8_DBL_LUT[br[kk]];
-                        c0 += F8_DBL_LUT[ad[kk]] * F8_DBL_LUT[bd[kk]];
-                    }
-                    float ArBi = (float)c1, AiBr = (float)c2, AriBri = (float)c0;
-                    float ArBi_up = fmaf_dir(ku, ArBi, ArBi, FE_UPWARD);
-                    float AiBr_up = fmaf_dir(ku, AiBr, AiBr, FE_UPWARD);
-                    float s12 = addf_dir(ArBi_up, AiBr_up, FE_UPWARD);
-                    float AriBri_up = fmaf_dir(ku, AriBri, AriBri, FE_UPWARD);
-                    float s0 = addf_dir(AriBri_up, s12, FE_UPWARD);
-                    v = s0 > s12 ? s0 : s12;
-                }
-                if (v > rmax[i]) rmax[i] = v;
-                if (v > cmax[j]) cmax[j] = v;
-            }
+        oz2_bound_maxima_f8(cplx, m, n, k, Abar, Bbar, 0, n, rmax, cmax);
         if (update_A)
             for (size_t i = 0; i < m; ++i) sftA[i] = (int16_t)(-(sftA[i] + accu_shift_from_max_f32(rmax[i], log2P)));
         if (update_B)
@@ -606,37 +610,59 @@ void oz2_gemm_mod(int backend, int cplx, unsigned N, size_t m, size_t n, size_t 
 }
 
 /* ---------------- phase 5: CRT accumulation, mod P, unscale, axpby ---------------- */
-static double crt_one(int backend, int use_dd, unsigned N, const void *C_mid, int mid16, size_t stride, size_t idx) {
-    const double(*q1)[20] = backend == OZ_INT8 ? GEMMUL8_QPI1_INT8 : GEMMUL8_QPI1_FP8;
-    const double(*qh)[20] = backend == OZ_INT8 ? GEMMUL8_QPI2_HI_INT8 : GEMMUL8_QPI2_HI_FP8;
-    const double(*ql)[20] = backend == OZ_INT8 ? GEMMUL8_QPI2_LO_INT8 : GEMMUL8_QPI2_LO_FP8;
+/* ngroups = 0: the reference's accumulation (inverse_scaling_real.hpp:56-89), one chain over t = 0..N-1.
+ * ngroups > 0: multi-GPU exchange variant (A) of SURVEY.md 8(e) -- NOT in the reference: the moduli are cut into ngroups
+ * contiguous groups [bounds[g], bounds[g+1]), every group accumulates its own chains from zero (what one rank does), the
+ * per-group partials are then added in group order (what an FP64 sum-reduction over the ranks does; for two groups the order is
+ * immaterial), and the mod-P reduction runs on the sums. */
+/* mod-P reduction of an accumulated CRT sum (inverse_scaling_real.hpp:66-72 single double, :76-86 double-double) */
+static double crt_close(int backend, int use_dd, unsigned N, double Sh, double Sl) {
     const double Phi = (backend == OZ_INT8 ? GEMMUL8_PNEG_HI_INT8 : GEMMUL8_PNEG_HI_FP8)[N - 2];
     const double Plo = (backend == OZ_INT8 ? GEMMUL8_PNEG_LO_INT8 : GEMMUL8_PNEG_LO_FP8)[N - 2];
     const double invP = (backend == OZ_INT8 ? GEMMUL8_INVP_INT8 : GEMMUL8_INVP_FP8)[N - 2];
-    if (!use_dd) {
-        double S = 0;
-        for (unsigned t = 0; t < N; ++t) {
-            const double c = mid16 ? (double)((const int16_t *)C_mid)[t * stride + idx] : (double)((const int8_t *)C_mid)[t * stride + idx];
-            S = fma(q1[N - 2][t], c, S);
-        }
-        const double quot = rint(invP * S);
-        return fma(Phi, quot, S);
-    }
-    double Sh = 0, Sl = 0;
-    for (unsigned t = 0; t < N; ++t) {
-        const double c = mid16 ? (double)((const int16_t *)C_mid)[t * stride + idx] : (double)((const int8_t *)C_mid)[t * stride + idx];
-        Sh = fma(qh[N - 2][t], c, Sh);
-        Sl = fma(ql[N - 2][t], c, Sl);
-    }
     const double quot = rint(invP * Sh);
+    if (!use_dd) return fma(Phi, quot, Sh);
     volatile double inner = fma(Phi, quot, Sh) + Sl;
     return fma(Plo, quot, inner);
+}
+/* one group's chains over t in [t0, t1) from zero (the rank-local partial sums of exchange variant (A)) */
+static void crt_partial_one(int backend, int use_dd, unsigned N, const void *C_mid, int mid16, size_t stride, size_t idx, unsigned t0,
+                            unsigned t1, double *ph_out, double *pl_out) {
+    const double(*q1)[20] = backend == OZ_INT8 ? GEMMUL8_QPI1_INT8 : GEMMUL8_QPI1_FP8;
+    const double(*qh)[20] = backend == OZ_INT8 ? GEMMUL8_QPI2_HI_INT8 : GEMMUL8_QPI2_HI_FP8;
+    const double(*ql)[20] = backend == OZ_INT8 ? GEMMUL8_QPI2_LO_INT8 : GEMMUL8_QPI2_LO_FP8;
+    double ph = 0, pl = 0;
+    for (unsigned t = t0; t < t1; ++t) {
+        const double c = mid16 ? (double)((const int16_t *)C_mid)[t * stride + idx] : (double)((const int8_t *)C_mid)[t * stride + idx];
+        if (use_dd) {
+            ph = fma(qh[N - 2][t], c, ph);
+            pl = fma(ql[N - 2][t], c, pl);
+        } else {
+            ph = fma(q1[N - 2][t], c, ph);
+        }
+    }
+    *ph_out = ph, *pl_out = pl;
+}
+static double crt_one(int backend, int use_dd, unsigned N, const void *C_mid, int mid16, size_t stride, size_t idx, unsigned ngroups,
+                      const unsigned *bounds, const double *sum_hi, const double *sum_lo) {
+    if (sum_hi) return crt_close(backend, use_dd, N, sum_hi[idx], sum_lo[idx]); /* partials already summed by the caller */
+    const unsigned one_group[2] = {0, N};
+    if (ngroups == 0) ngroups = 1, bounds = one_group;
+    volatile double Sh = 0, Sl = 0;
+    for (unsigned g = 0; g < ngroups; ++g) {
+        double ph, pl;
+        crt_partial_one(backend, use_dd, N, C_mid, mid16, stride, idx, bounds[g], bounds[g + 1], &ph, &pl);
+        if (g == 0) Sh = ph, Sl = pl;
+        else Sh = Sh + ph, Sl = Sl + pl;
+    }
+    return crt_close(backend, use_dd, N, Sh, Sl);
 }
 
 /* scalar_mode: 0 = host scalars (special cases for alpha=+-1, beta in {0,1}; inverse_scaling_real.hpp:218-236),
  *              1 = device-pointer scalars: always the general fma form (:120-144, :215) */
-void oz2_invscal(int dtype, int backend, unsigned N, size_t m, size_t n, const void *C_mid, const int16_t *sftA,
-                 const int16_t *sftB, const void *alpha, const void *beta, void *C, size_t ldc, int scalar_mode) {
+static void invscal_impl(int dtype, int backend, unsigned N, size_t m, size_t n, const void *C_mid, const int16_t *sftA,
+                         const int16_t *sftB, const void *alpha, const void *beta, void *C, size_t ldc, int scalar_mode, unsigned ngroups,
+                         const unsigned *bounds, const double *sum_hi, const double *sum_lo) {
     const int cplx = is_cplx(dtype), f32 = is_f32(dtype);
     const int use_dd = !(f32 || (int)N <= p_is_double(backend));
     const int mid16 = backend == OZ_FP8;
@@ -657,7 +683,7 @@ void oz2_invscal(int dtype, int backend, unsigned N, size_t m, size_t n, const v
             const int sft = (int)sftA[i] + (int)sftB[j];
             double ab[2] = {0, 0};
             for (size_t c = 0; c < comps; ++c) {
-                const double R = crt_one(backend, use_dd, N, C_mid, mid16, stride, (j * m + i) * comps + c);
+                const double R = crt_one(backend, use_dd, N, C_mid, mid16, stride, (j * m + i) * comps + c, ngroups, bounds, sum_hi, sum_lo);
                 ab[c] = f32 ? (double)scalbnf((float)R, sft) : scalbn(R, sft);
             }
             const size_t o = j * ldc + i;
@@ -721,6 +747,30 @@ void oz2_invscal(int dtype, int backend, unsigned N, size_t m, size_t n, const v
                 }
             }
         }
+}
+
+void oz2_invscal(int dtype, int backend, unsigned N, size_t m, size_t n, const void *C_mid, const int16_t *sftA,
+                 const int16_t *sftB, const void *alpha, const void *beta, void *C, size_t ldc, int scalar_mode) {
+    invscal_impl(dtype, backend, N, m, n, C_mid, sftA, sftB, alpha, beta, C, ldc, scalar_mode, 0, NULL, NULL, NULL);
+}
+/* exchange variant (A): CRT with the accumulation grouped by rank (see crt_one); bounds has ngroups + 1 entries */
+void oz2_invscal_grouped(int dtype, int backend, unsigned N, size_t m, size_t n, const void *C_mid, const int16_t *sftA,
+                         const int16_t *sftB, const void *alpha, const void *beta, void *C, size_t ldc, int scalar_mode, unsigned ngroups,
+                         const unsigned *bounds) {
+    invscal_impl(dtype, backend, N, m, n, C_mid, sftA, sftB, alpha, beta, C, ldc, scalar_mode, ngroups, bounds, NULL, NULL);
+}
+/* the two halves of variant (A) as separate steps: rank-local partial sums of moduli [t0, t1) for every element
+ * (out_hi / out_lo: [n][m] doubles, complex interleaved), and the close + unscale + axpby on sums formed elsewhere */
+void oz2_crt_partial(int dtype, int backend, unsigned N, unsigned t0, unsigned t1, size_t m, size_t n, const void *C_mid, double *out_hi,
+                     double *out_lo) {
+    const int use_dd = !(is_f32(dtype) || (int)N <= p_is_double(backend));
+    const size_t comps = is_cplx(dtype) ? 2 : 1, stride = m * n * comps;
+    for (size_t idx = 0; idx < stride; ++idx)
+        crt_partial_one(backend, use_dd, N, C_mid, backend == OZ_FP8, stride, idx, t0, t1, out_hi + idx, out_lo + idx);
+}
+void oz2_crt_finish(int dtype, int backend, unsigned N, size_t m, size_t n, const double *sum_hi, const double *sum_lo, const int16_t *sftA,
+                    const int16_t *sftB, const void *alpha, const void *beta, void *C, size_t ldc, int scalar_mode) {
+    invscal_impl(dtype, backend, N, m, n, NULL, sftA, sftB, alpha, beta, C, ldc, scalar_mode, 0, NULL, sum_hi, sum_lo);
 }
 
 /* ---------------- full pipeline ---------------- */

@@ -87,8 +87,76 @@ def shifts_close(dev, orc, what=""):
     return nd
 
 
+def bounds_case(A, B, N, opA="N", opB="N", backend=g.INT8, skip_layout=False):
+    """Accurate-mode scaling phase, first half, BIT-EXACT against the oracle (rows a3 / a4 of SURVEY.md section 8):
+    the 7-bit (INT8) / e4m3 round-up (FP8) bound planes of both operands, the preliminary shifts sft0 = maxUFP - ilogb(amax)
+    and the row / column maxima of the bound product (int32; FP8: inflated floats), read from the workspace right after
+    gemmul8_scale_bounds (scaling_accu_real.hpp:23-136,415-432, scaling.hpp:3-94, find_max.hpp:67-114).
+    skip_layout: carve the workspace with enable_skip_scalA/B = 1, where the bound planes have their own slot behind the
+    residue planes (gemmul8_real.hpp:101-104) instead of aliasing plane 0."""
+    dA, dB = to_dev(A), to_dev(B)
+    m, k = (A.shape if opA == "N" else A.shape[::-1])
+    n = B.shape[1] if opB == "N" else B.shape[0]
+    cplx = A.dtype.kind == "c"
+    en = int(skip_layout)
+    tot, _, _ = g.work_size(cplx, backend, m, n, k, N, en, en)
+    work = torch.full((tot,), 0x5A, dtype=torch.uint8, device="cuda")
+    L = g.Layout()
+    code = g._dtype_code(dA.dtype)
+    lib = g.lib()
+    g.check(lib.gemmul8_get_layout(code, backend, m, n, k, N, work.data_ptr(), None, None, en, en, C.byref(L)))
+    st = torch.cuda.current_stream().cuda_stream
+    g.check(lib.gemmul8_scale_bounds(st, code, backend, g.OPS[opA], g.OPS[opB], m, n, k, dA.data_ptr(), dA.shape[1], dB.data_ptr(),
+                                     dB.shape[1], N, 0, n, C.byref(L), 0, 0), "scale_bounds")
+    torch.cuda.synchronize()
+    w = work.cpu().numpy()
+    base = work.data_ptr()
+    parts = 3 if cplx else 1
+
+    def planes(ptr, rows, rows_alloc, plane_bytes):
+        out = np.zeros((parts, rows, k), np.uint8)
+        for p in range(parts):
+            off = ptr - base + p * plane_bytes
+            pl = w[off:off + rows_alloc * L.kp].reshape(rows_alloc, L.kp)
+            out[p] = pl[:rows, :k]
+            assert not pl[:rows, k:].any(), "k-padding of a bound plane must be zero"
+        return out
+    Ab = planes(L.A_bound, m, L.mp, L.sizeA)
+    Bb = planes(L.B_bound, n, n, L.sizeB)
+    s0A = w[L.sftA - base:L.sftA - base + 2 * m].view(np.int16)
+    s0B = w[L.sftB - base:L.sftB - base + 2 * n].view(np.int16)
+    np_ = (n + 255) // 256 * 256
+    mx = w[L.scratch - base:L.scratch - base + 4 * (L.mp + np_)]
+    mdt = np.int32 if backend == g.INT8 else np.float32
+    rmax, cmax = mx[:4 * m].view(mdt), mx[4 * L.mp:4 * L.mp + 4 * n].view(mdt)
+    oA, o0A = ol.extract_bounds(A, opA, True, backend)
+    oB, o0B = ol.extract_bounds(B, opB, False, backend)
+    assert np.array_equal(Ab, oA), f"A bound planes differ in {np.sum(Ab != oA)} bytes"
+    assert np.array_equal(Bb, oB), f"B bound planes differ in {np.sum(Bb != oB)} bytes"
+    assert np.array_equal(s0A, o0A) and np.array_equal(s0B, o0B), "preliminary shifts sft0 differ"
+    orm, ocm = ol.bound_maxima(oA, oB, backend)
+    if backend == g.INT8:
+        assert np.array_equal(rmax, orm), f"row maxima of the bound GEMM differ at {np.nonzero(rmax != orm)[0][:5]}"
+        assert np.array_equal(cmax, ocm), f"column maxima of the bound GEMM differ at {np.nonzero(cmax != ocm)[0][:5]}"
+        return 0
+    # FP8: the accumulation of the e4m3 products belongs to the ENGINE (the reference leaves it to the vendor's FP8 GEMM and
+    # inflates by (k+1)*2^-24, find_max.hpp:82-96).  gfx950's v_mfma_scale_f32_*_f8f6f4 does not round like a chain of FP32
+    # additions: products far below the largest one of a K-block lose low bits (measured: up to ~2e-4 relative on rows spanning
+    # 20 binades, always towards zero; exact when the products of a row span < ~13 binades, see
+    # test_bounds_fp8_exact_when_fp32_sums_are_exact).  Hence: bit-equal to the exactly accumulated oracle value, or below it by
+    # at most 2^-10 relative -- never above it by more than FP32 rounding.
+    up, down = (2.0 ** -10 if cplx else 4.0 * (k + 1) * 2.0 ** -24), 2.0 ** -10  # complex: (Ar-Ai)(Br-Bi) has products of both signs
+    for d, o, what in ((rmax, orm, "row"), (cmax, ocm, "column")):
+        rel = (d.astype(np.float64) - o) / np.maximum(o, 1e-300)
+        assert np.all((d == o) | ((rel <= up) & (rel >= -down))), f"{what} maxima of the FP8 bound GEMM off by {rel.min()} .. {rel.max()}"
+    return int((rmax != orm).sum() + (cmax != ocm).sum())
+
+
 def parity_case(A, B, N, fastmode, opA="N", opB="N", alpha=1.0, beta=0.0, C0=None, backend=g.INT8):
-    """Full bit-exact parity of one case: shifts (tolerant), planes, C_mid, C (exact given the device's shifts)."""
+    """Full bit-exact parity of one case: accurate mode's bound planes / sft0 / bound maxima (exact), shifts (tolerant),
+    planes, C_mid, C (exact given the device's shifts)."""
+    if not fastmode:
+        bounds_case(A, B, N, opA=opA, opB=opB, backend=backend)
     Cd, it = hip_gemm(A, B, N, fastmode=fastmode, backend=backend, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0, want_intermediates=True)
     # oracle with its own shifts -> compare shifts
     _, ito = ol.gemm(A, B, N, fastmode=fastmode, backend=backend, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0, want_intermediates=True)

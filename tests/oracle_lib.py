@@ -42,6 +42,15 @@ def lib():
                                      C.c_void_p, C.c_void_p]
         _lib.oz2_bound_shifts.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        _lib.oz2_bound_maxima_i8.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                             C.c_size_t, C.c_void_p, C.c_void_p]
+        _lib.oz2_bound_maxima_f8.argtypes = _lib.oz2_bound_maxima_i8.argtypes
+        _lib.oz2_shift_finalize_i8.argtypes = [C.c_int, C.c_uint, C.c_size_t, C.c_void_p, C.c_void_p]
+        _lib.oz2_invscal_grouped.argtypes = _lib.oz2_invscal.argtypes + [C.c_uint, C.c_void_p]
+        _lib.oz2_crt_partial.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_uint, C.c_uint, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]
+        _lib.oz2_crt_finish.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         _lib.oz2_fast_shifts.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p,
                                          C.c_size_t, C.c_void_p]
     return _lib
@@ -125,3 +134,29 @@ def accurate_shifts(A, B, N, backend=INT8):
     L.oz2_extract(DT[dt], backend, 1, 0, n, k, _p(B), B.shape[0], _p(Bb), _p(sB))
     L.oz2_bound_shifts(backend, int(cplx), N, m, n, k, _p(Ab), _p(Bb), _p(sA), _p(sB), 1, 1)
     return sA, sB
+
+
+def extract_bounds(X, op, is_A, backend=INT8):
+    """Accurate-mode extract of one operand as stored (before op): returns (planes uint8 [(1|3)][rows][k], sft0 int16[rows]).
+    A: rows = m, K-major iff op != N; B: rows = n, K-major iff op == N (scaling_accu_real.hpp:23-136)."""
+    X = np.asfortranarray(X)
+    dt = X.dtype
+    kmajor = (op != "N") if is_A else (op == "N")
+    rows, k = (X.shape[1], X.shape[0]) if kmajor else X.shape
+    parts = 3 if dt.kind == "c" else 1
+    lo = np.zeros((parts, rows, k), np.uint8)
+    sft0 = np.zeros(rows, np.int16)
+    lib().oz2_extract(DT[dt], backend, int(kmajor), int(op == "C"), rows, k, _p(X), X.shape[0], _p(lo), _p(sft0))
+    return lo, sft0
+
+
+def bound_maxima(Abar, Bbar, backend=INT8, c0=0, c1=None):
+    """Row / column maxima of the bound product (find_max.hpp:67-114): int32 for INT8, float32 (inflated) for FP8."""
+    parts, m, k = Abar.shape
+    n = Bbar.shape[1]
+    c1 = n if c1 is None else c1
+    dt = np.int32 if backend == INT8 else np.float32
+    rmax, cmax = np.zeros(m, dt), np.zeros(n, dt)
+    fn = lib().oz2_bound_maxima_i8 if backend == INT8 else lib().oz2_bound_maxima_f8
+    fn(int(parts == 3), m, n, k, _p(np.ascontiguousarray(Abar)), _p(np.ascontiguousarray(Bbar)), c0, c1, _p(rmax), _p(cmax))
+    return rmax, cmax

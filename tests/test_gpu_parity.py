@@ -293,3 +293,159 @@ def test_result_independent_of_workspace_contents(dt, backend, fast):
                 w = torch.full((tot,), int(fill, 16), dtype=torch.uint8, device="cuda")
             C1, _, _ = g.gemm(A, B, N, fastmode=fast, backend=be, work=w)
             assert torch.equal(C0.view(torch.uint8), C1.view(torch.uint8)), (m, n, k, fill)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Accurate-mode scaling phase, first half: bound planes, sft0 and bound maxima BIT-EXACT.
+# parity_case() already runs bounds_case() for every accurate-mode case above; these add the layouts and operand shapes that
+# exercise the tile masks of the MAX epilogue (rows/cols beyond m/n inside a 256-tile, several tiles, K-major and strided
+# operands, conj) and the skip-scaling carving, where the bound planes have their own slot.
+@pytest.mark.parametrize("backend", ["INT8", "FP8"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, np.complex128, np.complex64])
+@pytest.mark.parametrize("opA,opB", [("N", "N"), ("T", "N"), ("N", "T"), ("C", "C")])
+def test_bounds_bit_exact(backend, dtype, opA, opB):
+    import gemmul8_amd as g
+    import gpu_util as gu
+    if np.dtype(dtype).kind != "c" and "C" in (opA, opB):
+        opA, opB = "T", "T"
+    rng = np.random.default_rng(hash((backend, np.dtype(dtype).name, opA, opB)) % 2**31)
+    be = getattr(g, backend)
+    for (m, n, k) in [(37, 41, 300), (300, 520, 700), (513, 255, 1025), (1, 1, 1)]:
+        A = rand((m, k) if opA == "N" else (k, m), dtype, rng, phi=2.0)
+        B = rand((k, n) if opB == "N" else (n, k), dtype, rng, phi=2.0)
+        if m > 5:
+            (A if opA == "N" else A.T)[5, :] = 0                       # all-zero row
+            (A if opA == "N" else A.T)[3, min(4, k - 1)] = np.finfo(dtype).tiny / 4   # subnormal
+        gu.bounds_case(A, B, 13, opA=opA, opB=opB, backend=be)
+        gu.bounds_case(A, B, 13, opA=opA, opB=opB, backend=be, skip_layout=True)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.complex128])
+def test_bounds_fp8_exact_when_fp32_sums_are_exact(dtype):
+    """Operands of one binade: every e4m3 bound value is a multiple of 8 in [64, 256], so the FP32 accumulation of the
+    products is exact in any order and the device's inflated float maxima must equal the oracle's BITS."""
+    import gemmul8_amd as g
+    import gpu_util as gu
+    rng = np.random.default_rng(21)
+    m, n, k = 130, 70, 200
+
+    def one_binade(shape):
+        x = (0.25 + 0.25 * rng.random(shape)) * rng.choice([-1.0, 1.0], shape)
+        if np.dtype(dtype).kind == "c":
+            x = x + 1j * (0.25 + 0.25 * rng.random(shape)) * rng.choice([-1.0, 1.0], shape)
+        return x.astype(dtype)
+    nd = gu.bounds_case(one_binade((m, k)), one_binade((k, n)), 12, backend=g.FP8)
+    assert nd == 0
+
+
+@pytest.mark.parametrize("backend,dtype,N", [("INT8", np.float64, 14), ("INT8", np.complex64, 9), ("FP8", np.float32, 6), ("FP8", np.complex128, 13)])
+def test_skip_scaling_keeps_bound_planes_and_reuses_them(backend, dtype, N):
+    """enable_skip_scal{A,B}: after a whole call the bound plane of each operand persists in its own slot (bit-exact vs the
+    oracle's extract), and a second call with skip_scal{A,B} = 1 and a DIFFERENT partner operand reuses planes + shifts of the
+    kept operand: equal to the oracle run fed with the kept operand's shifts (gemmul8_real.hpp:82-83,101-104,123-139)."""
+    import ctypes as C
+    import gemmul8_amd as g
+    import gpu_util as gu
+    import oracle_lib as ol
+    be = getattr(g, backend)
+    rng = np.random.default_rng(N)
+    m, n, k = 77, 52, 260
+    A, B, B2 = rand((m, k), dtype, rng), rand((k, n), dtype, rng), rand((k, n), dtype, rng)
+    cplx = np.dtype(dtype).kind == "c"
+    lib = g.lib()
+    tot, wa, wb = g.work_size(cplx, be, m, n, k, N, True, True)
+    work = torch.zeros(tot, dtype=torch.uint8, device="cuda")
+    dA, dB, dB2 = gu.to_dev(A), gu.to_dev(B), gu.to_dev(B2)
+    dC = torch.zeros((n, m), dtype=dA.dtype, device="cuda")
+    one, zero = np.array([1], dtype), np.array([0], dtype)
+    st = torch.cuda.current_stream().cuda_stream
+    code = g._dtype_code(dA.dtype)
+
+    def call(Bt, skA, skB):
+        g.check(lib.gemmul8_gemm(st, code, be, 0, 0, m, n, k, one.ctypes.data, dA.data_ptr(), m, Bt.data_ptr(), k, zero.ctypes.data,
+                                 dC.data_ptr(), m, N, 0, work.data_ptr(), None, None, 1, 1, skA, skB, None))
+        torch.cuda.synchronize()
+        return gu.from_dev(dC).copy()
+    C1 = call(dB, 0, 0)
+    L = g.Layout()
+    g.check(lib.gemmul8_get_layout(code, be, m, n, k, N, work.data_ptr(), None, None, 1, 1, C.byref(L)))
+    w = work.cpu().numpy()
+    base = work.data_ptr()
+    parts = 3 if cplx else 1
+    oA, _ = ol.extract_bounds(A, "N", True, be)
+    oB, _ = ol.extract_bounds(B, "N", False, be)
+    for p in range(parts):
+        pa = w[L.A_bound - base + p * L.sizeA:][:L.mp * L.kp].reshape(L.mp, L.kp)[:m, :k]
+        pb = w[L.B_bound - base + p * L.sizeB:][:n * L.kp].reshape(n, L.kp)[:, :k]
+        assert np.array_equal(pa, oA[p]) and np.array_equal(pb, oB[p]), "kept bound planes differ from the oracle's extract"
+    sftA = w[L.sftA - base:][:2 * m].view(np.int16).copy()
+    Co1 = ol.gemm(A, B, N, backend=be, sftA_in=sftA, sftB_in=w[L.sftB - base:][:2 * n].view(np.int16).copy())
+    assert gu.bits_equal(C1, Co1)
+    # second call: A kept (skip), B2 new.  The accurate-mode shift of B2's columns is computed against A's KEPT bound plane.
+    C2 = call(dB2, 1, 0)
+    w = work.cpu().numpy()
+    assert np.array_equal(w[L.sftA - base:][:2 * m].view(np.int16), sftA), "the kept operand's shifts must not change"
+    sftB2 = w[L.sftB - base:][:2 * n].view(np.int16).copy()
+    oB2, s0B2 = ol.extract_bounds(B2, "N", False, be)
+    _, cmax = ol.bound_maxima(oA, oB2, be)
+    Co2 = ol.gemm(A, B2, N, backend=be, sftA_in=sftA, sftB_in=sftB2)
+    assert gu.bits_equal(C2, Co2)
+    if be == g.INT8:  # column shifts from the exact integer maxima: reproduce them through the oracle's finalize
+        exp = s0B2.copy()
+        ol.lib().oz2_shift_finalize_i8(be, N, n, cmax.ctypes.data_as(C.c_void_p), exp.ctypes.data_as(C.c_void_p))
+        gu.shifts_close(sftB2, exp, "sftB (skip A)")
+
+
+@pytest.mark.parametrize("backend,dtype,N", [("INT8", np.float64, 14), ("INT8", np.complex128, 15), ("FP8", np.float32, 6), ("INT8", np.float32, 7)])
+@pytest.mark.parametrize("alpha,beta", [(1, 0), (-1, 1), (-1.5, 1.5)])
+def test_device_pointer_scalars_bit_exact(backend, dtype, N, alpha, beta):
+    """alpha/beta in DEVICE memory (hipBLAS pointer mode device): always the general fma form, also for alpha = +-1 and
+    beta in {0, 1} (inverse_scaling_real.hpp:211-216) -- bit-exact against the oracle's scalar_mode = 1."""
+    import gemmul8_amd as g
+    import gpu_util as gu
+    import oracle_lib as ol
+    be = getattr(g, backend)
+    rng = np.random.default_rng(3)
+    m, n, k = 45, 33, 147
+    A, B, C0 = rand((m, k), dtype, rng), rand((k, n), dtype, rng), rand((m, n), dtype, rng)
+    if np.dtype(dtype).kind == "c" and alpha == -1.5:
+        alpha, beta = -1.5 + 1.2j, 1.5 - 0.7j
+    dA, dB, dC = gu.to_dev(A), gu.to_dev(B), gu.to_dev(C0.copy())
+    d_al = torch.tensor([alpha], dtype=dA.dtype, device="cuda")
+    d_be = torch.tensor([beta], dtype=dA.dtype, device="cuda")
+    cplx = np.dtype(dtype).kind == "c"
+    tot, _, _ = g.work_size(cplx, be, m, n, k, N)
+    work = torch.zeros(tot, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    import ctypes as C
+    code = g._dtype_code(dA.dtype)
+    for fast in (False, True):
+        dC.copy_(gu.to_dev(C0))
+        g.check(g.lib().gemmul8_gemm(st, code, be, 0, 0, m, n, k, d_al.data_ptr(), dA.data_ptr(), m, dB.data_ptr(), k, d_be.data_ptr(),
+                                     dC.data_ptr(), m, N, int(fast), work.data_ptr(), None, None, 0, 0, 0, 0, None))
+        torch.cuda.synchronize()
+        L = g.Layout()
+        g.check(g.lib().gemmul8_get_layout(code, be, m, n, k, N, work.data_ptr(), None, None, 0, 0, C.byref(L)))
+        w = work.cpu().numpy()
+        base = work.data_ptr()
+        sA = w[L.sftA - base:][:2 * m].view(np.int16).copy()
+        sB = w[L.sftB - base:][:2 * n].view(np.int16).copy()
+        Co = ol.gemm(A, B, N, fastmode=fast, backend=be, alpha=alpha, beta=beta, C0=C0, scalar_mode=1, sftA_in=sA, sftB_in=sB)
+        assert gu.bits_equal(gu.from_dev(dC), Co)
+
+
+@pytest.mark.parametrize("backend,N", [("INT8", 15), ("FP8", 13)])
+@pytest.mark.parametrize("fast", [False, True])
+def test_kat_result_bit_patterns(backend, N, fast):
+    """Regression pin: the result BITS of the reference's known-answer sample (tests/golden/kat_result_bits.json, produced by
+    the oracle -- tools/make_kat_result_bits.py) through the HIP path."""
+    import gemmul8_amd as g
+    import gpu_util as gu
+    d = json.load(open(os.path.join(GOLD, "kat_dgemm_4x5x3.json")))
+    A = np.array([float.fromhex(x) for x in d["A"]]).reshape((4, 5), order="F")
+    B = np.array([float.fromhex(x) for x in d["B"]]).reshape((5, 3), order="F")
+    gold = json.load(open(os.path.join(GOLD, "kat_result_bits.json")))[f"{backend}_N{N}_{'fast' if fast else 'accurate'}"]
+    Cd, it = gu.hip_gemm(A, B, N, fastmode=fast, backend=getattr(g, backend), want_intermediates=True)
+    assert [float(x).hex() for x in Cd.flatten(order="F")] == gold["C"]
+    assert it["sftA"].tolist() == gold["sftA"] and it["sftB"].tolist() == gold["sftB"]
+    assert it["C_mid"].flatten().tolist() == gold["C_mid"]

@@ -171,3 +171,40 @@ def test_worksize_matches_survey_table():
     assert abs(tot / GiB - 13.0) < 0.001
     tot, _, _ = ol.work_size(True, ol.INT8, 8192, 8192, 8192, 20)
     assert abs(tot / GiB - 10.75) < 0.001
+
+
+@pytest.mark.parametrize("backend,name,N", [(ol.INT8, "INT8", 15), (ol.FP8, "FP8", 13)])
+@pytest.mark.parametrize("fast", [False, True])
+def test_kat_result_bit_patterns_regression(backend, name, N, fast):
+    """Regression pin of the restatement itself: result bits, shifts and residue planes of the reference's known-answer sample
+    as committed in tests/golden/kat_result_bits.json (tools/make_kat_result_bits.py).  The GPU twin of this test
+    (tests/test_gpu_parity.py::test_kat_result_bit_patterns) holds the HIP path to the same bits."""
+    A, B, _ = kat()
+    gold = json.load(open(os.path.join(GOLD, "kat_result_bits.json")))[f"{name}_N{N}_{'fast' if fast else 'accurate'}"]
+    C, it = ol.gemm(A, B, N, fastmode=fast, backend=backend, want_intermediates=True)
+    assert [float(x).hex() for x in C.flatten(order="F")] == gold["C"]
+    assert it["sftA"].tolist() == gold["sftA"] and it["sftB"].tolist() == gold["sftB"]
+    assert it["C_mid"].flatten().tolist() == gold["C_mid"]
+
+
+def test_fp8_bound_maxima_against_numpy():
+    """oz2_bound_maxima_f8 (exported for the GPU bound-maxima parity test; the function oz2_bound_shifts runs) against an
+    independent numpy statement of find_max.hpp:82-96: decode e4m3, exact products and sums, one rounding to float,
+    inflate by (k+1)*2^-24 rounding up."""
+    def e4m3(b):
+        b = b.astype(np.int64)
+        e, mnt = (b >> 3) & 15, b & 7
+        v = np.where(e == 0, mnt * 2.0 ** -9, (8 + mnt) * 2.0 ** (e - 10))
+        return np.where(b & 128, -v, v)
+    rng = np.random.default_rng(4)
+    m, n, k = 9, 6, 33
+    A = ((rng.random((m, k)) - 0.5) * np.exp(rng.standard_normal((m, k)))).astype(np.float32)
+    B = ((rng.random((k, n)) - 0.5) * np.exp(rng.standard_normal((k, n)))).astype(np.float32)
+    oA, _ = ol.extract_bounds(A, "N", True, ol.FP8)
+    oB, _ = ol.extract_bounds(B, "N", False, ol.FP8)
+    rmax, cmax = ol.bound_maxima(oA, oB, ol.FP8)
+    prod = (e4m3(oA[0]) @ e4m3(oB[0]).T).astype(np.float32).astype(np.float64)   # [m][n], exact in double
+    x = prod + prod * ((k + 1) * 2.0 ** -24)                                     # exact in double (48-bit product)
+    up = x.astype(np.float32)
+    up = np.where(up.astype(np.float64) < x, np.nextafter(up, np.float32(np.inf)), up)
+    assert np.array_equal(rmax, up.max(axis=1)) and np.array_equal(cmax, up.max(axis=0))

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build timing-probe variants of libgemmul8.so (gemmul8_amd/lib/lib_<tag>.so): only oz2_gemm_i8.hip is recompiled with the given
+# -D flags, the other objects come from the regular build.   usage: tools/build_probes.sh tag1="-DOZ2_PROBE_LDS=4" tag2="..." ...
+set -e
+cd "$(dirname "$0")/../gemmul8_amd/csrc"
+make -j8 >/dev/null
+FLAGS="-std=c++20 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -DOCML_BASIC_ROUNDED_OPERATIONS -Wno-unused-function -fvisibility=hidden"
+for spec in "$@"; do
+  tag="${spec%%=*}"; defs="${spec#*=}"
+  src=${SRC:-oz2_gemm_i8}
+  /opt/rocm/bin/hipcc $FLAGS $defs -c $src.hip -o build/${src}_$tag.o
+  objs=""
+  for o in oz2_gemm_i8 oz2_gemm_f8 oz2_scale oz2_crt oz2_driver oz2_api oz2_hook oz2_dist; do
+    [ "$o" = "$src" ] && objs="$objs build/${src}_$tag.o" || objs="$objs build/$o.o"
+  done
+  /opt/rocm/lib/llvm/bin/clang++ -shared -fPIC -o ../lib/lib_$tag.so $objs -ldl -lpthread
+  echo "built lib_$tag.so ($defs)"
+done
