@@ -84,34 +84,29 @@ __device__ __forceinline__ void wave_rowmax_atomic(int (&w)[64], int* rowmax, in
     }
 }
 
-// The same for the 16x16 accumulator tiles of v_mfma_i32_16x16x64_i8 (INT8 kernel): a wave's 128 rows are 8 tiles of 16, lane l
-// holds rows 4 (l >> 4) + r (r = 0..3) of every tile for column l & 15.  w[idx], idx = 4 ti + r, is this lane's (column-masked,
-// non-negative) value; the 16 lanes of a quad q = l >> 4 hold the same 32 idx.  Butterfly reduce-scatter over the 16 lanes of each
-// quad (30 exchanges) leaves lane l with the finished maxima of idx = 2 (l & 15) and 2 (l & 15) + 1: two fully populated atomicMax.
-__device__ __forceinline__ void wave_rowmax_atomic16(int (&w)[32], int* rowmax, int i0, int m, int lane) {
-    int n = 32;
-#pragma unroll
-    for (int bit = 8; bit >= 1; bit >>= 1) {
-        const int half = n >> 1;
-        const bool up = (lane & bit) != 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (j < half) {
-                const int send = up ? w[j] : w[j + half];
-                const int keep = up ? w[j + half] : w[j];
-                const int got = __shfl_xor(send, bit);
-                w[j] = got > keep ? got : keep;
-            }
-        }
-        n = half;
-    }
-    const int q = lane >> 4;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int idx = 2 * (lane & 15) + j;
-        const int row = i0 + (idx >> 2) * 16 + 4 * q + (idx & 3);
-        if (row < m && w[j] > 0) atomicMax(rowmax + row, w[j]);
-    }
+// Row maxima of ONE 16-row accumulator tile row of the 16x16 MFMA shapes for the bound-GEMM epilogues: v[r], r = 0..3, is this lane's
+// (column-masked, non-negative) maximum over the wave's column tiles for row i0 + 4 (lane >> 4) + r; the 16 lanes of a quad hold the
+// 16 columns.  Reduce-scatter over lane bits 3, 2 (4 -> 2 -> 1 values), butterfly over bits 1, 0: lane l then holds the finished
+// maximum of row r = 2 b3 + b2 (b3, b2 = bits 3, 2 of l); the four lanes with (l & 3) == 0 of every quad issue the atomicMax.
+// Working tile by tile keeps only four values live beside the accumulators (a 32-entry array for the whole wave tile pushed the
+// FP8 kernel's LDS-DMA offsets into scratch, with a vmcnt(0) in front of every DMA instruction).
+__device__ __forceinline__ void tile_rowmax_atomic16(const int (&v)[4], int* rowmax, int i0, int m, int lane) {
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+    // bit 3: lanes with b3 keep r = 2, 3
+    const int s0 = b3 ? v[0] : v[2], s1 = b3 ? v[1] : v[3];
+    const int k0 = b3 ? v[2] : v[0], k1 = b3 ? v[3] : v[1];
+    const int g0 = __shfl_xor(s0, 8), g1 = __shfl_xor(s1, 8);
+    const int a0 = g0 > k0 ? g0 : k0, a1 = g1 > k1 ? g1 : k1;  // r = 2 b3, 2 b3 + 1
+    // bit 2: lanes with b2 keep the odd one
+    const int s = b2 ? a0 : a1, k = b2 ? a1 : a0;
+    const int g = __shfl_xor(s, 4);
+    int x = g > k ? g : k;  // r = 2 b3 + b2
+    int o = __shfl_xor(x, 2);
+    x = o > x ? o : x;
+    o = __shfl_xor(x, 1);
+    x = o > x ? o : x;
+    const int row = i0 + 4 * (lane >> 4) + 2 * (b3 ? 1 : 0) + (b2 ? 1 : 0);
+    if ((lane & 3) == 0 && row < m && x > 0) atomicMax(rowmax + row, x);
 }
 
 }  // namespace oz2

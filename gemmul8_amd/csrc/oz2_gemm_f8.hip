@@ -16,11 +16,16 @@
 //
 // Same tiling as oz2_gemm_i8.hip (256x256 tile, BK = 128 bytes, swizzled 128-B LDS rows fed by LDS-DMA, ping-pong
 // LOAD/MFMA segments with the two wave halves one slot apart); the matrix instruction is the block-scaled
-// v_mfma_scale_f32_32x32x64_f8f6f4 with unit scales (E8M0 0x7F) -- the only full-rate FP8 MFMA on CDNA4
-// (the unscaled 32x32x16 fp8 form runs at the BF16 rate).  Its 8-VGPR fragments (A 2x8 + B 2x8 live next to the 128
-// accumulators) do not fit the 168-VGPR budget of the 12-wave INT8 layout -- that version spilled accumulators
-// inside the K loop -- so this kernel runs 8 waves (2 per SIMD, 256 VGPRs) and the consumer waves issue the
-// LDS-DMA themselves in their LOAD segments (8 instructions per wave and operand panel).
+// v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales (E8M0 0x7F) -- the scaled forms are the only full-rate FP8 MFMAs on CDNA4
+// (the unscaled fp8 forms run at the BF16 rate), and at the board's power cap the 16x16x128 shape sustains 4.28 POP/s on the
+// integers in [-16, 16] this backend multiplies where 32x32x64 holds 3.97 (tools/ubench/mfma_shapes.hip,
+// profiles/r02_mfma_shapes.txt).  One instruction consumes a whole 128-byte K-step of 16 rows: lane l holds row l & 15 and the
+// 16-byte chunks q and q + 4 (q = l >> 4) of it -- any assignment of K positions works as long as A and B agree, and this one
+// keeps the ds_read_b128 pattern of the INT8 kernel (conflict-free with the row-XOR swizzle).  A K-step is two segments (row
+// halves) of 16 MFMAs: A fragments of 64 rows (32 registers) per segment, the B fragments of the wave's 64 columns (32
+// registers) loaded in the first and kept for the second.  128 accumulators + 64 operand registers do not fit the 168-VGPR budget
+// of the 12-wave INT8 layout, so this kernel runs 8 waves (2 per SIMD, 256 VGPRs) and the consumer waves issue the LDS-DMA
+// themselves in their LOAD segments (8 instructions per wave and operand panel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -32,7 +37,7 @@
 namespace oz2 {
 
 typedef int v8i __attribute__((ext_vector_type(8)));
-typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 // EPI_FINAL_CPLX: like EPI_FINAL for the third complex part Z = (Ar+Ai)(Br+Bi), then (Cr, Ci) = (X - Y, Z - X - Y) mod p with
 // the residues X, Y of the first two parts -> interleaved int16 pairs (conv_hi2mid_complex.hpp:28-41).
@@ -66,21 +71,20 @@ struct F8Args {
 __device__ __forceinline__ unsigned pack16(int a, int b) { return ((unsigned)a & 0xFFFFu) | ((unsigned)b << 16); }
 
 constexpr int F8_THREADS = 512;
-#ifndef OZ2_F8_PB
-#define OZ2_F8_PB 2
+#ifndef OZ2_F8_SEGS
+#define OZ2_F8_SEGS 2  // LOAD / MFMA segment pairs per K-step: 2 (row halves, 16 MFMAs each) or 4 (row x column halves, 8 MFMAs each)
 #endif
 #ifndef OZ2_F8_PROBE_L2
 #define OZ2_F8_PROBE_L2 0
 #endif
-constexpr int F8_PB = OZ2_F8_PB;  // LOAD segments (of 4) over which a B wave spreads its 8 DMA instructions
 
 // int16 residue epilogues (EPI_PART / EPI_FINAL) of a wave's 128 x 64 accumulator block.  ODD: odd modulus -- the accumulators are
 // exact integers (|c| <= 2^24): one exact FP64 quotient step (five full-rate instructions); the combined value (|v| < 2^18)
 // needs one fp32 step.  p = 1024 (the only even FP8 modulus; the tie +-512 keeps the reference's representative +512): ((a + 511) & 1023) - 511.
 template <int EPI, bool ODD>
-__device__ __forceinline__ void f8_epilogue_mod(const v16f (&acc)[4][2], const F8Args& args, int plane, int i0, int j0, int lane) {
-    const int frow = lane & 31;
-    const int khalf = lane >> 5;
+__device__ __forceinline__ void f8_epilogue_mod(const v4f (&acc)[8][4], const F8Args& args, int plane, int i0, int j0, int lane) {
+    const int c16 = lane & 15;
+    const int q = lane >> 4;
     const int t = args.t_begin + plane;
     const int p = args.moduli[t];
     // value = k0*R0 + k1*R1 + k2*R2:  square moduli s*(R0+R1) + R2;  Karatsuba 256*R0 + 16*(R2-R0-R1) + R1
@@ -106,31 +110,35 @@ __device__ __forceinline__ void f8_epilogue_mod(const v16f (&acc)[4][2], const F
         }
     };
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = j0 + j * 32 + frow;
+    for (int tj = 0; tj < 4; ++tj) {
+        const int col = j0 + tj * 16 + c16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned d[4][2];  // quad q: rows 8q+4h..+3 as 4 x int16
+        for (int tg = 0; tg < 2; ++tg) {
+            unsigned d[4][2];  // tile ti of the group: this lane quad's rows 4 q .. 4 q + 3 as 4 x int16
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int ti = 0; ti < 4; ++ti) {
                 int r[4];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) r[b] = red_acc(acc[i][j][q * 4 + b]);
-                d[q][0] = pack16(r[0], r[1]);
-                d[q][1] = pack16(r[2], r[3]);
+                for (int b = 0; b < 4; ++b) r[b] = red_acc(acc[tg * 4 + ti][tj][b]);
+                d[ti][0] = pack16(r[0], r[1]);
+                d[ti][1] = pack16(r[2], r[3]);
             }
-            unsigned z[8];  // after the exchange: 16 consecutive rows (h=0: rows 0..15, h=1: rows 16..31)
+            // 4 x 4 transpose over the lane quads (bits 5, 4) as in oz2_gemm_i8.hip: afterwards quad q holds the 16 consecutive rows
+            // 64 tg + 16 q .. + 15 (tile ti = q): rows 4 s .. 4 s + 3 from source quad s in z[2 s], z[2 s + 1]
+            unsigned z[8];
 #pragma unroll
             for (int w = 0; w < 2; ++w) {
-                auto s0 = __builtin_amdgcn_permlane32_swap(d[0][w], d[2][w], false, false);
-                auto s1 = __builtin_amdgcn_permlane32_swap(d[1][w], d[3][w], false, false);
-                z[0 + w] = s0[0];  // rows 0-3   (own quad 0 | quad 2 of the lower half)
-                z[2 + w] = s0[1];  // rows 4-7
-                z[4 + w] = s1[0];  // rows 8-11
-                z[6 + w] = s1[1];  // rows 12-15
+                const auto s0 = __builtin_amdgcn_permlane32_swap(d[0][w], d[2][w], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(d[1][w], d[3][w], false, false);
+                const auto w01 = __builtin_amdgcn_permlane16_swap(s0[0], s1[0], false, false);
+                const auto w23 = __builtin_amdgcn_permlane16_swap(s0[1], s1[1], false, false);
+                z[0 + w] = w01[0];  // rows 0-3
+                z[2 + w] = w01[1];  // rows 4-7
+                z[4 + w] = w23[0];  // rows 8-11
+                z[6 + w] = w23[1];  // rows 12-15
             }
             if (col < args.n) {
-                const size_t e = (size_t)col * args.ldo + i0 + i * 32 + khalf * 16;
+                const size_t e = (size_t)col * args.ldo + i0 + tg * 64 + q * 16;
                 int16_t* dst = args.out + (size_t)plane * args.strideO + e;
                 if constexpr (EPI == EPI_FINAL || EPI == EPI_FINAL_CPLX) {
                     const uint4* p0 = (const uint4*)(args.r0 + (size_t)plane * args.strideR + e);
@@ -181,73 +189,73 @@ __device__ __forceinline__ void f8_epilogue_mod(const v16f (&acc)[4][2], const F
 // error of the inexact bound products); FMAX and FB3 then reduce row / column maxima (atomicMax on the bit patterns of
 // non-negative floats).
 template <int EPI>
-__device__ __forceinline__ void f8_epilogue_bound(v16f (&acc)[4][2], const F8Args& args, int i0, int j0, int lane) {
-    const int frow = lane & 31;
-    const int khalf = lane >> 5;
+__device__ __forceinline__ void f8_epilogue_bound(v4f (&acc)[8][4], const F8Args& args, int i0, int j0, int lane) {
+    const int c16 = lane & 15;
+    const int q = lane >> 4;
     const float ku = args.ku;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = j0 + j * 32 + frow;
+    for (int tj = 0; tj < 4; ++tj) {
+        const int col = j0 + tj * 16 + c16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int ti = 0; ti < 8; ++ti) {
+            float u[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float u[4];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) u[b] = __fmaf_ru(ku, acc[i][j][q * 4 + b], acc[i][j][q * 4 + b]);
-                if constexpr (EPI != EPI_FMAX) {
-                    float4* fp = (float4*)(args.fbuf + (size_t)col * args.ldo + i0 + i * 32 + 8 * q + 4 * khalf);
-                    if (col < args.n) {
-                        if constexpr (EPI == EPI_FB1) {
-                            *fp = make_float4(u[0], u[1], u[2], u[3]);
+            for (int b = 0; b < 4; ++b) u[b] = __fmaf_ru(ku, acc[ti][tj][b], acc[ti][tj][b]);
+            if constexpr (EPI != EPI_FMAX) {
+                float4* fp = (float4*)(args.fbuf + (size_t)col * args.ldo + i0 + ti * 16 + 4 * q);  // this lane's 4 consecutive rows
+                if (col < args.n) {
+                    if constexpr (EPI == EPI_FB1) {
+                        *fp = make_float4(u[0], u[1], u[2], u[3]);
+                    } else {
+                        const float4 w = *fp;
+                        const float ws[4] = {w.x, w.y, w.z, w.w};
+                        if constexpr (EPI == EPI_FB2) {
+                            *fp = make_float4(__fadd_ru(ws[0], u[0]), __fadd_ru(ws[1], u[1]), __fadd_ru(ws[2], u[2]), __fadd_ru(ws[3], u[3]));
                         } else {
-                            const float4 w = *fp;
-                            const float ws[4] = {w.x, w.y, w.z, w.w};
-                            if constexpr (EPI == EPI_FB2) {
-                                *fp = make_float4(__fadd_ru(ws[0], u[0]), __fadd_ru(ws[1], u[1]), __fadd_ru(ws[2], u[2]), __fadd_ru(ws[3], u[3]));
-                            } else {
 #pragma unroll
-                                for (int b = 0; b < 4; ++b) {
-                                    const float s0 = __fadd_ru(u[b], ws[b]);
-                                    u[b] = s0 > ws[b] ? s0 : ws[b];
-                                }
+                            for (int b = 0; b < 4; ++b) {
+                                const float s0 = __fadd_ru(u[b], ws[b]);
+                                u[b] = s0 > ws[b] ? s0 : ws[b];
                             }
                         }
                     }
                 }
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[i][j][q * 4 + b] = u[b];
             }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[ti][tj][b] = u[b];
+        }
     }
     if constexpr (EPI == EPI_FMAX || EPI == EPI_FB3) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int tj = 0; tj < 4; ++tj) {
             float cm = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int ti = 0; ti < 8; ++ti)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = i0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    cm = fmaxf(cm, (row < args.m) ? acc[i][j][r] : 0.0f);
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i0 + ti * 16 + 4 * q + r;
+                    cm = fmaxf(cm, (row < args.m) ? acc[ti][tj][r] : 0.0f);
                 }
+            cm = fmaxf(cm, __shfl_xor(cm, 16));
             cm = fmaxf(cm, __shfl_xor(cm, 32));
-            const int col = j0 + j * 32 + frow;
-            if (khalf == 0 && col < args.n && cm > 0.0f) atomicMax(args.colmax + col, __float_as_int(cm));
+            const int col = j0 + tj * 16 + c16;
+            if (q == 0 && col < args.n && cm > 0.0f) atomicMax(args.colmax + col, __float_as_int(cm));
         }
-        int w[64];  // bit patterns of non-negative floats order like ints
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int ti = 0; ti < 8; ++ti) {
+            int w[4];  // bit patterns of non-negative floats order like ints
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 4; ++r) {
                 float v = 0.0f;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = j0 + j * 32 + frow;
-                    v = fmaxf(v, (col < args.n) ? acc[i][j][r] : 0.0f);
+                for (int tj = 0; tj < 4; ++tj) {
+                    const int col = j0 + tj * 16 + c16;
+                    v = fmaxf(v, (col < args.n) ? acc[ti][tj][r] : 0.0f);
                 }
-                w[i * 16 + r] = __float_as_int(v);
+                w[r] = __float_as_int(v);
             }
-        wave_rowmax_atomic(w, args.rowmax, i0, args.m, lane);
+            tile_rowmax_atomic16(w, args.rowmax, i0 + ti * 16, args.m, lane);
+        }
     }
 }
 
@@ -297,15 +305,16 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
                                      (__attribute__((address_space(3))) void*)((stage_) + ((wave & 3) * 8 + (q_)) * 1024), 16, 0, 0)
 
     const int wm = wave >> 2, wn = wave & 3;
-    const int frow = lane & 31;
-    const int khalf = lane >> 5;
-    const int sw = (frow >> 1) & 7;
-    const int a_base = (wm * 128 + frow) * BK;
-    const int b_base = (wn * 64 + frow) * BK;
+    const int r16 = lane & 15;
+    const int q = lane >> 4;
+    const int sw = (r16 >> 1) & 7;
+    const int a_base = (wm * 128 + r16) * BK;
+    const int b_base = (wn * 64 + r16) * BK;
+    const int clo = (q ^ sw) << 4, chi = ((q | 4) ^ sw) << 4;  // this lane's two 16-byte chunks (q, q + 4) of a 128-byte row, swizzled
 
-    auto frag = [&](const char* base, int c0) {  // 32 bytes = logical chunks c0, c0+1 of this lane's row
-        const v4i lo = *(const v4i*)(base + ((c0 ^ sw) << 4));
-        const v4i hi = *(const v4i*)(base + (((c0 + 1) ^ sw) << 4));
+    auto frag = [&](const char* base) {  // 32 bytes of this lane's row
+        const v4i lo = *(const v4i*)(base + clo);
+        const v4i hi = *(const v4i*)(base + chi);
         return v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
     constexpr int UNIT = 0x7F7F7F7F;  // E8M0 scale 2^0 for every 32-element block
@@ -314,9 +323,9 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
     // branch-free inside the LOAD segments
     auto run = [&]<bool ISB>() {
         // 2.5-stage ring of operand panels as in oz2_gemm_i8.hip: panel h = 2 g + isB in slot h % 5 of five 32 KiB panels.  The A
-        // waves fetch A(g+2) during K-step g, two instructions in each of their four LOAD segments; the B waves fetch B(g+1), four
-        // instructions in each of their first two LOAD segments (measured: spreading B further, or issuing it all at once, loses
-        // 3-12 %).  Against the two-stage pipeline: 63.4 -> 56.2 ms on the 18 FP8 GEMMs of config 3.
+        // waves fetch A(g+2) during K-step g, four instructions in each of their two LOAD segments; the B waves fetch B(g+1), all eight
+        // instructions in their first LOAD segment (B must land within the K-step).  Against the two-stage pipeline (32x32x64 kernel of
+        // round 1): 63.4 -> 56.2 ms on the 18 FP8 GEMMs of config 3.
         // Fetch state = the panel fetched LAST; every K-step first advances it (at the TOP of the K-step: a branch after the
         // LOAD/MFMA segments lets the compiler sink all MFMAs of the K-step behind it, which destroys the ping-pong) and then
         // issues that panel.  Past the last panel the state stops advancing and the fetch repeats the last valid source into
@@ -363,13 +372,13 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
         // before anyone reads the new panels.
         int sA = 0;  // slot of A(g); B(g) sits in the next slot (mod 5)
         for (int vb = blockIdx.x; vb < total; vb += G) {
-            v16f acc[4][2];
+            v4f acc[8][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
 
             for (int kt = 0; kt < KT; ++kt) {
                 const char* curA = smem + sA * TILE_BYTES + a_base;
@@ -377,47 +386,92 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
                 sA = sA + 2 >= 5 ? sA - 3 : sA + 2;
                 F8_FETCH_ADVANCE();
                 F8_FETCH_BEGIN();
+#if OZ2_F8_SEGS == 4
+                // four segments (row half x column half) of 8 MFMAs; every fragment of the K-step stays resident (A 64 + B 32 registers),
+                // so the LDS reads are spread 12 / 8 / 4 / 0 over the LOAD segments and the DMA 2 per segment (A waves) / 4 + 4 (B waves)
+                v8i bf[4], af[8];
 #pragma unroll
-                for (int ks2 = 0; ks2 < 2; ++ks2) {
-                    const int c0 = ks2 * 4 + khalf * 2;
-                    v8i bf[2];
+                for (int seg = 0; seg < 4; ++seg) {
+                    const int ah = seg >> 1, bh = seg & 1;
+                    if constexpr (ISB) {
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        v8i af[2];
-                        const int seg = ks2 * 2 + half;  // LOAD segment 0..3 of this K-step
-                        if constexpr (ISB) {
+                        for (int q8 = 0; q8 < 8; ++q8)
+                            if (q8 / 4 == seg) F8_DMA(fsrc, q8, fdst);
+                    } else {
 #pragma unroll
-                            for (int q = 0; q < 8; ++q)
-                                if (q * F8_PB / 8 == seg) F8_DMA(fsrc, q, fdst);
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < 2; ++q) F8_DMA(fsrc, seg * 2 + q, fdst);
-                        }
-                        if (half == 0) {
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) bf[j] = frag(curB + j * 32 * BK, c0);
-                        }
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) af[i] = frag(curA + (half * 2 + i) * 32 * BK, c0);
-                        if (seg == 3 && !ISB) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-                        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_sched_barrier(0);
-                        __builtin_amdgcn_s_barrier();
-                        __builtin_amdgcn_sched_barrier(0);
-                        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j)
-                                acc[half * 2 + i][j] =
-                                    __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[i], bf[j], acc[half * 2 + i][j], 0, 0, 0, UNIT, 0, UNIT);
-                        __builtin_amdgcn_s_setprio(0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (seg == 3 && ISB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();
-                        __builtin_amdgcn_sched_barrier(0);
+                        for (int q8 = 0; q8 < 2; ++q8) F8_DMA(fsrc, seg * 2 + q8, fdst);
                     }
+                    if (seg == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) af[i] = frag(curA + i * 16 * BK);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) bf[j] = frag(curB + j * 16 * BK);
+                    } else if (seg == 1) {
+#pragma unroll
+                        for (int j = 2; j < 4; ++j) bf[j] = frag(curB + j * 16 * BK);
+#pragma unroll
+                        for (int i = 4; i < 6; ++i) af[i] = frag(curA + i * 16 * BK);
+                    } else if (seg == 2) {
+#pragma unroll
+                        for (int i = 6; i < 8; ++i) af[i] = frag(curA + i * 16 * BK);
+                    }
+                    if (seg == 3 && !ISB) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[ah * 4 + i][bh * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[ah * 4 + i], bf[bh * 2 + j],
+                                                                                                           acc[ah * 4 + i][bh * 2 + j], 0, 0, 0, UNIT, 0, UNIT);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (seg == 3 && ISB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+#else
+                v8i bf[4];
+#pragma unroll
+                for (int ah = 0; ah < 2; ++ah) {  // LOAD segment ah of this K-step
+                    v8i af[4];
+                    if constexpr (ISB) {
+                        if (ah == 0) {
+#pragma unroll
+                            for (int q8 = 0; q8 < 8; ++q8) F8_DMA(fsrc, q8, fdst);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q8 = 0; q8 < 4; ++q8) F8_DMA(fsrc, ah * 4 + q8, fdst);
+                    }
+                    if (ah == 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bf[j] = frag(curB + j * 16 * BK);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i] = frag(curA + (ah * 4 + i) * 16 * BK);
+                    if (ah == 1 && !ISB) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[ah * 4 + i][j] =
+                                __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[i], bf[j], acc[ah * 4 + i][j], 0, 0, 0, UNIT, 0, UNIT);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ah == 1 && ISB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#endif
             }
             const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n);
             const int i0 = tmap.tm * BM + wm * 128, j0 = tmap.tn * BN + wn * 64;

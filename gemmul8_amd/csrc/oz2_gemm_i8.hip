@@ -202,10 +202,10 @@ __device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmAr
             const int col = j0 + tj * 16 + c16;
             if (q == 0 && col < args.n && cm > 0) atomicMax(args.colmax + col, cm);
         }
-        // row max across the 16 lanes (columns) of each quad, for each of the 32 rows this lane touches
-        int w[32];
+        // row max across the 16 lanes (columns) of each quad, one 16-row tile row at a time
 #pragma unroll
-        for (int ti = 0; ti < 8; ++ti)
+        for (int ti = 0; ti < 8; ++ti) {
+            int w[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int v = 0;
@@ -215,14 +215,24 @@ __device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmAr
                     const int a = (col < args.n) ? acc[ti][tj][r] : 0;
                     v = a > v ? a : v;
                 }
-                w[ti * 4 + r] = v;
+                w[r] = v;
             }
-        wave_rowmax_atomic16(w, args.rowmax, i0, args.m, lane);
+            tile_rowmax_atomic16(w, args.rowmax, i0 + ti * 16, args.m, lane);
+        }
     }
 }
 
 #ifndef OZ2_PB
 #define OZ2_PB 4
+#endif
+#ifndef OZ2_KBAR_MAX_KP
+#define OZ2_KBAR_MAX_KP 4096  // padded k up to which the K-step-barrier schedule is used (see launch<EPI>); 0 = never, 1 << 30 = always
+#endif
+#ifndef OZ2_SLEEP_A
+#define OZ2_SLEEP_A 4  // s_sleep units (64 clocks) between the A producers' 8 groups of 2 LDS-DMA instructions
+#endif
+#ifndef OZ2_SLEEP_B
+#define OZ2_SLEEP_B 4  // ... between the B producers' 4 groups of 4
 #endif
 constexpr int RING_LDS_BYTES = 5 * TILE_BYTES;  // five 32 KiB operand panels = the whole 160 KiB of LDS
 
@@ -235,7 +245,7 @@ constexpr int RING_LDS_BYTES = 5 * TILE_BYTES;  // five 32 KiB operand panels = 
 // are in the last K-step and the epilogue of a tile the producers already fetch the first K-tile of the next one, the
 // epilogue's stores drain behind the next tile's MFMAs, and there is no workgroup launch / LDS re-allocation between
 // tiles -- a non-persistent version of this kernel lost ~11 us of a ~120 us tile to those three.
-template <int EPI>
+template <int EPI, bool KBAR>
 __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -326,6 +336,38 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
         if (ahead) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if constexpr (KBAR) {
+        // ONE workgroup barrier per K-step (see the consumer branch).  Without per-segment barriers to pace them the producers space
+        // their instructions with s_sleep (64 clocks per unit): bursts of LDS-DMA cost (all 16 at once: +7 % kernel time).
+        for (int vb = blockIdx.x; vb < total; vb += G) {
+            for (int kt = 0; kt < KT; ++kt) {
+                const bool issued = more && (!(OZ2_PROBE_LDS & 4) || vb == (int)blockIdx.x);  // probe bit 2: DMA during the first tile only
+                if (issued) {
+                    PRODUCER_BEGIN();
+                    if (isB) {  // needed next K-step: 4 groups of 4 in the first part of the K-step
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) PRODUCER_DMA(fsrc, gq * 4 + q, fdst);
+                            __builtin_amdgcn_s_sleep(OZ2_SLEEP_B);
+                        }
+                    } else {    // needed in two K-steps: 8 groups of 2 over the whole K-step
+#pragma unroll
+                        for (int gq = 0; gq < 8; ++gq) {
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) PRODUCER_DMA(fsrc, gq * 2 + q, fdst);
+                            __builtin_amdgcn_s_sleep(OZ2_SLEEP_A);
+                        }
+                    }
+                    PRODUCER_ADVANCE();
+                }
+                // the panel needed NEXT K-step must have landed: for the A producers everything except the 16 instructions just issued
+                if (!isB && issued) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        } else {
         for (int vb = blockIdx.x; vb < total; vb += G) {
             for (int kt = 0; kt < KT; ++kt) {
                 // A producers: A(g+2); B producers: B(g+1); afterwards the panel needed NEXT K-step must have landed, which
@@ -357,6 +399,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
             }
         }
         __builtin_amdgcn_s_barrier();
+        }
 #undef PRODUCER_FETCH
 #undef PRODUCER_BEGIN
 #undef PRODUCER_ADVANCE
@@ -379,6 +422,87 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     const int a_base = (wm * 128 + r16) * BK;
     const int b_base = (wn * 64 + r16) * BK;
 
+    if constexpr (KBAR) {
+    // K-step-barrier schedule: ONE workgroup barrier per K-step -- the only one the LDS ring needs (RAW: the producers' vmcnt wait for
+    // panel g + 1 precedes it; WAR: every read of K-step g precedes it, every refill of those slots follows it).  The two waves of a
+    // SIMD stay in anti-phase by construction instead of by per-segment barriers: the wm = 0 half runs L0 M0 L1 M1 L2 M2 L3 M3 inside
+    // a K-step, the wm = 1 half M3' L0 M0 L1 M1 L2 M2 L3 (M3' = the last MFMA segment of the PREVIOUS K-step, whose fragments it
+    // keeps in registers across the barrier), so one wave's LDS reads always sit beside the other's MFMAs, and when both have MFMAs
+    // ready they simply share the pipe.  The per-segment barriers of the ping-pong version cost ~7 % (every hand-over idles the
+    // matrix pipe for the barrier latency: mfma-only probe 3.70 vs 3.97 POP/s free-running).
+    __builtin_amdgcn_s_barrier();  // K-tile 0 published by the producers
+    // the whole persistent loop is instantiated once per half (WM1 = lagging half) so that each gets its own register allocation
+    auto run = [&]<bool WM1>() {
+        int sA = 0;  // slot of A(g); B(g) sits in the next slot (mod 5)
+        for (int vb = blockIdx.x; vb < total; vb += G) {
+            v4i acc[8][4];
+            v4i af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = 0;
+#define OZ2_LOAD_SEG(seg_)                                                                                                   \
+    do {                                                                                                                     \
+        const int coff_ = (((((seg_) >> 1) << 2) | q) ^ sw) << 4;                                                            \
+        if (((seg_) & 1) == 0) {                                                                                             \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) bf[j] = *(const v4i*)(curB + j * 16 * BK + coff_);                 \
+        }                                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) af[i] = *(const v4i*)(curA + (((seg_) & 1) * 4 + i) * 16 * BK + coff_); \
+    } while (0)
+#define OZ2_MMA_SEG(seg_)                                                                                                    \
+    do {                                                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                          \
+            acc[((seg_) & 1) * 4 + i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[((seg_) & 1) * 4 + i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    } while (0)
+#define OZ2_SET_PANELS()                                                                                                     \
+    const char* curA = smem + sA * TILE_BYTES + a_base;                                                                      \
+    const char* curB = smem + (sA == 4 ? 0 : sA + 1) * TILE_BYTES + b_base;                                                  \
+    sA = sA + 2 >= 5 ? sA - 3 : sA + 2
+            for (int kt = 0; kt < KT; ++kt) {
+                OZ2_SET_PANELS();
+#pragma unroll
+                for (int seg = 0; seg < 4; ++seg) {
+                    OZ2_LOAD_SEG(seg);
+                    // the lagging half crosses the K-step barrier between its last LOAD and its last MFMA segment (all its LDS reads of the
+                    // K-step precede the barrier; the fragments cross it in registers): same instruction stream, shifted by one segment
+                    if (WM1 && seg == 3) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    OZ2_MMA_SEG(seg);
+                }
+                if (!WM1) {
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#undef OZ2_SET_PANELS
+#undef OZ2_LOAD_SEG
+#undef OZ2_MMA_SEG
+            const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n);
+#if OZ2_PROBE_LDS & 8
+            (void)tmap;  // probe bit 3: no epilogue; the accumulators stay live
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+#else
+            i8_epilogue<EPI>(acc, args, tmap.plane, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane);
+#endif
+        }
+    };
+    if (wm == 0) run.template operator()<false>();
+    else run.template operator()<true>();
+    } else {
     __builtin_amdgcn_s_barrier();               // K-tile 0 published by the producers
     if (wm == 1) __builtin_amdgcn_s_barrier();  // trailing half: one segment behind
     int sA = 0;                                  // slot of A(g); B(g) sits in the next slot (mod 5)
@@ -446,6 +570,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #endif
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();
+    }
 }
 
 static void fill_common(GemmArgs& a, size_t kp, size_t m, size_t n) {
@@ -472,27 +597,37 @@ static int num_cus() {
     return n;
 }
 
-template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int planes) {
+template <int EPI, bool KBAR> static hipError_t launch_sched(hipStream_t stream, GemmArgs& a) {
     // the attribute belongs to the function on ONE device; setting it is idempotent, so concurrent first calls from several host
     // threads only need the flag itself to be race-free
     static std::atomic<bool> attr_set_dev[64];
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 0;
     if (!attr_set_dev[dev_].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_kernel<EPI, KBAR>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set_dev[dev_].store(true, std::memory_order_release);
     }
-    a.total_tiles = planes * a.tiles_m * a.tiles_n;
-    if (a.total_tiles <= 0) return hipSuccess;
     // persistent: one workgroup per CU; a multiple of 8 keeps "workgroup b runs on XCD b % 8" aligned with map_tile.
     // Measured interleaved against one-workgroup-per-tile launches of the same kernel (tools/gemm_ab.py, 8192 x 8192 x k,
     // 14 planes): 13 % faster at k = 256, 7 % at k = 2048, 1 % at k = 8192.
     int grid = num_cus() & ~7;
     if (grid <= 0) grid = 8;
     if (a.total_tiles < grid) grid = a.total_tiles;
-    hipLaunchKernelGGL(gemm_i8_kernel<EPI>, dim3(grid), dim3(WS_THREADS), RING_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((gemm_i8_kernel<EPI, KBAR>), dim3(grid), dim3(WS_THREADS), RING_LDS_BYTES, stream, a);
     return hipGetLastError();
+}
+
+// Two schedules of the same tile loop (bit-identical results): with a workgroup barrier after every LOAD / MFMA segment (ping-pong)
+// or with one barrier per K-step.  Interleaved on one box (tools/gemm_ab.py, 8192^2 x k, 14 planes, profiles/r02_sched_ab.txt): the
+// K-step-barrier form is faster by 10 / 7.5 / 4.7 / 2.4 % at k = 512 / 1024 / 2048 / 4096 (tile boundaries -- epilogue beside the
+// other half's first K-steps -- overlap better) and 2.4 % slower at k = 8192, where the board is power-bound and removing stalls
+// buys nothing while the s_sleep-paced LDS-DMA is a little less smooth than the barrier-paced one.
+template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int planes) {
+    a.total_tiles = planes * a.tiles_m * a.tiles_n;
+    if (a.total_tiles <= 0) return hipSuccess;
+    if (a.kp * a.nseg <= OZ2_KBAR_MAX_KP) return launch_sched<EPI, true>(stream, a);
+    return launch_sched<EPI, false>(stream, a);
 }
 
 hipError_t launch_gemm_i8_mod(hipStream_t stream, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp, size_t m,

@@ -1,4 +1,4 @@
-// LD_PRELOAD hipBLAS hook: hipblas{S,D,C,Z}gemm, hipblasGemmEx, their strided-batched forms and hipblasDestroy are intercepted
+// LD_PRELOAD hipBLAS hook: hipblas{S,D,C,Z}gemm, hipblasGemmEx, their strided-batched forms, hipblasLtMatmul and hipblasDestroy are intercepted
 // and routed to the Ozaki-II emulation (C ABI, gemmul8_c.h) according to the GEMMUL8_* environment
 // variables; everything else -- and every call the environment does not select -- is passed to the
 // real library found with dlsym(RTLD_NEXT).
@@ -12,6 +12,8 @@
 //     GEMMUL8_MAX_{M,N,K}, GEMMUL8_MAX_NUM_MOD, GEMMUL8_MAXWS_BACKEND (read once): workspace
 //       pre-sizing applied when a SKIP_SCALE switch is on                      hook.cu:232-281,656-662
 //   early outs: m|n|k <= 0 -> SUCCESS, null A/B/C -> INVALID_VALUE            hook.cu:616-617
+//   GEMMUL8_DIST (this build only)  blocks | moduli | fp64sum: shard every emulated GEMM over the ranks of an SPMD job (see try_dist)
+//   GEMMUL8_MIN_FLOPS (this build only) calls below 2*m*n*k of it use the native routine (default 0: emulate everything)
 //   per-handle state under a mutex: three grow-only stream-ordered buffers (hipMallocAsync /
 //   hipFreeAsync), event hand-off when the handle's stream changes, skip-scaling cache
 //   (hook.cu:70-162,331-374,684-727); hipblasDestroy frees the state first (hook.cu:846-856).
@@ -27,8 +29,11 @@
 #include <memory>
 #include <mutex>
 #include <unordered_map>
+#include <utility>
+#include <vector>
 
 #include "../../include/gemmul8_c.h"
+#include "../../include/gemmul8_dist.h"
 
 #ifdef OZ2_HOOK_SHIM
 // Preload shim for hosts that load their HIP runtime late and privately (Python/PyTorch): this library contains no device
@@ -42,6 +47,11 @@ struct Abi {
     size_t (*work_size)(int, int, size_t, size_t, size_t, unsigned, int, int, size_t*, size_t*) = nullptr;
     int (*gemm)(void*, int, int, int, int, size_t, size_t, size_t, const void*, const void*, size_t, const void*, size_t, const void*, void*,
                 size_t, unsigned, int, void*, void*, void*, int, int, int, int, double*) = nullptr;
+    decltype(&::gemmul8_comm_rccl_from_env) comm_from_env = nullptr;
+    decltype(&::gemmul8_dist_create) dist_create = nullptr;
+    decltype(&::gemmul8_dist_gemm) dist_gemm = nullptr;
+    decltype(&::gemmul8_dist_allgather_c) dist_allgather_c = nullptr;
+    decltype(&::gemmul8_dist_destroy) dist_destroy = nullptr;
 };
 const Abi& abi() {
     static const Abi a = [] {
@@ -72,7 +82,12 @@ const Abi& abi() {
         }
         r.work_size = (decltype(r.work_size))dlsym(h, "gemmul8_work_size");
         r.gemm = (decltype(r.gemm))dlsym(h, "gemmul8_gemm");
-        if (!r.work_size || !r.gemm) {
+        r.comm_from_env = (decltype(r.comm_from_env))dlsym(h, "gemmul8_comm_rccl_from_env");
+        r.dist_create = (decltype(r.dist_create))dlsym(h, "gemmul8_dist_create");
+        r.dist_gemm = (decltype(r.dist_gemm))dlsym(h, "gemmul8_dist_gemm");
+        r.dist_allgather_c = (decltype(r.dist_allgather_c))dlsym(h, "gemmul8_dist_allgather_c");
+        r.dist_destroy = (decltype(r.dist_destroy))dlsym(h, "gemmul8_dist_destroy");
+        if (!r.work_size || !r.gemm || !r.comm_from_env || !r.dist_create || !r.dist_gemm || !r.dist_allgather_c || !r.dist_destroy) {
             std::fprintf(stderr, "[GEMMUL8 HOOK] libgemmul8.so lacks the C ABI entry points\n");
             std::abort();
         }
@@ -83,6 +98,11 @@ const Abi& abi() {
 }  // namespace
 #define gemmul8_work_size abi().work_size
 #define gemmul8_gemm abi().gemm
+#define gemmul8_comm_rccl_from_env abi().comm_from_env
+#define gemmul8_dist_create abi().dist_create
+#define gemmul8_dist_gemm abi().dist_gemm
+#define gemmul8_dist_allgather_c abi().dist_allgather_c
+#define gemmul8_dist_destroy abi().dist_destroy
 #endif
 
 namespace {
@@ -201,29 +221,34 @@ hipblasStatus_t grow(Buffer& b, size_t need, hipStream_t stream, const char* tag
 
 // The real hipBLAS entry point: the next definition in the global search order, or -- when the host loaded hipBLAS privately
 // (Python extension modules are dlopen'ed RTLD_LOCAL) -- the copy of libhipblas that is already mapped into the process.
-void* mapped_hipblas() {
-    static void* h = [] {
-        void* r = nullptr;
-        if (FILE* f = std::fopen("/proc/self/maps", "r")) {
-            char line[1024];
-            while (std::fgets(line, sizeof line, f)) {
-                if (!std::strstr(line, "libhipblas.so")) continue;  // not libhipblaslt
-                char* path = std::strchr(line, '/');
-                if (!path) continue;
-                path[std::strcspn(path, "\n")] = 0;
-                r = dlopen(path, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
-                if (r) break;
-            }
-            std::fclose(f);
+void* mapped_library(const char* needle) {
+    void* r = nullptr;
+    if (FILE* f = std::fopen("/proc/self/maps", "r")) {
+        char line[1024];
+        while (std::fgets(line, sizeof line, f)) {
+            if (!std::strstr(line, needle)) continue;
+            char* path = std::strchr(line, '/');
+            if (!path) continue;
+            path[std::strcspn(path, "\n")] = 0;
+            r = dlopen(path, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+            if (r) break;
         }
-        return r;
-    }();
+        std::fclose(f);
+    }
+    return r;
+}
+void* mapped_hipblas() {
+    static void* h = mapped_library("libhipblas.so");  // not libhipblaslt
+    return h;
+}
+void* mapped_hipblaslt() {
+    static void* h = mapped_library("libhipblaslt.so");
     return h;
 }
 template <typename Fn> Fn real_fn(const char* name) {
     void* f = dlsym(RTLD_NEXT, name);
     if (!f)
-        if (void* h = mapped_hipblas()) f = dlsym(h, name);
+        if (void* h = (std::strncmp(name, "hipblasLt", 9) == 0 ? mapped_hipblaslt() : mapped_hipblas())) f = dlsym(h, name);
     return reinterpret_cast<Fn>(f);
 }
 
@@ -253,11 +278,87 @@ hipblasStatus_t order_streams(HandleState& st, hipStream_t cur) {
 }
 
 // returns true and sets *status when the call was emulated; false -> caller passes through
+// ---- GEMMUL8_DIST = blocks | moduli | fp64sum (not in the reference, which is single-GPU): an SPMD application -- every rank of a
+// torchrun / mpirun job issuing the SAME GEMM calls on replicated operands, RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in its
+// environment -- gets each emulated GEMM sharded over the ranks' GPUs by the plans of include/gemmul8_dist.h; the result is
+// all-gathered so that every rank ends up with the full C, as it would without the hook.  One RCCL communicator per process, a
+// small cache of plans keyed by the call's shape (a plan owns its workspaces).
+struct DistKey {
+    int kind, dtype, backend, ta, tb, fast;
+    size_t m, n, k;
+    unsigned N;
+    bool operator==(const DistKey& o) const {
+        return kind == o.kind && dtype == o.dtype && backend == o.backend && ta == o.ta && tb == o.tb && fast == o.fast && m == o.m && n == o.n &&
+               k == o.k && N == o.N;
+    }
+};
+struct DistState {
+    std::mutex mtx;
+    gemmul8_comm* comm = nullptr;
+    bool failed = false;
+    std::vector<std::pair<DistKey, gemmul8_dist_plan*>> plans;  // most recently used last; at most 8
+};
+DistState g_dist;
+
+int dist_kind_from_env() {
+    const char* s = std::getenv("GEMMUL8_DIST");
+    if (!s || !*s || !std::strcmp(s, "0")) return -1;
+    if (!std::strcmp(s, "moduli")) return GEMMUL8_DIST_MODULI;
+    if (!std::strcmp(s, "fp64sum")) return GEMMUL8_DIST_MODULI_FP64SUM;
+    return GEMMUL8_DIST_BLOCKS;  // "1", "blocks"
+}
+
+// returns true when the sharded path took the call (status in *status); false -> single-GPU emulation
+bool try_dist(int kind, int dtype, int backend, hipblasOperation_t ta, hipblasOperation_t tb, int m, int n, int k, const void* alpha, const void* A,
+              int lda, const void* B, int ldb, const void* beta, void* C, int ldc, unsigned N, bool fastmode, hipStream_t stream,
+              hipblasStatus_t* status) {
+    std::lock_guard<std::mutex> lk(g_dist.mtx);
+    if (g_dist.failed) return false;
+    if (!g_dist.comm) {
+        const int rc = gemmul8_comm_rccl_from_env(&g_dist.comm);
+        if (rc != 0 || !g_dist.comm) {
+            std::fprintf(stderr, "[GEMMUL8 HOOK] GEMMUL8_DIST is set but no RCCL communicator could be created (status %d; RANK/WORLD_SIZE/"
+                                 "MASTER_ADDR/MASTER_PORT?): single-GPU emulation\n", rc);
+            g_dist.failed = true;
+            return false;
+        }
+    }
+    const DistKey key{kind, dtype, backend, (int)ta, (int)tb, fastmode ? 1 : 0, (size_t)m, (size_t)n, (size_t)k, N};
+    gemmul8_dist_plan* plan = nullptr;
+    for (size_t i = 0; i < g_dist.plans.size(); ++i)
+        if (g_dist.plans[i].first == key) {
+            plan = g_dist.plans[i].second;
+            std::rotate(g_dist.plans.begin() + i, g_dist.plans.begin() + i + 1, g_dist.plans.end());
+            break;
+        }
+    if (!plan) {
+        if (g_dist.plans.size() >= 8) {  // plans own workspaces of the problem's size: keep only a few
+            (void)hipStreamSynchronize(stream);
+            gemmul8_dist_destroy(g_dist.plans.front().second);
+            g_dist.plans.erase(g_dist.plans.begin());
+        }
+        const int rc = gemmul8_dist_create(g_dist.comm, nullptr, kind, 0, dtype, backend, (int)ta, (int)tb, (size_t)m, (size_t)n, (size_t)k, N,
+                                           fastmode ? 1 : 0, &plan);
+        if (rc != 0 || !plan) return false;  // outside the emulator's range etc.: let the single-GPU path decide
+        g_dist.plans.emplace_back(key, plan);
+    }
+    int rc = gemmul8_dist_gemm(plan, stream, alpha, A, (size_t)lda, B, (size_t)ldb, beta, C, (size_t)ldc);
+    if (rc == 0) rc = gemmul8_dist_allgather_c(plan, stream, C, (size_t)ldc);
+    *status = rc == 0 ? HIPBLAS_STATUS_SUCCESS : HIPBLAS_STATUS_INTERNAL_ERROR;
+    return true;
+}
+
+// explicit_stream: hipblasLtMatmul carries its stream as an argument (a hipblasLt handle has none)
 bool try_emulate(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, hipblasOperation_t tb, int m, int n, int k, const void* alpha,
-                 const void* A, int lda, const void* B, int ldb, const void* beta, void* C, int ldc, hipblasStatus_t* status) {
+                 const void* A, int lda, const void* B, int ldb, const void* beta, void* C, int ldc, hipblasStatus_t* status,
+                 const hipStream_t* explicit_stream = nullptr) {
     const TypeInfo& ti = kTypes[dtype];
     const unsigned N = (unsigned)env_u64(ti.nmod, 0);
     if (N < 2u || N > ti.max_moduli) return false;
+    // GEMMUL8_MIN_FLOPS (not in the reference; default 0 = emulate every call like the reference): calls with 2*m*n*k below it go to
+    // the native routine -- below ~2048^3 the emulation is launch-bound (ten kernels) and slower than native (profiles/sweeps)
+    const unsigned long long floor_flops = env_u64("GEMMUL8_MIN_FLOPS", 0);
+    if (floor_flops && 2.0 * (double)m * (double)n * (double)k < (double)floor_flops) return false;
     const bool fastmode = env_one(ti.fast);
     const bool enA = env_one("GEMMUL8_SKIP_SCALE_A"), enB = env_one("GEMMUL8_SKIP_SCALE_B");
     const int backend = env_backend("GEMMUL8_BACKEND", 0, false);
@@ -265,10 +366,14 @@ bool try_emulate(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, hipbl
     auto sp = state_of(handle);
     std::lock_guard<std::mutex> lk(sp->mtx);
     init_max_workspace();
-    hipblasStatus_t st;
-    hipStream_t stream = handle_stream(handle, &st);
+    hipblasStatus_t st = HIPBLAS_STATUS_SUCCESS;
+    hipStream_t stream = explicit_stream ? *explicit_stream : handle_stream(handle, &st);
     if (st != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
     if ((st = order_streams(*sp, stream)) != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
+
+    const int dist_kind = dist_kind_from_env();
+    if (dist_kind >= 0 && try_dist(dist_kind, dtype, backend, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, N, fastmode, stream, status))
+        return true;
 
     size_t needA = 0, needB = 0;
     const size_t tot = gemmul8_work_size(ti.cplx, backend, (size_t)m, (size_t)n, (size_t)k, N, enA, enB, &needA, &needB);
@@ -552,4 +657,162 @@ hipblasStatus_t hipblasGemmStridedBatchedEx(hipblasHandle_t handle, hipblasOpera
 }
 
 }  // extern "C"
+
+// ---- hipblasLtMatmul (not hooked by the reference; PyTorch on ROCm routes most float32 matmuls through hipBLASLt, so without
+// this GEMMUL8_NUM_MOD_S is a no-op for them).  Only the plain case is emulated: D = alpha*op(A)*op(B) + beta*C with A, B, C, D of
+// one type in {float, double, complex float, complex double}, column-major order, no batch, default epilogue, no scale pointers,
+// host or device scalars; everything else goes to the real routine untouched.  C != D is served in place on D after a copy of C.
+#include <hipblaslt/hipblaslt.h>
+namespace {
+struct LtLayout {
+    int32_t type = -1, order = -1, batch = 1;
+    uint64_t rows = 0, cols = 0;
+    int64_t ld = 0;
+};
+// hipBLASLt (ROCm 7.2) cannot be asked what a matrix layout holds -- hipblasLtMatrixLayoutGetAttribute answers only the two batch
+// attributes -- so the hook records type / rows / cols / ld / order / batch when a layout is created or modified
+// (hipblasLtMatrixLayoutCreate / SetAttribute / Destroy are interposed below) and reads its own table here.
+std::mutex g_lt_mtx;
+std::unordered_map<hipblasLtMatrixLayout_t, LtLayout> g_lt_layouts;
+bool lt_layout(hipblasLtMatrixLayout_t L, LtLayout* o) {
+    std::lock_guard<std::mutex> g(g_lt_mtx);
+    auto it = g_lt_layouts.find(L);
+    if (it == g_lt_layouts.end()) return false;  // created before the hook was loaded, or by an interface we do not see
+    *o = it->second;
+    return true;
+}
+// GEMMUL8_HOOK_VERBOSE=1: say why a hipblasLtMatmul call was left to the native routine
+bool lt_decline(const char* why) {
+    if (env_one("GEMMUL8_HOOK_VERBOSE")) std::fprintf(stderr, "[GEMMUL8 HOOK] hipblasLtMatmul -> native: %s\n", why);
+    return false;
+}
+// returns true when the call was emulated (status in *st)
+bool lt_try(hipblasLtHandle_t handle, hipblasLtMatmulDesc_t desc, const void* alpha, const void* A, hipblasLtMatrixLayout_t Ad, const void* B,
+            hipblasLtMatrixLayout_t Bd, const void* beta, const void* C, hipblasLtMatrixLayout_t Cd, void* D, hipblasLtMatrixLayout_t Dd,
+            hipStream_t stream, hipblasStatus_t* st) {
+    if (!desc || !alpha || !beta || !A || !B || !D) return lt_decline("null argument");
+    using DescGet = hipblasStatus_t (*)(hipblasLtMatmulDesc_t, hipblasLtMatmulDescAttributes_t, void*, size_t, size_t*);
+    static DescGet dget = real_fn<DescGet>("hipblasLtMatmulDescGetAttribute");
+    if (!dget) return lt_decline("hipblasLtMatmulDescGetAttribute not found");
+    size_t w = 0;
+    int32_t ta = 0, tb = 0;
+    uint32_t epi = 0;
+    if (dget(desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof ta, &w) != HIPBLAS_STATUS_SUCCESS) return lt_decline("TRANSA unreadable");
+    if (dget(desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof tb, &w) != HIPBLAS_STATUS_SUCCESS) return lt_decline("TRANSB unreadable");
+    if (dget(desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof epi, &w) != HIPBLAS_STATUS_SUCCESS || epi != HIPBLASLT_EPILOGUE_DEFAULT)
+        return lt_decline("epilogue is not the default one");
+    for (auto attr : {HIPBLASLT_MATMUL_DESC_A_SCALE_POINTER, HIPBLASLT_MATMUL_DESC_B_SCALE_POINTER, HIPBLASLT_MATMUL_DESC_C_SCALE_POINTER,
+                      HIPBLASLT_MATMUL_DESC_D_SCALE_POINTER, HIPBLASLT_MATMUL_DESC_AMAX_D_POINTER}) {
+        void* ptr = nullptr;
+        if (dget(desc, attr, &ptr, sizeof ptr, &w) == HIPBLAS_STATUS_SUCCESS && ptr) return lt_decline("scale / amax pointer set");
+    }
+    int32_t pmode = 0;
+    if (dget(desc, HIPBLASLT_MATMUL_DESC_POINTER_MODE, &pmode, sizeof pmode, &w) == HIPBLAS_STATUS_SUCCESS && pmode != HIPBLASLT_POINTER_MODE_HOST &&
+        pmode != HIPBLASLT_POINTER_MODE_DEVICE)
+        return lt_decline("device-vector scalars");
+    LtLayout a, b, c, d;
+    if (!lt_layout(Ad, &a) || !lt_layout(Bd, &b) || !lt_layout(Dd, &d)) return lt_decline("a matrix layout was not created under the hook");
+    const bool haveC = C && Cd;
+    if (haveC && !lt_layout(Cd, &c)) return lt_decline("the C layout was not created under the hook");
+    if (!haveC) c = d;
+    if (a.type != b.type || a.type != d.type || c.type != d.type) return lt_decline("mixed matrix types");
+    int dtype = -1;
+    switch (a.type) {
+    case HIP_R_32F: dtype = GEMMUL8_S; break;
+    case HIP_R_64F: dtype = GEMMUL8_D; break;
+    case HIP_C_32F: dtype = GEMMUL8_C; break;
+    case HIP_C_64F: dtype = GEMMUL8_Z; break;
+    default: return lt_decline("not an S/D/C/Z matrix type");
+    }
+    if (a.order != HIPBLASLT_ORDER_COL || b.order != HIPBLASLT_ORDER_COL || c.order != HIPBLASLT_ORDER_COL || d.order != HIPBLASLT_ORDER_COL) return lt_decline("not column-major");
+    if (a.batch != 1 || b.batch != 1 || c.batch != 1 || d.batch != 1) return lt_decline("batched");
+    const uint64_t m = d.rows, n = d.cols, k = (ta == HIPBLAS_OP_N) ? a.cols : a.rows;
+    if ((ta == HIPBLAS_OP_N ? a.rows : a.cols) != m || (tb == HIPBLAS_OP_N ? b.cols : b.rows) != n || (tb == HIPBLAS_OP_N ? b.rows : b.cols) != k)
+        return lt_decline("inconsistent dimensions");
+    if (c.rows != m || c.cols != n || m == 0 || n == 0 || k == 0) return lt_decline("C / D shape");
+    if (!fits_int((int64_t)m, (int64_t)n, (int64_t)k, a.ld, b.ld, d.ld) || c.ld > 2147483647) return false;
+    const size_t esz = dtype == GEMMUL8_S ? 4 : dtype == GEMMUL8_Z ? 16 : 8;
+    // cheap env test before touching D: is emulation selected for this type at all?
+    const unsigned N = (unsigned)env_u64(kTypes[dtype].nmod, 0);
+    if (N < 2u || N > kTypes[dtype].max_moduli) return false;
+    const unsigned long long floor_flops = env_u64("GEMMUL8_MIN_FLOPS", 0);
+    if (floor_flops && 2.0 * (double)m * (double)n * (double)k < (double)floor_flops) return false;
+    if (k > (1u << 17) || (env_backend("GEMMUL8_BACKEND", 0, false) == 1 && k > 65536)) return false;  // outside the emulator's range
+    if (haveC && C != D) {  // out-of-place form: bring C into D, then update D in place (beta = 0 never reads it, but the copy is harmless)
+        if (hipMemcpy2DAsync(D, (size_t)d.ld * esz, C, (size_t)c.ld * esz, m * esz, n, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+            return *st = HIPBLAS_STATUS_INTERNAL_ERROR, true;
+    }
+    return try_emulate(dtype, (hipblasHandle_t)handle, (hipblasOperation_t)ta, (hipblasOperation_t)tb, (int)m, (int)n, (int)k, alpha, A, (int)a.ld, B,
+                       (int)b.ld, beta, D, (int)d.ld, st, &stream);
+}
+}  // namespace
+
+extern "C" hipblasStatus_t hipblasLtMatrixLayoutCreate(hipblasLtMatrixLayout_t* matLayout, hipDataType type, uint64_t rows, uint64_t cols, int64_t ld) {
+    using Fn = hipblasStatus_t (*)(hipblasLtMatrixLayout_t*, hipDataType, uint64_t, uint64_t, int64_t);
+    static Fn real = real_fn<Fn>("hipblasLtMatrixLayoutCreate");
+    if (!real) return HIPBLAS_STATUS_NOT_INITIALIZED;
+    const hipblasStatus_t st = real(matLayout, type, rows, cols, ld);
+    if (st == HIPBLAS_STATUS_SUCCESS && matLayout && *matLayout) {
+        LtLayout rec;
+        rec.type = (int32_t)type, rec.order = HIPBLASLT_ORDER_COL, rec.batch = 1, rec.rows = rows, rec.cols = cols, rec.ld = ld;
+        std::lock_guard<std::mutex> g(g_lt_mtx);
+        g_lt_layouts[*matLayout] = rec;
+    }
+    return st;
+}
+extern "C" hipblasStatus_t hipblasLtMatrixLayoutSetAttribute(hipblasLtMatrixLayout_t matLayout, hipblasLtMatrixLayoutAttribute_t attr, const void* buf,
+                                                             size_t sizeInBytes) {
+    using Fn = hipblasStatus_t (*)(hipblasLtMatrixLayout_t, hipblasLtMatrixLayoutAttribute_t, const void*, size_t);
+    static Fn real = real_fn<Fn>("hipblasLtMatrixLayoutSetAttribute");
+    if (!real) return HIPBLAS_STATUS_NOT_INITIALIZED;
+    const hipblasStatus_t st = real(matLayout, attr, buf, sizeInBytes);
+    if (st == HIPBLAS_STATUS_SUCCESS && buf) {
+        std::lock_guard<std::mutex> g(g_lt_mtx);
+        auto it = g_lt_layouts.find(matLayout);
+        if (it != g_lt_layouts.end()) {
+            LtLayout& r = it->second;
+            switch (attr) {
+            case HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT: if (sizeInBytes >= 4) std::memcpy(&r.batch, buf, 4); break;
+            case HIPBLASLT_MATRIX_LAYOUT_TYPE: if (sizeInBytes >= 4) std::memcpy(&r.type, buf, 4); break;
+            case HIPBLASLT_MATRIX_LAYOUT_ORDER: if (sizeInBytes >= 4) std::memcpy(&r.order, buf, 4); break;
+            case HIPBLASLT_MATRIX_LAYOUT_ROWS: if (sizeInBytes >= 8) std::memcpy(&r.rows, buf, 8); break;
+            case HIPBLASLT_MATRIX_LAYOUT_COLS: if (sizeInBytes >= 8) std::memcpy(&r.cols, buf, 8); break;
+            case HIPBLASLT_MATRIX_LAYOUT_LD: if (sizeInBytes >= 8) std::memcpy(&r.ld, buf, 8); break;
+            default: break;
+            }
+        }
+    }
+    return st;
+}
+extern "C" hipblasStatus_t hipblasLtMatrixLayoutDestroy(const hipblasLtMatrixLayout_t matLayout) {
+    {
+        std::lock_guard<std::mutex> g(g_lt_mtx);
+        g_lt_layouts.erase(matLayout);
+    }
+    using Fn = hipblasStatus_t (*)(const hipblasLtMatrixLayout_t);
+    static Fn real = real_fn<Fn>("hipblasLtMatrixLayoutDestroy");
+    return real ? real(matLayout) : HIPBLAS_STATUS_NOT_INITIALIZED;
+}
+
+// the per-handle state of an hipblasLt handle is released with the handle, as for hipblasDestroy
+extern "C" hipblasStatus_t hipblasLtDestroy(const hipblasLtHandle_t handle) {
+    release_state((hipblasHandle_t)handle);
+    using Fn = hipblasStatus_t (*)(const hipblasLtHandle_t);
+    static Fn real = real_fn<Fn>("hipblasLtDestroy");
+    return real ? real(handle) : HIPBLAS_STATUS_NOT_INITIALIZED;
+}
+
+extern "C" hipblasStatus_t hipblasLtMatmul(hipblasLtHandle_t handle, hipblasLtMatmulDesc_t matmulDesc, const void* alpha, const void* A,
+                                           hipblasLtMatrixLayout_t Adesc, const void* B, hipblasLtMatrixLayout_t Bdesc, const void* beta,
+                                           const void* C, hipblasLtMatrixLayout_t Cdesc, void* D, hipblasLtMatrixLayout_t Ddesc,
+                                           const hipblasLtMatmulAlgo_t* algo, void* workspace, size_t workspaceSizeInBytes, hipStream_t stream) {
+    hipblasStatus_t st;
+    if (lt_try(handle, matmulDesc, alpha, A, Adesc, B, Bdesc, beta, C, Cdesc, D, Ddesc, stream, &st)) return st;
+    using Fn = hipblasStatus_t (*)(hipblasLtHandle_t, hipblasLtMatmulDesc_t, const void*, const void*, hipblasLtMatrixLayout_t, const void*,
+                                   hipblasLtMatrixLayout_t, const void*, const void*, hipblasLtMatrixLayout_t, void*, hipblasLtMatrixLayout_t,
+                                   const hipblasLtMatmulAlgo_t*, void*, size_t, hipStream_t);
+    static Fn real = real_fn<Fn>("hipblasLtMatmul");
+    return real ? real(handle, matmulDesc, alpha, A, Adesc, B, Bdesc, beta, C, Cdesc, D, Ddesc, algo, workspace, workspaceSizeInBytes, stream)
+                : HIPBLAS_STATUS_NOT_INITIALIZED;
+}
 #pragma GCC visibility pop

@@ -33,3 +33,26 @@ def test_ld_preload_hook():
                "GEMMUL8_SKIP_SCALE_B": "1", "GEMMUL8_MAX_M": "256", "GEMMUL8_MAX_N": "256", "GEMMUL8_MAX_K": "1024",
                "GEMMUL8_MAX_NUM_MOD": "15"})
     assert "bitwise" in out
+
+
+def test_ld_preload_hook_hipblaslt_and_range_passthrough():
+    """hipblasLtMatmul interception (plain S / D matmul, in place and out of place: bitwise equal to the direct call; bias epilogue and
+    GEMMUL8_MIN_FLOPS floor: native) and the k > 2^17 passthrough of the hipBLAS hook."""
+    assert os.path.exists(os.path.join(BIN, "test_hook_lt")), "tests/cpp not built (run __graft_entry__.build())"
+    out = run([os.path.join(BIN, "test_hook_lt")], {"LD_PRELOAD": LIB, "GEMMUL8_NUM_MOD_D": "15", "GEMMUL8_NUM_MOD_S": "8"})
+    assert "hipblasLtMatmul<float>" in out and "hipblasLtMatmul<double>" in out and "passed to the native routine" in out
+
+
+@pytest.mark.parametrize("kind", ["blocks", "moduli", "fp64sum"])
+def test_ld_preload_hook_dist_opt_in_one_rank(kind):
+    """GEMMUL8_DIST: the hook's sharded path (RCCL communicator bootstrapped from RANK / WORLD_SIZE / MASTER_* inside libgemmul8.so,
+    plan cache, all-gather of C) with the one rank this box allows: the same C++ program, the same bits as the direct call."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = run([os.path.join(BIN, "test_hook")],
+              {"LD_PRELOAD": LIB, "GEMMUL8_NUM_MOD_D": "15", "GEMMUL8_NUM_MOD_S": "8", "GEMMUL8_DIST": kind, "RANK": "0", "WORLD_SIZE": "1",
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert "bitwise" in out

@@ -20,7 +20,9 @@ def _run(extra_env):
     assert out.returncode == 0, out.stderr[-2000:]
     m = re.search(r"TFLOPS, normwise err ([0-9.e+-]+)", out.stdout)
     mb = re.search(r"bmm normwise err ([0-9.e+-]+)", out.stdout)
-    assert m and mb, out.stdout
+    ms = re.search(r"sgemm normwise err ([0-9.e+-]+)", out.stdout)
+    assert m and mb and ms, out.stdout
+    _run.sgemm_err = float(ms.group(1))
     assert "graph replay equals eager: True" in out.stdout, out.stdout   # the hooked call captured in a HIP graph and replayed
     return float(m.group(1)), float(mb.group(1))
 
@@ -33,3 +35,16 @@ def test_torch_matmul_is_emulated_under_ld_preload():
     assert (passthrough, passthrough_b) == (native, native_b)
     assert native > 1e-15 and emulated < 1e-15, (native, emulated)
     assert native_b > 4e-16 and emulated_b < 4e-16, (native_b, emulated_b)     # torch.bmm -> strided-batched hook
+
+
+def test_torch_float32_matmul_is_emulated_under_ld_preload():
+    """float32 matmuls: whichever library PyTorch picks (hipBLASLt's hipblasLtMatmul or hipBLAS) the hook catches the call --
+    GEMMUL8_NUM_MOD_S=13 gives the correctly rounded float product where the native SGEMM carries ~sqrt(k) roundings."""
+    _run({})
+    native = _run.sgemm_err
+    _run({"LD_PRELOAD": SHIM, "GEMMUL8_NUM_MOD_S": "13"})
+    emulated = _run.sgemm_err
+    for prefer in ("1", "0"):
+        _run({"LD_PRELOAD": SHIM, "GEMMUL8_NUM_MOD_S": "13", "TORCH_BLAS_PREFER_HIPBLASLT": prefer})
+        assert _run.sgemm_err == emulated, (prefer, _run.sgemm_err, emulated)   # same bits through either library
+    assert emulated < 0.25 * native, (native, emulated)

@@ -15,6 +15,15 @@ ref = (A[:64].cpu().numpy().astype("longdouble") @ B.cpu().numpy().astype("longd
 err = float(abs(C[:64].cpu().numpy() - ref).max() / abs(ref).max())
 print(f"LD_PRELOAD={'yes' if 'gemmul8' in os.environ.get('LD_PRELOAD','') else 'no'}  torch DGEMM {n}^3: {2*n**3/dt*1e-12:.1f} TFLOPS, normwise err {err:.2e}")
 
+# float32: PyTorch on ROCm sends these to hipBLASLt (hipblasLtMatmul) or hipBLAS (hipblasSgemm / GemmEx) depending on shape and settings
+Af = (torch.rand((n, n), dtype=torch.float32, device="cuda") - 0.5)
+Bf = (torch.rand((n, n), dtype=torch.float32, device="cuda") - 0.5)
+Cf = Af @ Bf
+torch.cuda.synchronize()
+reff = Af[:64].double() @ Bf.double()
+errf = float(((Cf[:64].double() - reff).abs().max() / reff.abs().max()).item())
+print(f"torch SGEMM {n}^3: sgemm normwise err {errf:.2e}")
+
 # batched: torch.bmm -> hipblasDgemmStridedBatched / hipblasGemmStridedBatchedEx
 nb, b = 1024, 6
 X = torch.rand((b, nb, nb), dtype=torch.float64, device="cuda") - 0.5

@@ -10,6 +10,23 @@
 #include <cstdint>
 #include <cstring>
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 x e4m3, unit E8M0 scales): A / B operand (v8i) of lane l = row / column l & 15, 32 K values;
+// result as for the INT8 form.  Any assignment of the 128 K positions to (lane >> 4, byte) works as long as A and B use the same
+// one: the FP8 GEMM gives lane quad q the 16-byte chunks q and q + 4 of the 128-byte K-step (conflict-free LDS reads).
+__global__ void kf8(const unsigned char* A, const unsigned char* B, float* D) {
+    const int l = threadIdx.x, q = l >> 4;
+    auto frag = [&](const unsigned char* M) {
+        const v4i lo = *(const v4i*)(M + (l & 15) * 128 + 16 * q);
+        const v4i hi = *(const v4i*)(M + (l & 15) * 128 + 16 * (q + 4));
+        return v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    v4f c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(frag(A), frag(B), c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    for (int r = 0; r < 4; ++r) D[(4 * q + r) * 16 + (l & 15)] = c[r];
+}
 
 __global__ void k(const int8_t* A, const int8_t* B, int* D, unsigned* P) {
     const int l = threadIdx.x;
@@ -62,5 +79,35 @@ int main() {
         for (int l = 0; l < 64; ++l) printf(" %u", hP[192 + l]);
         printf("\n");
     }
-    return bad || b32 || b16;
+    // FP8: integers in [-16, 16] as e4m3 bytes (sign, 4-bit exponent bias 7, 3-bit mantissa)
+    auto e4m3 = [](int v) -> unsigned char {
+        if (v == 0) return 0;
+        const unsigned sgn = v < 0 ? 0x80u : 0u;
+        int a = v < 0 ? -v : v, e = 0;
+        while ((a >> (e + 1)) != 0) ++e;               // a in [2^e, 2^(e+1))
+        const int mant = ((a << 3) >> e) & 7;           // exact for a <= 16
+        return (unsigned char)(sgn | ((unsigned)(e + 7) << 3) | (unsigned)mant);
+    };
+    unsigned char fA[16 * 128], fB[16 * 128];
+    int iA[16 * 128], iB[16 * 128];
+    for (int i = 0; i < 16 * 128; ++i) {
+        s = s * 1664525u + 1013904223u, iA[i] = (int)((s >> 16) % 33u) - 16, fA[i] = e4m3(iA[i]);
+        s = s * 1664525u + 1013904223u, iB[i] = (int)((s >> 16) % 33u) - 16, fB[i] = e4m3(iB[i]);
+    }
+    unsigned char *dfA, *dfB;
+    float* dF;
+    hipMalloc(&dfA, sizeof fA), hipMalloc(&dfB, sizeof fB), hipMalloc(&dF, 256 * 4);
+    hipMemcpy(dfA, fA, sizeof fA, hipMemcpyHostToDevice), hipMemcpy(dfB, fB, sizeof fB, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(kf8, dim3(1), dim3(64), 0, 0, dfA, dfB, dF);
+    float hF[256];
+    hipMemcpy(hF, dF, sizeof hF, hipMemcpyDeviceToHost);
+    int badf = 0;
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            int ref = 0;
+            for (int kk = 0; kk < 128; ++kk) ref += iA[i * 128 + kk] * iB[j * 128 + kk];
+            badf += (float)ref != hF[i * 16 + j];
+        }
+    printf("mfma_scale_f32_16x16x128_f8f6f4 (e4m3, unit scales) lane maps: %s (%d of 256 differ)\n", badf ? "WRONG" : "as assumed", badf);
+    return bad || b32 || b16 || badf;
 }
