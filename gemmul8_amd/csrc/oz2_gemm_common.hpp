@@ -52,38 +52,6 @@ __device__ __forceinline__ TileMap map_tile(int bid, int nwg, int tiles_m, int t
     return t;
 }
 
-// Row maxima of a wave's 128-row accumulator block for the bound GEMM epilogues.  w[idx], idx = 16 i + r, is this lane's
-// (column-masked, non-negative) value for MFMA tile row i, accumulator register r; lanes 0-31 / 32-63 hold the same 64 idx
-// for two interleaved row sets (row = i0 + 32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  A butterfly reduce-scatter over
-// the 32 lanes of each half (62 exchanges instead of 64 x 5 for a full butterfly per row) leaves lane l with the finished
-// maxima of idx = 2 (l & 31) and 2 (l & 31) + 1, so the wave needs two fully populated atomicMax instructions instead
-// of 64 with two active lanes each.
-__device__ __forceinline__ void wave_rowmax_atomic(int (&w)[64], int* rowmax, int i0, int m, int lane) {
-    int n = 64;
-#pragma unroll
-    for (int bit = 16; bit >= 1; bit >>= 1) {
-        const int half = n >> 1;
-        const bool up = (lane & bit) != 0;  // this lane keeps the upper half of the index range
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            if (j < half) {
-                const int send = up ? w[j] : w[j + half];
-                const int keep = up ? w[j + half] : w[j];
-                const int got = __shfl_xor(send, bit);
-                w[j] = got > keep ? got : keep;
-            }
-        }
-        n = half;
-    }
-    const int khalf = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int idx = 2 * (lane & 31) + j;
-        const int row = i0 + (idx >> 4) * 32 + (idx & 3) + 8 * ((idx & 15) >> 2) + 4 * khalf;
-        if (row < m && w[j] > 0) atomicMax(rowmax + row, w[j]);
-    }
-}
-
 // Row maxima of ONE 16-row accumulator tile row of the 16x16 MFMA shapes for the bound-GEMM epilogues: v[r], r = 0..3, is this lane's
 // (column-masked, non-negative) maximum over the wave's column tiles for row i0 + 4 (lane >> 4) + r; the 16 lanes of a quad hold the
 // 16 columns.  Reduce-scatter over lane bits 3, 2 (4 -> 2 -> 1 values), butterfly over bits 1, 0: lane l then holds the finished

@@ -71,9 +71,6 @@ struct F8Args {
 __device__ __forceinline__ unsigned pack16(int a, int b) { return ((unsigned)a & 0xFFFFu) | ((unsigned)b << 16); }
 
 constexpr int F8_THREADS = 512;
-#ifndef OZ2_F8_SEGS
-#define OZ2_F8_SEGS 2  // LOAD / MFMA segment pairs per K-step: 2 (row halves, 16 MFMAs each) or 4 (row x column halves, 8 MFMAs each)
-#endif
 #ifndef OZ2_F8_PROBE_L2
 #define OZ2_F8_PROBE_L2 0
 #endif
@@ -322,6 +319,13 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
     // the whole persistent loop is instantiated twice (A-fetching waves 0-3, B-fetching waves 4-7) so that the fetch schedule is
     // branch-free inside the LOAD segments
     auto run = [&]<bool ISB>() {
+        // Measured on config 3 (18 GEMMs, interleaved builds, profiles/r02_f8_ab.txt): this kernel 54.9 ms, the round-1 32x32x64 kernel
+        // (four segments of 4 MFMAs) 55.5 ms, a four-segment (row x column halves) form of this one 55.8 ms.  The matrix pipes stay
+        // ~25 % idle for a reason the MFMA shape does not touch: the consumer waves issue the LDS-DMA themselves, and a
+        // global_load_lds costs 100-185 issue cycles inside a LOAD phase that also carries 16 ds_read_b128 (MI355X_MICROARCH.md,
+        // LDS-DMA piece), so a wave's LOAD phases outlast its partner's MFMA phases.  Dedicated producer waves (the INT8 layout)
+        // would need <= 168 registers: 128 accumulators + 32 operand registers + the two-chunk address set of 32-byte fragments
+        // does not fit (round 1: one accumulator tile spilled per K-step).
         // 2.5-stage ring of operand panels as in oz2_gemm_i8.hip: panel h = 2 g + isB in slot h % 5 of five 32 KiB panels.  The A
         // waves fetch A(g+2) during K-step g, four instructions in each of their two LOAD segments; the B waves fetch B(g+1), all eight
         // instructions in their first LOAD segment (B must land within the K-step).  Against the two-stage pipeline (32x32x64 kernel of
@@ -386,54 +390,6 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
                 sA = sA + 2 >= 5 ? sA - 3 : sA + 2;
                 F8_FETCH_ADVANCE();
                 F8_FETCH_BEGIN();
-#if OZ2_F8_SEGS == 4
-                // four segments (row half x column half) of 8 MFMAs; every fragment of the K-step stays resident (A 64 + B 32 registers),
-                // so the LDS reads are spread 12 / 8 / 4 / 0 over the LOAD segments and the DMA 2 per segment (A waves) / 4 + 4 (B waves)
-                v8i bf[4], af[8];
-#pragma unroll
-                for (int seg = 0; seg < 4; ++seg) {
-                    const int ah = seg >> 1, bh = seg & 1;
-                    if constexpr (ISB) {
-#pragma unroll
-                        for (int q8 = 0; q8 < 8; ++q8)
-                            if (q8 / 4 == seg) F8_DMA(fsrc, q8, fdst);
-                    } else {
-#pragma unroll
-                        for (int q8 = 0; q8 < 2; ++q8) F8_DMA(fsrc, seg * 2 + q8, fdst);
-                    }
-                    if (seg == 0) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) af[i] = frag(curA + i * 16 * BK);
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) bf[j] = frag(curB + j * 16 * BK);
-                    } else if (seg == 1) {
-#pragma unroll
-                        for (int j = 2; j < 4; ++j) bf[j] = frag(curB + j * 16 * BK);
-#pragma unroll
-                        for (int i = 4; i < 6; ++i) af[i] = frag(curA + i * 16 * BK);
-                    } else if (seg == 2) {
-#pragma unroll
-                        for (int i = 6; i < 8; ++i) af[i] = frag(curA + i * 16 * BK);
-                    }
-                    if (seg == 3 && !ISB) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[ah * 4 + i][bh * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[ah * 4 + i], bf[bh * 2 + j],
-                                                                                                           acc[ah * 4 + i][bh * 2 + j], 0, 0, 0, UNIT, 0, UNIT);
-                    __builtin_amdgcn_s_setprio(0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (seg == 3 && ISB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#else
                 v8i bf[4];
 #pragma unroll
                 for (int ah = 0; ah < 2; ++ah) {  // LOAD segment ah of this K-step
@@ -471,7 +427,6 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                 }
-#endif
             }
             const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n);
             const int i0 = tmap.tm * BM + wm * 128, j0 = tmap.tn * BN + wn * 64;
