@@ -230,20 +230,28 @@ def main():
         L = g.Layout()
         g.check(lib.gemmul8_get_layout(g.D, g.INT8, n, n, n, N, work.data_ptr(), None, None, 0, 0, C.byref(L)))
 
+        phase_events = []
+
         def step(record):
             st = stream.cuda_stream
-            g.check(lib.gemmul8_scale(st, g.D, g.INT8, 0, 0, n, n, n, A.data_ptr(), n, B.data_ptr(), n, N, int(args.fast), 0, N,
-                                      C.byref(L), 0, 0))
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
+            if not args.fast:
+                g.check(lib.gemmul8_scale_bounds(st, g.D, g.INT8, 0, 0, n, n, n, A.data_ptr(), n, B.data_ptr(), n, N, 0, n, C.byref(L), 0, 0))
             if record:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
+                ev[0].record(stream)
+            g.check(lib.gemmul8_scale_finish(st, g.D, g.INT8, 0, 0, n, n, n, A.data_ptr(), n, B.data_ptr(), n, N, int(args.fast), 0, N,
+                                             C.byref(L), 0, 0))
+            if record:
+                ev[1].record(stream)
             g.check(lib.gemmul8_lowprec_gemm(st, g.D, g.INT8, n, n, n, N, 0, N, C.byref(L)))
             if record:
-                e1.record(stream)
-                gemm_events.append((e0, e1))
+                ev[2].record(stream)
+                gemm_events.append((ev[1], ev[2]))
             g.check(lib.gemmul8_crt(st, g.D, g.INT8, N, n, n, L.C_mid, L.mp, L.sizeC, L.sftA, L.sftB, one.ctypes.data,
                                     zero.ctypes.data, Cmat.data_ptr(), n))
+            if record:
+                ev[3].record(stream)
+                phase_events.append(ev)
         parallelism = "single-gpu"
     else:
         from gemmul8_amd import dist as gd
@@ -307,14 +315,16 @@ def main():
             roof = {"bound": "mfma", "kernel": "oz2::gemm_i8_kernel<EPI_MOD> (batched over moduli)", "achieved": ach, "peak": peak,
                     "unit": "TOP/s", "frac": ach / peak, "traffic": None, "launch_ms": gemm_ms, "ops_per_launch": ops,
                     "algorithmic_bytes_per_launch": planes_here * 3.0 * n * n if not multi else None,
-                    # measured with tools/ubench/mfma_peak.hip (profiles/r01_mfma_power_ceiling.txt): a register-only MFMA loop
-                    # reaches the nominal peak on all-zero operands but is power-limited to this on random INT8 data
-                    "sustained_mfma_on_random_data_TOPs": 3426.0}
+                    # measured with tools/ubench/mfma_shapes.hip (profiles/r02_mfma_shapes.txt): a register-only loop of the kernel's
+                    # instruction (v_mfma_i32_16x16x64_i8) reaches the nominal peak on all-zero operands but is limited by the 1400 W
+                    # socket cap to this on uniformly distributed residues (v_mfma_i32_32x32x32_i8: 3448)
+                    "sustained_mfma_on_residue_data_TOPs": 3969.0}
             # HBM-side bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
             # WRITE_SIZE, tools/pmc_traffic.py); only valid for the configuration that was profiled
             tf = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
             if tf and not multi and n == 8192 and N == 14:
-                rec = json.load(open(tf[-1])).get("oz2::gemm_i8_kernel<0>")
+                recs = json.load(open(tf[-1]))
+                rec = recs.get("oz2::gemm_i8_kernel<0, false>") or recs.get("oz2::gemm_i8_kernel<0>")
                 if rec:
                     roof["traffic"] = rec["hbm_side_bytes_per_launch"]
                     roof["traffic_source"] = "profiles/" + os.path.basename(tf[-1])
@@ -327,6 +337,19 @@ def main():
                        "parallelism": parallelism},
             "roofline": roof,
         }
+        if not multi and phase_events:
+            # the HBM-bound kernels beside the GEMM (events on the launch stream inside the timed region): algorithmic bytes / time
+            # against the 8 TB/s HBM3E peak (a plain device copy reaches 4.96 TB/s on this part, tools/hbm_probe.py)
+            q_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in phase_events]))
+            c_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in phase_events]))
+            q_bytes = 2.0 * (8.0 * n * n + N * n * n)   # quantise A and B: read the FP64 operand, write N int8 planes
+            c_bytes = N * n * n + 8.0 * n * n             # CRT: read N int8 planes, write the FP64 result
+            out["secondary_kernels"] = [
+                {"kernel": "oz2::stage_strided_kernel<double,MOD> + stage_kmajor_kernel<double,MOD> (+ shift_finalize; fast mode: + the norm kernels)",
+                 "bound": "hbm", "ms": q_ms, "algorithmic_bytes": q_bytes, "achieved": q_bytes / q_ms * 1e-6, "peak": 8000.0, "unit": "GB/s",
+                 "frac": q_bytes / q_ms * 1e-6 / 8000.0},
+                {"kernel": "oz2::crt_kernel<double>", "bound": "hbm", "ms": c_ms, "algorithmic_bytes": c_bytes, "achieved": c_bytes / c_ms * 1e-6,
+                 "peak": 8000.0, "unit": "GB/s", "frac": c_bytes / c_ms * 1e-6 / 8000.0}]
         out["max_rel_err"] = sampled_error(A, B, Cfull, n)
         if not multi:
             nat, Cn = native_fp64(A, B)
