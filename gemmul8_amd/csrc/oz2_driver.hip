@@ -65,7 +65,7 @@ static bool scalars_on_device(const void* alpha);
 
 extern "C" {
 
-const char* gemmul8_version(void) { return "gemmul8-mi355x 0.2 (gfx950; INT8 MFMA_I32_32x32x32_I8, fused epilogues)"; }
+const char* gemmul8_version(void) { return "gemmul8-mi355x 0.2 (gfx950; v_mfma_i32_16x16x64_i8 / v_mfma_scale_f32_16x16x128_f8f6f4, fused epilogues)"; }
 
 size_t gemmul8_work_size(int is_complex, int backend, size_t m, size_t n, size_t k, unsigned N, int enA, int enB, size_t* wA,
                          size_t* wB) {

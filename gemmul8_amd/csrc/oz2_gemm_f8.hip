@@ -71,6 +71,9 @@ struct F8Args {
 __device__ __forceinline__ unsigned pack16(int a, int b) { return ((unsigned)a & 0xFFFFu) | ((unsigned)b << 16); }
 
 constexpr int F8_THREADS = 512;
+#ifndef OZ2_F8_PROBE_NODMA
+#define OZ2_F8_PROBE_NODMA 0  // timing probe on real data (wrong results): the LDS-DMA is issued during a workgroup's first tile only
+#endif
 #ifndef OZ2_F8_PROBE_L2
 #define OZ2_F8_PROBE_L2 0
 #endif
@@ -321,11 +324,12 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
     auto run = [&]<bool ISB>() {
         // Measured on config 3 (18 GEMMs, interleaved builds, profiles/r02_f8_ab.txt): this kernel 54.9 ms, the round-1 32x32x64 kernel
         // (four segments of 4 MFMAs) 55.5 ms, a four-segment (row x column halves) form of this one 55.8 ms.  The matrix pipes stay
-        // ~25 % idle for a reason the MFMA shape does not touch: the consumer waves issue the LDS-DMA themselves, and a
-        // global_load_lds costs 100-185 issue cycles inside a LOAD phase that also carries 16 ds_read_b128 (MI355X_MICROARCH.md,
-        // LDS-DMA piece), so a wave's LOAD phases outlast its partner's MFMA phases.  Dedicated producer waves (the INT8 layout)
-        // would need <= 168 registers: 128 accumulators + 32 operand registers + the two-chunk address set of 32-byte fragments
-        // does not fit (round 1: one accumulator tile spilled per K-step).
+        // ~25 % idle, and the cost sits in the L2 -> LDS operand path itself: with the DMA issued in the first tile only (real data
+        // in LDS, -DOZ2_F8_PROBE_NODMA=1) the 18 GEMMs take 44.2 instead of 54.2 ms (-18.5 %; the INT8 kernel: -13 %), of which
+        // L2-miss latency explains 6 % (round 1, L2-resident operands).  WHERE the DMA is issued from does not matter: a 12-wave
+        // variant with dedicated producer waves (the INT8 layout; 32x32x64 so that 128 accumulators + 32 operand registers fit 168
+        // VGPRs, address set folded into one register by XOR variants) was built, is bit-exact and runs 58.9 ms, 46.5 without
+        // DMA -- tools/experiments/gemm_f8_ws_experiment.inc.
         // 2.5-stage ring of operand panels as in oz2_gemm_i8.hip: panel h = 2 g + isB in slot h % 5 of five 32 KiB panels.  The A
         // waves fetch A(g+2) during K-step g, four instructions in each of their two LOAD segments; the B waves fetch B(g+1), all eight
         // instructions in their first LOAD segment (B must land within the K-step).  Against the two-stage pipeline (32x32x64 kernel of
@@ -394,14 +398,16 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
 #pragma unroll
                 for (int ah = 0; ah < 2; ++ah) {  // LOAD segment ah of this K-step
                     v8i af[4];
-                    if constexpr (ISB) {
-                        if (ah == 0) {
+                    if (!(OZ2_F8_PROBE_NODMA) || vb == (int)blockIdx.x) {  // timing probe (wrong results): LDS-DMA in the first tile only
+                        if constexpr (ISB) {
+                            if (ah == 0) {
 #pragma unroll
-                            for (int q8 = 0; q8 < 8; ++q8) F8_DMA(fsrc, q8, fdst);
+                                for (int q8 = 0; q8 < 8; ++q8) F8_DMA(fsrc, q8, fdst);
+                            }
+                        } else {
+#pragma unroll
+                            for (int q8 = 0; q8 < 4; ++q8) F8_DMA(fsrc, ah * 4 + q8, fdst);
                         }
-                    } else {
-#pragma unroll
-                        for (int q8 = 0; q8 < 4; ++q8) F8_DMA(fsrc, ah * 4 + q8, fdst);
                     }
                     if (ah == 0) {
 #pragma unroll
