@@ -315,8 +315,8 @@ int gemmul8_comm_rccl_create(const void* id128, int rank, int world, gemmul8_com
     return GEMMUL8_OK;
 }
 
-int gemmul8_comm_rccl_from_env(gemmul8_comm** out) {
-    if (!out) return GEMMUL8_E_ARG;
+int gemmul8_comm_rccl_id_from_env(void* id128, int* rank_out, int* world_out) {
+    if (!id128) return GEMMUL8_E_ARG;
     const char* srank = std::getenv("RANK");
     const char* sworld = std::getenv("WORLD_SIZE");
     if (!srank || !sworld) return GEMMUL8_E_ARG;
@@ -336,6 +336,17 @@ int gemmul8_comm_rccl_from_env(gemmul8_comm** out) {
         }
         OZ2_RC(exchange_id_tcp(addr ? addr : "127.0.0.1", port, rank, world, &id));
     }
+    std::memcpy(id128, &id, sizeof id);
+    if (rank_out) *rank_out = rank;
+    if (world_out) *world_out = world;
+    return GEMMUL8_OK;
+}
+
+int gemmul8_comm_rccl_from_env(gemmul8_comm** out) {
+    if (!out) return GEMMUL8_E_ARG;
+    ncclUniqueId id;
+    int rank = 0, world = 1;
+    OZ2_RC(gemmul8_comm_rccl_id_from_env(&id, &rank, &world));
     return gemmul8_comm_rccl_create(&id, rank, world, out);
 }
 

@@ -76,6 +76,8 @@ def _lib():
         L.gemmul8_comm_rccl_unique_id.argtypes = [C.c_void_p]
         L.gemmul8_comm_rccl_create.restype = C.c_int
         L.gemmul8_comm_rccl_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.POINTER(Comm))]
+        L.gemmul8_comm_rccl_id_from_env.restype = C.c_int
+        L.gemmul8_comm_rccl_id_from_env.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.gemmul8_comm_rccl_from_env.restype = C.c_int
         L.gemmul8_comm_rccl_from_env.argtypes = [C.POINTER(C.POINTER(Comm))]
         L.gemmul8_comm_destroy.restype = None
@@ -113,12 +115,18 @@ class RcclComm:
         ident = C.create_string_buffer(128)
         if rank == 0:
             g.check(L.gemmul8_comm_rccl_unique_id(ident), "gemmul8_comm_rccl_unique_id")
-        box = [ident.raw]
+        raw = ident.raw
         if world > 1:
+            # plain tensor broadcast on the group's own device type (the most exercised torch.distributed path: no pickling, no
+            # object collectives); nccl groups need a device tensor on the current device, gloo groups a host tensor
+            import torch
+            on_dev = dist.get_backend(group) == "nccl"
+            t = torch.tensor(list(raw), dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()) if on_dev else "cpu")
             src = 0 if group is None else dist.get_global_rank(group, 0)
-            dist.broadcast_object_list(box, src=src, group=group)
+            dist.broadcast(t, src=src, group=group)
+            raw = bytes(t.cpu().tolist())
         self.ptr = C.POINTER(Comm)()
-        g.check(L.gemmul8_comm_rccl_create(C.create_string_buffer(box[0], 128), rank, world, C.byref(self.ptr)), "gemmul8_comm_rccl_create")
+        g.check(L.gemmul8_comm_rccl_create(C.create_string_buffer(raw, 128), rank, world, C.byref(self.ptr)), "gemmul8_comm_rccl_create")
         self.rank, self.world = rank, world
 
     def close(self):

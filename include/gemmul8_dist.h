@@ -61,6 +61,7 @@ typedef struct gemmul8_comm {
  *                the id travels over a TCP connection to MASTER_ADDR:GEMMUL8_DIST_PORT (default MASTER_PORT + 17). */
 GEMMUL8_API int gemmul8_comm_rccl_unique_id(void *id128);
 GEMMUL8_API int gemmul8_comm_rccl_create(const void *id128, int rank, int world, gemmul8_comm **out);
+GEMMUL8_API int gemmul8_comm_rccl_id_from_env(void *id128, int *rank, int *world); /* the rendezvous alone: same 128 bytes on every rank */
 GEMMUL8_API int gemmul8_comm_rccl_from_env(gemmul8_comm **out);
 GEMMUL8_API void gemmul8_comm_destroy(gemmul8_comm *comm);
 

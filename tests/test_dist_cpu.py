@@ -159,3 +159,33 @@ def test_rccl_symbols_are_optional_at_load_time():
     import gemmul8_amd as g
     out = subprocess.run(["readelf", "-d", g.LIB_PATH], capture_output=True, text=True).stdout
     assert "rccl" not in out and "amdhip64" not in out and "hipblas" not in out, out
+
+
+def _id_worker(rank, world, port, q):
+    import ctypes as C
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", GEMMUL8_DIST_PORT=str(port))
+    from gemmul8_amd import dist as gd
+    buf = C.create_string_buffer(128)
+    r, w = C.c_int(-1), C.c_int(-1)
+    rc = gd._lib().gemmul8_comm_rccl_id_from_env(buf, C.byref(r), C.byref(w))
+    q.put((rank, rc, r.value, w.value, buf.raw))
+
+
+def test_unique_id_rendezvous_over_tcp():
+    """gemmul8_comm_rccl_id_from_env: rank 0 creates the ncclUniqueId and hands it to the other ranks over TCP (the bootstrap a C++ host
+    or the hook's GEMMUL8_DIST uses when there is no torch.distributed): every rank ends up with the same 128 bytes.  (Creating the
+    communicator itself needs GPUs: tests/test_gpu_dist.py.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 4
+    procs = [ctx.Process(target=_id_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in reversed(procs):   # rank 0 last: the others must retry until it listens
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=10) for _ in range(world))
+    assert [g_[0] for g_ in got] == list(range(world))
+    assert all(g_[1] == 0 and g_[2] == g_[0] and g_[3] == world for g_ in got), [(g_[0], g_[1]) for g_ in got]
+    assert len({g_[4] for g_ in got}) == 1 and any(got[0][4]), "ranks disagree on the unique id"

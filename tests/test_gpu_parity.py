@@ -449,3 +449,35 @@ def test_kat_result_bit_patterns(backend, N, fast):
     assert [float(x).hex() for x in Cd.flatten(order="F")] == gold["C"]
     assert it["sftA"].tolist() == gold["sftA"] and it["sftB"].tolist() == gold["sftB"]
     assert it["C_mid"].flatten().tolist() == gold["C_mid"]
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_tall_skinny_accurate_mode(n):
+    """m = 2.7 M rows, n <= 3: the accurate-mode scratch (row maxima, column maxima, per-row amax bits = 16 m + ... bytes)
+    no longer fits the C_hi region alone (4 * mp * n bytes) nor the 32 MiB tail alone -- it spans both, which are adjacent -- and the
+    row-strided extract / quantise launches need more than 65535 row tiles (1-D grid).  Sampled rows bit-exact against the oracle fed
+    with the device's shifts; every shift within the usual +-1 of the oracle's."""
+    import ctypes as C
+    import gemmul8_amd as g
+    import gpu_util as gu
+    import oracle_lib as ol
+    m, k, N = 2_700_000, 8, 6
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    A = (torch.rand((k, m), generator=gen, dtype=torch.float64, device="cuda") - 0.5).contiguous()   # column-major m x k
+    B = (torch.rand((n, k), generator=gen, dtype=torch.float64, device="cuda") - 0.5).contiguous()   # column-major k x n
+    Cd, _, work = g.gemm(A, B, N, fastmode=False)
+    torch.cuda.synchronize()
+    L = g.Layout()
+    g.check(g.lib().gemmul8_get_layout(g.D, g.INT8, m, n, k, N, work.data_ptr(), None, None, 0, 0, C.byref(L)))
+    base = work.data_ptr()
+    sftA = work[L.sftA - base:L.sftA - base + 2 * m].cpu().numpy().view(np.int16)
+    sftB = work[L.sftB - base:L.sftB - base + 2 * n].cpu().numpy().view(np.int16)
+    An = np.asfortranarray(A.cpu().numpy().T)
+    Bn = np.asfortranarray(B.cpu().numpy().T)
+    oA, oB = ol.accurate_shifts(An, Bn, N)
+    gu.shifts_close(sftA, oA, "sftA")
+    gu.shifts_close(sftB, oB, "sftB")
+    rows = np.array([0, 1, 255, 256, 65535 * 16, 65535 * 16 + 17, 1_048_576, m - 257, m - 1] + np.random.default_rng(1).integers(0, m, 40).tolist())
+    Co = ol.gemm(An[rows], Bn, N, sftA_in=sftA[rows], sftB_in=sftB)
+    got = Cd[:, torch.as_tensor(rows, device="cuda")].cpu().numpy().T
+    assert gu.bits_equal(np.ascontiguousarray(got), np.ascontiguousarray(Co))
