@@ -57,7 +57,13 @@ std::vector<double> run(hipStream_t stream, int backend, hipblasOperation_t op_A
     std::vector<double> timer(4, 0.0);
     const int rc = gemmul8_gemm(stream, TypeCode<T>::v, backend, (int)op_A, (int)op_B, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc,
                                 num_moduli, fastmode ? 1 : 0, work, workA, workB, enA, enB, skA, skB, async_mode() ? nullptr : timer.data());
-    if (rc != 0) std::fprintf(stderr, "[GEMMUL8] gemm failed with status %d (m=%zu n=%zu k=%zu num_moduli=%u)\n", rc, m, n, k, num_moduli);
+    if (rc != 0) {
+        // The reference's API has no error channel (its gemm validates nothing, include/gemmul8.hpp:98-151).  Here a failed call
+        // leaves C untouched and says so; GEMMUL8_ABORT_ON_ERROR=1 turns it into an abort for callers that cannot check stderr.
+        std::fprintf(stderr, "[GEMMUL8] gemm failed with status %d (m=%zu n=%zu k=%zu num_moduli=%u): C was not computed\n", rc, m, n, k, num_moduli);
+        const char* s = std::getenv("GEMMUL8_ABORT_ON_ERROR");
+        if (s && std::strcmp(s, "1") == 0) std::abort();
+    }
     return timer;
 }
 

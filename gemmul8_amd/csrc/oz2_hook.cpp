@@ -124,6 +124,14 @@ struct Buffer {
     size_t size = 0;
 };
 
+// side lane of a batched call: its own stream, join event and single work buffer (see emulate_batch)
+struct BatchLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    Buffer w;
+};
+constexpr int kMaxBatchLanes = 8;
+
 struct HandleState {
     std::mutex mtx;
     Buffer wA, wB, wC;
@@ -131,6 +139,8 @@ struct HandleState {
     hipStream_t last_stream = nullptr;
     hipEvent_t last_event = nullptr;
     bool have_stream = false;
+    BatchLane lanes[kMaxBatchLanes];  // lane 0 unused (= the handle's stream and buffers)
+    hipEvent_t fork = nullptr;
 };
 
 std::mutex g_map_mtx;
@@ -451,6 +461,17 @@ void release_state(hipblasHandle_t handle) {
         b->size = 0;
     }
     if (sp->last_event) (void)hipEventDestroy(sp->last_event), sp->last_event = nullptr;
+    for (BatchLane& ln : sp->lanes) {
+        if (ln.w.ptr) {
+            hipError_t e = ln.stream ? hipFreeAsync(ln.w.ptr, ln.stream) : hipFree(ln.w.ptr);
+            if (e == hipSuccess && ln.stream) e = hipStreamSynchronize(ln.stream);
+            if (e != hipSuccess) std::fprintf(stderr, "[GEMMUL8 HOOK] hipblasDestroy: freeing a batch workspace failed (%s)\n", hipGetErrorString(e));
+            ln.w = Buffer{};
+        }
+        if (ln.done) (void)hipEventDestroy(ln.done), ln.done = nullptr;
+        if (ln.stream) (void)hipStreamDestroy(ln.stream), ln.stream = nullptr;
+    }
+    if (sp->fork) (void)hipEventDestroy(sp->fork), sp->fork = nullptr;
 }
 
 #define OZ2_EARLY_OUT()                                           \
@@ -593,18 +614,72 @@ hipblasStatus_t hipblasGemmExWithFlags_64(hipblasHandle_t handle, hipblasOperati
                 : HIPBLAS_STATUS_NOT_INITIALIZED;
 }
 
-// Strided-batched entry points (not hooked by the reference; PyTorch's bmm uses them): the batch is a loop of emulated
-// GEMMs on the handle's stream.  alpha/beta are shared by the batch; element strides are in units of the matrix type.
+// Strided-batched entry points (not hooked by the reference; PyTorch's bmm uses them).  alpha/beta are shared by the batch; element
+// strides are in units of the matrix type.  The items of a batch are independent, and below ~2048^3 one emulated GEMM is ten
+// latency-bound launches that leave most of the chip idle, so the batch is spread over GEMMUL8_BATCH_STREAMS lanes (default 4, 1 =
+// serial loop on the handle's stream): lane 0 is the handle's stream with the handle's buffers, every other lane has its own
+// non-blocking stream and workspace; the lanes fork from the handle's stream with an event and join it again before the call
+// returns, so the call stays stream-ordered for the application (and capturable in a HIP graph after one warm-up call).
 static bool emulate_batch(int dtype, size_t elem, hipblasHandle_t handle, hipblasOperation_t ta, hipblasOperation_t tb, int m, int n, int k,
                           const void* alpha, const void* A, int lda, long long sa, const void* B, int ldb, long long sb, const void* beta,
                           void* C, int ldc, long long sc, int batch, hipblasStatus_t* status) {
     *status = HIPBLAS_STATUS_SUCCESS;
-    for (int b = 0; b < batch; ++b) {
-        hipblasStatus_t st;
-        const bool done = try_emulate(dtype, handle, ta, tb, m, n, k, alpha, (const char*)A + (size_t)b * sa * elem, lda,
-                                      (const char*)B + (size_t)b * sb * elem, ldb, beta, (char*)C + (size_t)b * sc * elem, ldc, &st);
-        if (!done) return b == 0 ? false : (*status = HIPBLAS_STATUS_INTERNAL_ERROR, true);  // not selected by the environment: pass through
-        if (st != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
+    auto item = [&](int b, const void** a, const void** bb, void** c) {
+        *a = (const char*)A + (size_t)b * sa * elem, *bb = (const char*)B + (size_t)b * sb * elem, *c = (char*)C + (size_t)b * sc * elem;
+    };
+    const void *Ai, *Bi;
+    void* Ci;
+    hipblasStatus_t st;
+    // item 0 on the handle's stream decides whether the environment selects emulation for this call at all
+    item(0, &Ai, &Bi, &Ci);
+    if (!try_emulate(dtype, handle, ta, tb, m, n, k, alpha, Ai, lda, Bi, ldb, beta, Ci, ldc, &st)) return false;
+    if (st != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
+    int lanes = (int)env_u64("GEMMUL8_BATCH_STREAMS", 4);
+    lanes = std::max(1, std::min({lanes, kMaxBatchLanes, batch}));
+    const TypeInfo& ti = kTypes[dtype];
+    const unsigned N = (unsigned)env_u64(ti.nmod, 0);
+    const bool fastmode = env_one(ti.fast);
+    const int backend = env_backend("GEMMUL8_BACKEND", 0, false);
+    if (lanes > 1 && dist_kind_from_env() >= 0) lanes = 1;  // the sharded path keeps its collectives on one stream
+    auto sp = state_of(handle);
+    hipStream_t main_stream = nullptr;
+    if (lanes > 1) {
+        std::lock_guard<std::mutex> lk(sp->mtx);
+        main_stream = sp->last_stream;  // set by item 0
+        bool ok = sp->fork || hipEventCreateWithFlags(&sp->fork, hipEventDisableTiming) == hipSuccess;
+        const size_t need = gemmul8_work_size(ti.cplx, backend, (size_t)m, (size_t)n, (size_t)k, N, 0, 0, nullptr, nullptr);
+        ok = ok && hipEventRecord(sp->fork, main_stream) == hipSuccess;
+        for (int l = 1; l < lanes && ok; ++l) {
+            BatchLane& ln = sp->lanes[l];
+            if (!ln.stream) ok = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking) == hipSuccess;
+            if (ok && !ln.done) ok = hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipStreamWaitEvent(ln.stream, sp->fork, 0) == hipSuccess;
+            ok = ok && grow(ln.w, need, ln.stream, "batch lane") == HIPBLAS_STATUS_SUCCESS;
+        }
+        if (!ok) lanes = 1;  // fall back to the serial loop
+    }
+    for (int b = 1; b < batch; ++b) {
+        item(b, &Ai, &Bi, &Ci);
+        const int l = b % lanes;
+        if (l == 0) {
+            const bool done = try_emulate(dtype, handle, ta, tb, m, n, k, alpha, Ai, lda, Bi, ldb, beta, Ci, ldc, &st);
+            if (!done) return *status = HIPBLAS_STATUS_INTERNAL_ERROR, true;
+            if (st != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
+        } else {
+            std::lock_guard<std::mutex> lk(sp->mtx);
+            BatchLane& ln = sp->lanes[l];
+            const int rc = gemmul8_gemm(ln.stream, dtype, backend, (int)ta, (int)tb, (size_t)m, (size_t)n, (size_t)k, alpha, Ai, (size_t)lda, Bi,
+                                        (size_t)ldb, beta, Ci, (size_t)ldc, N, fastmode, ln.w.ptr, nullptr, nullptr, 0, 0, 0, 0, nullptr);
+            if (rc != 0) *status = HIPBLAS_STATUS_INTERNAL_ERROR;  // item 0 ran with the same shape and switches: should not happen
+        }
+    }
+    if (lanes > 1) {  // join: the handle's stream waits for every lane
+        std::lock_guard<std::mutex> lk(sp->mtx);
+        for (int l = 1; l < lanes; ++l) {
+            BatchLane& ln = sp->lanes[l];
+            if (hipEventRecord(ln.done, ln.stream) != hipSuccess || hipStreamWaitEvent(main_stream, ln.done, 0) != hipSuccess)
+                *status = HIPBLAS_STATUS_INTERNAL_ERROR;
+        }
     }
     return true;
 }

@@ -98,6 +98,39 @@ int main() {
     }
     std::printf("hooked hipblasDgemm/GemmEx (+ _64, WithFlags) == direct gemmul8_gemm (bitwise), incl. skip-scaling and stream switch\n");
 
+    // strided batched (torch.bmm's entry point; the reference has none): 7 items spread over the hook's stream lanes
+    // (GEMMUL8_BATCH_STREAMS, default 4), then the serial loop -- every item bitwise equal to the direct call on that item
+    {
+        const int nb = 7;
+        std::vector<double> bA((size_t)nb * m * k), bB((size_t)nb * k * n), bC((size_t)nb * m * n, 0.0), bgot(bC.size());
+        for (auto& x : bA) x = U(gen) - 0.5;
+        for (auto& x : bB) x = U(gen) - 0.5;
+        double *dA = dev(bA), *dB = dev(bB), *dC = dev(bC);
+        std::vector<double> bref(bC.size());
+        for (int b = 0; b < nb; ++b) {
+            CHECK(direct(nullptr, 1, 0, 0, 0, m, n, k, &one, dA + (size_t)b * m * k, m, dB + (size_t)b * k * n, k, &zero, C2, m, 15, 0, work, nullptr,
+                         nullptr, 0, 0, 0, 0, nullptr) == 0);
+            hipMemcpy(bref.data() + (size_t)b * m * n, C2, (size_t)m * n * 8, hipMemcpyDeviceToHost);
+        }
+        for (int pass = 0; pass < 3; ++pass) {
+            if (pass == 2) setenv("GEMMUL8_BATCH_STREAMS", "1", 1);
+            hipMemset(dC, 0, bC.size() * 8);
+            hipDeviceSynchronize();
+            CHECK(hipblasDgemmStridedBatched(handle, HIPBLAS_OP_N, HIPBLAS_OP_N, m, n, k, &one, dA, m, (long long)m * k, dB, k, (long long)k * n, &zero,
+                                             dC, m, (long long)m * n, nb) == HIPBLAS_STATUS_SUCCESS);
+            hipStreamSynchronize(s1);  // the handle's stream: the side lanes must have been joined into it
+            hipMemcpy(bgot.data(), dC, bgot.size() * 8, hipMemcpyDeviceToHost);
+            for (size_t i = 0; i < bgot.size(); ++i)
+                if (bgot[i] != bref[i]) {
+                    std::printf("FAILED batched pass %d: item %zu differs from the direct call: %a vs %a\n", pass, i / ((size_t)m * n), bgot[i], bref[i]);
+                    return 1;
+                }
+        }
+        unsetenv("GEMMUL8_BATCH_STREAMS");
+        std::printf("hooked hipblasDgemmStridedBatched (7 items, stream lanes and serial) == direct gemmul8_gemm per item (bitwise)\n");
+        hipFree(dA), hipFree(dB), hipFree(dC);
+    }
+
     // float result sanity (S path emulated with GEMMUL8_NUM_MOD_S from the environment)
     std::vector<float> gs(fC.size());
     hipMemcpy(gs.data(), sC, gs.size() * 4, hipMemcpyDeviceToHost);

@@ -31,6 +31,8 @@ EXPORT hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEv
 EXPORT hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { std::memset((void*)e, 1, 8); return hipSuccess; }
 EXPORT hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t e, unsigned) { return *(volatile char*)e == 1 ? hipSuccess : hipErrorInvalidValue; }
 EXPORT hipError_t hipEventDestroy(hipEvent_t e) { std::free((void*)e); return hipSuccess; }
+EXPORT hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)std::malloc(8); return hipSuccess; }
+EXPORT hipError_t hipStreamDestroy(hipStream_t s) { std::free((void*)s); return hipSuccess; }
 EXPORT hipError_t hipDeviceSynchronize() { return hipSuccess; }
 EXPORT hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 EXPORT hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t) {

@@ -30,9 +30,22 @@ X = torch.rand((b, nb, nb), dtype=torch.float64, device="cuda") - 0.5
 Y = torch.rand((b, nb, nb), dtype=torch.float64, device="cuda") - 0.5
 Z = torch.bmm(X, Y)
 torch.cuda.synchronize()
-refb = X[b - 1].cpu().numpy().astype("longdouble") @ Y[b - 1].cpu().numpy().astype("longdouble")
-errb = float(abs(Z[b - 1].cpu().numpy() - refb).max() / abs(refb).max())
+errb = 0.0
+for i in range(b):   # every item: the hook spreads them over GEMMUL8_BATCH_STREAMS stream lanes
+    refb = X[i, :64].cpu().numpy().astype("longdouble") @ Y[i].cpu().numpy().astype("longdouble")
+    errb = max(errb, float(abs(Z[i, :64].cpu().numpy() - refb).max() / abs(refb).max()))
 print(f"torch.bmm {b} x {nb}^3: bmm normwise err {errb:.2e}")
+for nbb, bb in ((512, 32), (1024, 16), (2048, 8)):
+    X2 = torch.rand((bb, nbb, nbb), dtype=torch.float64, device="cuda") - 0.5
+    for _ in range(2):
+        Z2 = torch.bmm(X2, X2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        Z2 = torch.bmm(X2, X2)
+    torch.cuda.synchronize()
+    dtb = (time.perf_counter() - t0) / 5
+    print(f"torch.bmm {bb} x {nbb}^3 (lanes={os.environ.get('GEMMUL8_BATCH_STREAMS', 'default')}): {2 * bb * nbb**3 / dtb * 1e-12:.1f} TFLOPS")
 
 # HIP-graph capture of a hooked matmul (torch.cuda.graph warms nothing up by itself: run once on a side stream first)
 s = torch.cuda.Stream()
