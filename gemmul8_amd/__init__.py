@@ -95,6 +95,11 @@ def lib():
     L.gemmul8_crt.restype = C.c_int
     L.gemmul8_crt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                               C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.gemmul8_lowprec_gemm_crt.restype = C.c_int
+    L.gemmul8_lowprec_gemm_crt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.POINTER(Layout),
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.gemmul8_fused_crt_selected.restype = C.c_int
+    L.gemmul8_fused_crt_selected.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_uint]
     _lib = L
     return L
 

@@ -14,41 +14,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "oz2_crt_common.hpp"
 #include "oz2_kernels.h"
 
 namespace oz2 {
-
-struct CrtArgs {
-    const void* Cmid;
-    size_t ld_mid;        // elements (int8 or char2 or int16...) between columns
-    size_t plane_stride;  // elements between residue planes
-    size_t m, n;
-    const int16_t* sftA;
-    const int16_t* sftB;
-    void* C;
-    size_t ldc;
-    unsigned N;
-    int use_dd;
-    int mode;  // 0 general(host scalars) 1: C=AB 2: C+=AB 3: C=-AB 4: C-=AB 5: general(device scalars)
-    double alpha[2], beta[2];
-    const void* alpha_dev;
-    const void* beta_dev;
-    double Phi, Plo, invP;
-    double q1[20], qh[20], ql[20];
-};
-
-template <typename U> __device__ __forceinline__ U scalb(U x, int s);
-template <> __device__ __forceinline__ float scalb<float>(float x, int s) { return scalbnf(x, s); }
-template <> __device__ __forceinline__ double scalb<double>(double x, int s) { return scalbn(x, s); }
-template <typename U> __device__ __forceinline__ U fmaU(U a, U b, U c);
-template <> __device__ __forceinline__ float fmaU<float>(float a, float b, float c) { return fmaf(a, b, c); }
-template <> __device__ __forceinline__ double fmaU<double>(double a, double b, double c) { return fma(a, b, c); }
-
-__device__ __forceinline__ double crt_reduce(const CrtArgs& a, double Sh, double Sl) {
-    const double q = rint(a.invP * Sh);
-    if (!a.use_dd) return fma(a.Phi, q, Sh);
-    return fma(a.Plo, q, fma(a.Phi, q, Sh) + Sl);
-}
 
 // U = float|double ; CPLX ; MID = int8_t|int16_t
 template <typename U, bool CPLX, typename MID>
@@ -274,7 +243,7 @@ __global__ void __launch_bounds__(256) crt_finish_kernel(const CrtArgs a, const 
     }
 }
 
-static void fill_crt_tables(CrtArgs& a, int dtype, int backend, unsigned N) {
+void fill_crt_tables(CrtArgs& a, int dtype, int backend, unsigned N) {
     const bool f32 = is_f32(dtype);
     const int pdbl = backend == kINT8 ? 6 : 5;
     a.N = N;
@@ -289,7 +258,7 @@ static void fill_crt_tables(CrtArgs& a, int dtype, int backend, unsigned N) {
         a.ql[t] = (i8 ? GEMMUL8_QPI2_LO_INT8 : GEMMUL8_QPI2_LO_FP8)[N - 2][t];
     }
 }
-static void fill_crt_scalars(CrtArgs& a, int dtype, const void* alpha, const void* beta, bool scalars_on_device) {
+void fill_crt_scalars(CrtArgs& a, int dtype, const void* alpha, const void* beta, bool scalars_on_device) {
     const bool f32 = is_f32(dtype), cplx = is_complex(dtype);
     if (scalars_on_device) {
         a.mode = 5;

@@ -41,7 +41,9 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <type_traits>
 
+#include "oz2_crt_common.hpp"
 #include "oz2_gemm_common.hpp"
 #include "oz2_kernels.h"
 
@@ -67,7 +69,8 @@ struct GemmArgs {
     size_t strideR;
     int* rowmax;           // EPI_MAX
     int* colmax;
-    int total_tiles;       // planes * tiles_m * tiles_n
+    int total_tiles;       // planes * tiles_m * tiles_n (tile-stationary order, FUSE != 0: tiles_m * tiles_n)
+    int planes;            // FUSE != 0: residue planes every workgroup runs through per output tile
     int moduli[20];
     int pinv32[20];
 };
@@ -222,6 +225,139 @@ __device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmAr
     }
 }
 
+
+// CRT tail of the tile-stationary order (FUSE != 0): after the epilogue of the LAST residue plane of an output tile
+// every consumer lane re-reads the 16-byte residue vectors IT stored for the N planes (same addresses, same lane: ordered by its own
+// vmcnt wait, no cross-wave visibility needed), accumulates the CRT sums exactly as crt_kernel does (oz2_crt.hip: same chains, same
+// order t = 0..N-1, same reduction, scalbn and axpby forms) and writes 16 consecutive rows of one column of C.  The residue planes
+// were written microseconds earlier: the re-read is served by the L2 / Infinity Cache, the stand-alone CRT pass over C_mid (N bytes
+// per element from HBM, 5 % of the config-2 call, 20 % at k = 1024) and its launch disappear.
+// The CRT block is read from the kernel-argument segment through a pointer the compiler cannot see through: taken by value it
+// hoists the 60 table doubles into SGPRs at kernel entry and keeps them (spilled to VGPR lanes) across the K loop, which pushed
+// accumulator spills INTO the MFMA loop.
+#ifndef OZ2_TAIL_ABL
+#define OZ2_TAIL_ABL 0  // timing ablations of the CRT tail (wrong results): 1 no residue re-reads, 2 no C stores, 4 no CRT chains, 8 no tail
+#endif
+template <typename U>
+__device__ __forceinline__ void i8_crt_tail(const GemmArgs& args, int i0, int j0, int lane) {
+    if (OZ2_TAIL_ABL & 8) return;
+    typedef const __attribute__((address_space(4))) CrtArgs* CrtPtr;
+    CrtPtr cp = (CrtPtr)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(GemmArgs) + 7) & ~size_t(7)));
+    asm volatile("" : "+s"(cp)::"memory");
+    const auto& c = *cp;
+    const double cPhi = c.Phi, cPlo = c.Plo, cinvP = c.invP;
+    const bool use_dd = c.use_dd != 0;
+    auto reduce = [&](double Sh, double Sl) {  // crt_reduce of oz2_crt_common.hpp
+        const double q = rint(cinvP * Sh);
+        if (!use_dd) return fma(cPhi, q, Sh);
+        return fma(cPlo, q, fma(cPhi, q, Sh) + Sl);
+    };
+    const int c16 = lane & 15;
+    const int q = lane >> 4;
+    const size_t e00 = (size_t)(j0 + c16) * args.ldo + i0 + q * 16;
+    const size_t ejs = (size_t)16 * args.ldo;
+    U al = (U)c.alpha[0], be = (U)c.beta[0];
+    int mode = c.mode;
+    if (mode == 5) {
+        al = *(const U*)c.alpha_dev;
+        be = *(const U*)c.beta_dev;
+        mode = 0;
+    }
+    const bool reads_c = mode == 0 || mode == 2 || mode == 4;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's residue stores of the last plane
+#pragma unroll 1
+    for (int sb = 0; sb < 8; ++sb) {
+        const int tj = sb >> 1, tg = sb & 1;
+        const int col = j0 + tj * 16 + c16;
+        const int r0 = i0 + tg * 64 + q * 16;
+        if (col >= args.n || r0 >= args.m) continue;
+        const size_t e = e00 + tj * ejs + tg * 64;
+        uint4 rv[20];
+#pragma unroll
+        for (unsigned t = 0; t < 20; ++t)
+            if (t < c.N) {
+                if (OZ2_TAIL_ABL & 1) rv[t] = make_uint4(lane + t, lane * 3 + t, lane * 5 + t, lane * 7 + t);
+                else rv[t] = *(const uint4*)(args.out + (size_t)t * args.strideO + e);
+            }
+        const int sB = (int)c.sftB[col];
+        const uint4 sa0 = *(const uint4*)(c.sftA + r0), sa1 = *(const uint4*)(c.sftA + r0 + 8);  // the shift vector is padded to 256 rows
+        const unsigned saw[8] = {sa0.x, sa0.y, sa0.z, sa0.w, sa1.x, sa1.y, sa1.z, sa1.w};
+        U* Cc = (U*)c.C + (size_t)col * c.ldc + r0;
+        const bool aligned = (reinterpret_cast<uintptr_t>(Cc) & 15) == 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // 8 rows at a time
+            double Sh[8], Sl[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) Sh[x] = 0.0, Sl[x] = 0.0;
+#pragma unroll
+            for (unsigned t = 0; t < 20; ++t) {
+                if (t < c.N) {
+                    const unsigned w0 = h == 0 ? rv[t].x : rv[t].z, w1 = h == 0 ? rv[t].y : rv[t].w;
+                    if (OZ2_TAIL_ABL & 4) {
+                        Sh[t & 7] += (double)(int)(w0 ^ w1);
+                    } else if (use_dd) {
+                        const double qh = c.qh[t], ql = c.ql[t];
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) {
+                            const double cd = (double)(int)(int8_t)((x < 4 ? w0 : w1) >> (8 * (x & 3)));
+                            Sh[x] = fma(qh, cd, Sh[x]);
+                            Sl[x] = fma(ql, cd, Sl[x]);
+                        }
+                    } else {
+                        const double q1 = c.q1[t];
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) Sh[x] = fma(q1, (double)(int)(int8_t)((x < 4 ? w0 : w1) >> (8 * (x & 3))), Sh[x]);
+                    }
+                }
+            }
+            const int rb = r0 + 8 * h;
+            const bool full = rb + 8 <= args.m;
+            U oldc[8], outv[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) oldc[x] = (U)0;
+            if (reads_c) {
+                if (full && aligned) {
+                    __builtin_memcpy(oldc, Cc + 8 * h, sizeof(oldc));
+                } else {
+#pragma unroll
+                    for (int x = 0; x < 8; ++x)
+                        if (rb + x < args.m) oldc[x] = Cc[8 * h + x];
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const int sA = (int)(int16_t)(saw[4 * h + (x >> 1)] >> (16 * (x & 1)));
+                const U AB = scalb<U>((U)reduce(Sh[x], Sl[x]), sA + sB);
+                switch (mode) {
+                case 1: outv[x] = AB; break;
+                case 2: outv[x] = oldc[x] + AB; break;
+                case 3: outv[x] = -AB; break;
+                case 4: outv[x] = oldc[x] - AB; break;
+                default: outv[x] = fmaU<U>(be, oldc[x], al * AB); break;
+                }
+            }
+            if (OZ2_TAIL_ABL & 2) {
+#pragma unroll
+                for (int x = 0; x < 8; ++x) asm volatile("" ::"v"(outv[x]));
+            } else if (full && aligned) {
+                typedef U VecU __attribute__((ext_vector_type(16 / sizeof(U))));
+                constexpr int PER = 16 / (int)sizeof(U);
+#pragma unroll
+                for (int v = 0; v < 8 / PER; ++v) {
+                    VecU ov;
+#pragma unroll
+                    for (int x = 0; x < PER; ++x) ov[x] = outv[v * PER + x];
+                    __builtin_nontemporal_store(ov, (VecU*)(Cc + 8 * h) + v);
+                }
+            } else {
+#pragma unroll
+                for (int x = 0; x < 8; ++x)
+                    if (rb + x < args.m) Cc[8 * h + x] = outv[x];
+            }
+        }
+    }
+}
+
 #ifndef OZ2_PB
 #define OZ2_PB 4
 #endif
@@ -245,8 +381,19 @@ constexpr int RING_LDS_BYTES = 5 * TILE_BYTES;  // five 32 KiB operand panels = 
 // are in the last K-step and the epilogue of a tile the producers already fetch the first K-tile of the next one, the
 // epilogue's stores drain behind the next tile's MFMAs, and there is no workgroup launch / LDS re-allocation between
 // tiles -- a non-persistent version of this kernel lost ~11 us of a ~120 us tile to those three.
-template <int EPI, bool KBAR>
-__global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args) {
+// FUSE != 0 (EPI_MOD only; 1: double, 2: float output): TILE-STATIONARY order -- a workgroup runs all args.planes residue planes of one
+// output tile back to back (at any moment the 256 workgroups still work on the same few planes of a chunk of 256 tiles, so the L2 /
+// Infinity Cache sharing of map_tile is unchanged) and then accumulates the CRT for that tile itself (i8_crt_tail).
+struct NoCrt {
+    int unused;
+};
+template <int EPI, bool KBAR, int FUSE>
+__global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args, const std::conditional_t<FUSE != 0, CrtArgs, NoCrt> crt) {
+    static_assert(FUSE == 0 || EPI == EPI_MOD, "the CRT tail follows the real requantise epilogue");
+    using OutT = std::conditional_t<FUSE == 2, float, double>;
+    static_assert(offsetof(CrtArgs, Cmid) == 0 && alignof(CrtArgs) == 8, "i8_crt_tail locates the block in the kernel-argument segment");
+    (void)crt;
+    const int planes_per_tile = FUSE ? args.planes : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -297,6 +444,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
         // producers B(g+1): 96 KiB in flight per CU instead of 64 -- the 2-stage version was bound by the DMA round trip
         // (64 KiB per ~1.5 us of L2-miss latency = 43 GB/s per CU against the 60 GB/s a full-speed K-step consumes).
         int vb_next = blockIdx.x;  // tile of the panel to fetch next
+        int pl_next = 0;           // FUSE: its residue plane
         bool more = true;
         PRODUCER_SET_TILE(vb_next);
         int seg = 0, kin = 0;      // its segment / K-step inside the segment (no divisions in the loop)
@@ -313,9 +461,15 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
             kin = 0;                                                                                                         \
             if (++seg == args.nseg) {                                                                                        \
                 seg = 0;                                                                                                     \
-                vb_next += G;                                                                                                \
-                more = vb_next < total;                                                                                      \
-                if (more) PRODUCER_SET_TILE(vb_next);                                                                        \
+                if (FUSE && ++pl_next < planes_per_tile) { /* same tile, next residue plane: the lane offsets stay */        \
+                    const size_t st_ = isB ? args.strideB : args.strideA;                                                    \
+                    g0 = uniform(g0 + st_), g1 = uniform(g1 + st_), g2 = uniform(g2 + st_);                                  \
+                } else {                                                                                                     \
+                    pl_next = 0;                                                                                             \
+                    vb_next += G;                                                                                            \
+                    more = vb_next < total;                                                                                  \
+                    if (more) PRODUCER_SET_TILE(vb_next);                                                                    \
+                }                                                                                                            \
             }                                                                                                                \
         }                                                                                                                    \
     } while (0)
@@ -340,7 +494,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
         // ONE workgroup barrier per K-step (see the consumer branch).  Without per-segment barriers to pace them the producers space
         // their instructions with s_sleep (64 clocks per unit): bursts of LDS-DMA cost (all 16 at once: +7 % kernel time).
         for (int vb = blockIdx.x; vb < total; vb += G) {
-            for (int kt = 0; kt < KT; ++kt) {
+            for (int kt = 0; kt < KT * planes_per_tile; ++kt) {
                 const bool issued = more && (!(OZ2_PROBE_LDS & 4) || vb == (int)blockIdx.x);  // probe bit 2: DMA during the first tile only
                 if (issued) {
                     PRODUCER_BEGIN();
@@ -369,7 +523,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
         }
         } else {
         for (int vb = blockIdx.x; vb < total; vb += G) {
-            for (int kt = 0; kt < KT; ++kt) {
+            for (int kt = 0; kt < KT * planes_per_tile; ++kt) {
                 // A producers: A(g+2); B producers: B(g+1); afterwards the panel needed NEXT K-step must have landed, which
                 // for the A producers means everything except the 16 instructions just issued
                 const bool issued = more && (!(OZ2_PROBE_LDS & 4) || vb == (int)blockIdx.x);  // probe bit 2: DMA during the first tile only
@@ -435,6 +589,8 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     auto run = [&]<bool WM1>() {
         int sA = 0;  // slot of A(g); B(g) sits in the next slot (mod 5)
         for (int vb = blockIdx.x; vb < total; vb += G) {
+            const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n);
+            for (int pl = 0; pl < planes_per_tile; ++pl) {
             v4i acc[8][4];
             v4i af[4], bf[4];
 #pragma unroll
@@ -488,7 +644,6 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #undef OZ2_SET_PANELS
 #undef OZ2_LOAD_SEG
 #undef OZ2_MMA_SEG
-            const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n);
 #if OZ2_PROBE_LDS & 8
             (void)tmap;  // probe bit 3: no epilogue; the accumulators stay live
 #pragma unroll
@@ -496,8 +651,10 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #pragma unroll
                 for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-            i8_epilogue<EPI>(acc, args, tmap.plane, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane);
+            i8_epilogue<EPI>(acc, args, FUSE ? pl : tmap.plane, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane);
 #endif
+            }
+            if constexpr (FUSE != 0) i8_crt_tail<OutT>(args, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane);
         }
     };
     if (wm == 0) run.template operator()<false>();
@@ -507,6 +664,8 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     if (wm == 1) __builtin_amdgcn_s_barrier();  // trailing half: one segment behind
     int sA = 0;                                  // slot of A(g); B(g) sits in the next slot (mod 5)
     for (int vb = blockIdx.x; vb < total; vb += G) {
+        const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n);
+        for (int pl = 0; pl < planes_per_tile; ++pl) {
         v4i acc[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -558,7 +717,6 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
                 }
             }
         }
-        const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n);
 #if OZ2_PROBE_LDS & 8
         (void)tmap;  // probe bit 3: no epilogue; the accumulators stay live
 #pragma unroll
@@ -566,8 +724,10 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-        i8_epilogue<EPI>(acc, args, tmap.plane, tmap.tm * BM + wm * 128, tmap.tn * BN + wn * 64, lane);
+        i8_epilogue<EPI>(acc, args, FUSE ? pl : tmap.plane, tmap.tm * BM + wm * 128, tmap.tn * BN + wn * 64, lane);
 #endif
+        }
+        if constexpr (FUSE != 0) i8_crt_tail<OutT>(args, tmap.tm * BM + wm * 128, tmap.tn * BN + wn * 64, lane);
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();
     }
@@ -597,14 +757,15 @@ static int num_cus() {
     return n;
 }
 
-template <int EPI, bool KBAR> static hipError_t launch_sched(hipStream_t stream, GemmArgs& a) {
+template <int EPI, bool KBAR, int FUSE = 0>
+static hipError_t launch_sched(hipStream_t stream, GemmArgs& a, const std::conditional_t<FUSE != 0, CrtArgs, NoCrt>& crt = {}) {
     // the attribute belongs to the function on ONE device; setting it is idempotent, so concurrent first calls from several host
     // threads only need the flag itself to be race-free
     static std::atomic<bool> attr_set_dev[64];
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 0;
     if (!attr_set_dev[dev_].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_kernel<EPI, KBAR>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_kernel<EPI, KBAR, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set_dev[dev_].store(true, std::memory_order_release);
     }
@@ -614,7 +775,7 @@ template <int EPI, bool KBAR> static hipError_t launch_sched(hipStream_t stream,
     int grid = num_cus() & ~7;
     if (grid <= 0) grid = 8;
     if (a.total_tiles < grid) grid = a.total_tiles;
-    hipLaunchKernelGGL((gemm_i8_kernel<EPI, KBAR>), dim3(grid), dim3(WS_THREADS), RING_LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((gemm_i8_kernel<EPI, KBAR, FUSE>), dim3(grid), dim3(WS_THREADS), RING_LDS_BYTES, stream, a, crt);
     return hipGetLastError();
 }
 
@@ -644,6 +805,49 @@ hipError_t launch_gemm_i8_mod(hipStream_t stream, const int8_t* A, const int8_t*
     a.strideO = strideO;
     fill_common(a, kp, m, n);
     return launch<EPI_MOD>(stream, a, t_end - t_begin);
+}
+
+// Tile-stationary GEMM + requantise + CRT in one launch (real types, all N moduli).  Worth it when the tiles of ONE plane fill the
+// chip about as well as the tiles of all planes do: the unit of work per workgroup is N times larger.
+bool gemm_i8_crt_fusable(size_t m, size_t n, unsigned N) {
+    const long tiles = (long)((m + BM - 1) / BM) * (long)((n + BN - 1) / BN);
+    long grid = num_cus() & ~7;
+    if (grid <= 0) grid = 8;
+    const long rounds_fused = (tiles + grid - 1) / grid * (long)N;    // tile-times on the busiest workgroup
+    const long rounds_plain = (tiles * (long)N + grid - 1) / grid;
+    return tiles >= grid && rounds_fused * 100 <= rounds_plain * 104;
+}
+
+hipError_t launch_gemm_i8_mod_crt(hipStream_t stream, int dtype, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp,
+                                  size_t m, size_t n, unsigned N, int8_t* out, size_t ldo, size_t strideO, const int16_t* sftA,
+                                  const int16_t* sftB, const void* alpha, const void* beta, bool scalars_on_device, void* C, size_t ldc) {
+    if (dtype != kF64 && dtype != kF32) return hipErrorInvalidValue;
+    GemmArgs a{};
+    a.A[0] = A;
+    a.B[0] = B;
+    a.nseg = 1;
+    a.strideA = strideA;
+    a.strideB = strideB;
+    a.t_begin = 0;
+    a.out = out;
+    a.ldo = ldo;
+    a.strideO = strideO;
+    fill_common(a, kp, m, n);
+    a.planes = (int)N;
+    a.total_tiles = a.tiles_m * a.tiles_n;
+    if (a.total_tiles <= 0) return hipSuccess;
+    CrtArgs c{};
+    c.m = m;
+    c.n = n;
+    c.sftA = sftA;
+    c.sftB = sftB;
+    c.C = C;
+    c.ldc = ldc;
+    fill_crt_tables(c, dtype, kINT8, N);
+    fill_crt_scalars(c, dtype, alpha, beta, scalars_on_device);
+    const bool kbar = a.kp <= OZ2_KBAR_MAX_KP;
+    if (dtype == kF64) return kbar ? launch_sched<EPI_MOD, true, 1>(stream, a, c) : launch_sched<EPI_MOD, false, 1>(stream, a, c);
+    return kbar ? launch_sched<EPI_MOD, true, 2>(stream, a, c) : launch_sched<EPI_MOD, false, 2>(stream, a, c);
 }
 
 hipError_t launch_gemm_i8_cplx(hipStream_t stream, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp, size_t m,

@@ -113,6 +113,16 @@ GEMMUL8_API int gemmul8_crt(void *stream, int dtype, int backend, unsigned num_m
                 size_t ld_mid, size_t plane_stride, const int16_t *sftA, const int16_t *sftB, const void *alpha,
                 const void *beta, void *C, size_t ldc);
 
+/* Low-precision GEMMs of ALL moduli + CRT accumulation + inverse scaling + axpby in ONE launch (real types on
+ * the INT8 backend): the kernel keeps an output tile, runs its num_moduli residue GEMMs back to back and accumulates the CRT for the
+ * tile itself -- the stand-alone pass over C_mid and its launch disappear; results are bit-identical to gemmul8_lowprec_gemm followed
+ * by gemmul8_crt (the residue planes still land in L->C_mid).  Returns GEMMUL8_E_UNSUPPORTED for complex types and the FP8 backend.
+ * gemmul8_fused_crt_selected: 1 when gemmul8_gemm takes this path for the shape: opt-in with GEMMUL8_FUSED_CRT=1 (whenever legal) or
+ * =auto (when the tiles of one plane fill the chip); unset = the two-launch path.  Replaces the loop at src/gemmul8_real.hpp:144-204 as a whole. */
+GEMMUL8_API int gemmul8_lowprec_gemm_crt(void *stream, int dtype, int backend, size_t m, size_t n, size_t k, unsigned num_moduli,
+                             const gemmul8_layout *L, const void *alpha, const void *beta, void *C, size_t ldc);
+GEMMUL8_API int gemmul8_fused_crt_selected(int dtype, int backend, size_t m, size_t n, unsigned num_moduli);
+
 /* Multi-GPU exchange variant (A) of the moduli-sharded plan (include/gemmul8_dist.h): the rank's FP64 partial CRT sums over its
  * moduli [t_begin, t_end) -- C_mid points at plane t_begin -- as two double planes (hi: error-free chain, lo: rounded chain;
  * same FMAs and order as gemmul8_crt restricted to those moduli), written in column blocks of col_block columns, block b at

@@ -20,6 +20,7 @@ ap.add_argument("--size", type=int, default=8192)
 ap.add_argument("--moduli", type=int, default=14)
 ap.add_argument("--k", default="8192")
 ap.add_argument("--rounds", type=int, default=9)
+ap.add_argument("--fused", action="store_true", help="time gemmul8_lowprec_gemm_crt (GEMMs + CRT in one launch) of every build; the first build's two-launch path (lowprec_gemm + crt) is timed beside it")
 a = ap.parse_args()
 n, N = a.size, a.moduli
 ref = g.lib()  # binds the HIP runtime, gives layout/work_size
@@ -31,7 +32,16 @@ for i, pth in enumerate(a.libs):
     L = C.CDLL(cp)
     L.gemmul8_lowprec_gemm.restype = C.c_int
     L.gemmul8_lowprec_gemm.argtypes = ref.gemmul8_lowprec_gemm.argtypes
+    L.gemmul8_lowprec_gemm_crt.restype = C.c_int
+    L.gemmul8_lowprec_gemm_crt.argtypes = ref.gemmul8_lowprec_gemm_crt.argtypes
+    L.gemmul8_crt.restype = C.c_int
+    L.gemmul8_crt.argtypes = ref.gemmul8_crt.argtypes
     libs.append(L)
+if a.fused:
+    libs.append(None)  # the two-launch path of the first build
+    a.libs.append("two-launch(" + os.path.basename(a.libs[0]) + ")")
+import numpy as np
+one, zero = np.array([1.0]), np.array([0.0])
 st = torch.cuda.current_stream().cuda_stream
 for k in [int(x) for x in a.k.split(",")]:
     tot, _, _ = g.work_size(False, g.INT8, n, n, k, N)
@@ -41,13 +51,25 @@ for k in [int(x) for x in a.k.split(",")]:
     offA, offB = Lo.A_lo - work.data_ptr(), Lo.B_lo - work.data_ptr()
     work[offA:offA + N * Lo.sizeA] = torch.randint(0, 256, (N * Lo.sizeA,), dtype=torch.uint8, device="cuda")
     work[offB:offB + N * Lo.sizeB] = torch.randint(0, 256, (N * Lo.sizeB,), dtype=torch.uint8, device="cuda")
+    Cout = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+    offS = Lo.sftA - work.data_ptr()
+    work[offS:offS + 2 * Lo.mp] = 0
+    offS = Lo.sftB - work.data_ptr()
+    work[offS:offS + 2 * n] = 0
     ts = [[] for _ in libs]
     for r in range(a.rounds + 2):
         for i, L in enumerate(libs):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
-                g.check(L.gemmul8_lowprec_gemm(st, g.D, g.INT8, n, n, k, N, 0, N, C.byref(Lo)))
+                if not a.fused:
+                    g.check(L.gemmul8_lowprec_gemm(st, g.D, g.INT8, n, n, k, N, 0, N, C.byref(Lo)))
+                elif L is not None:
+                    g.check(L.gemmul8_lowprec_gemm_crt(st, g.D, g.INT8, n, n, k, N, C.byref(Lo), one.ctypes.data, zero.ctypes.data, Cout.data_ptr(), n))
+                else:
+                    g.check(libs[0].gemmul8_lowprec_gemm(st, g.D, g.INT8, n, n, k, N, 0, N, C.byref(Lo)))
+                    g.check(libs[0].gemmul8_crt(st, g.D, g.INT8, N, n, n, Lo.C_mid, Lo.mp, Lo.sizeC, Lo.sftA, Lo.sftB, one.ctypes.data, zero.ctypes.data,
+                                                Cout.data_ptr(), n))
             e1.record()
             torch.cuda.synchronize()
             if r >= 2:
