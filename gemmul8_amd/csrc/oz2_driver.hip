@@ -332,7 +332,7 @@ int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t
 int gemmul8_fused_crt_selected(int dtype, int backend, size_t m, size_t n, unsigned N) {
     if (backend != kINT8 || dtype < 0 || dtype > 3 || is_complex(dtype) || N < 2 || N > 20) return 0;
     const char* s = getenv("GEMMUL8_FUSED_CRT");
-    if (s && s[0] == '1') return 1;                                     // whenever it is legal
+    if (s && (s[0] == '1' || s[0] == '2')) return s[0] - '0';          // whenever it is legal (2: the consumer-tail variant)
     if (s && s[0] == 'a') return gemm_i8_crt_fusable(m, n, N) ? 1 : 0;  // "auto": when the tiles of one plane fill the chip
     return 0;  // default off: measured slower than the two-launch path
 }
@@ -344,8 +344,10 @@ int gemmul8_lowprec_gemm_crt(void* stream_, int dtype, int backend, size_t m, si
     if (dtype < 0 || dtype > 3 || backend < 0 || backend > 1) return GEMMUL8_E_ARG;
     if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
     if (backend != kINT8 || is_complex(dtype)) return GEMMUL8_E_UNSUPPORTED;
+    const char* env_fused = getenv("GEMMUL8_FUSED_CRT");
     OZ2_HIP(launch_gemm_i8_mod_crt((hipStream_t)stream_, dtype, (const int8_t*)L->A_lo, (const int8_t*)L->B_lo, L->sizeA, L->sizeB, L->kp, m, n, N,
-                                   (int8_t*)L->C_mid, L->mp, L->sizeC, L->sftA, L->sftB, alpha, beta, scalars_on_device(alpha), C, ldc));
+                                   (int8_t*)L->C_mid, L->mp, L->sizeC, L->sftA, L->sftB, alpha, beta, scalars_on_device(alpha), C, ldc,
+                                   (env_fused && env_fused[0] == '2') ? 2 : 1));
     return GEMMUL8_OK;
 }
 

@@ -381,6 +381,269 @@ constexpr int RING_LDS_BYTES = 5 * TILE_BYTES;  // five 32 KiB operand panels = 
 // are in the last K-step and the epilogue of a tile the producers already fetch the first K-tile of the next one, the
 // epilogue's stores drain behind the next tile's MFMAs, and there is no workgroup launch / LDS re-allocation between
 // tiles -- a non-persistent version of this kernel lost ~11 us of a ~120 us tile to those three.
+// The producer waves of the tile-stationary kernel, OUT OF LINE: as a separate function they get their own register allocation.  Inlined,
+// their scalar state (two tile cursors, the CRT block) spilled SGPRs into VGPR lanes, and the two VGPRs the compiler reserves for that
+// in the WHOLE kernel pushed accumulator spills into the consumers' MFMA loop (which uses all 168 registers).
+template <int FUSE>
+__device__ __attribute__((noinline)) void i8_producer_crt(__attribute__((address_space(3))) char* smem3,
+                                                          const __attribute__((address_space(4))) char* kernarg) {
+    // the kernel-argument segment pointer is not available in a callable function (the builtin yields null there): the kernel passes
+    // it; made wave-uniform again (arguments arrive in VGPRs) so that every field is a scalar load
+    {
+        const unsigned long long v = (unsigned long long)kernarg;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        kernarg = (const __attribute__((address_space(4))) char*)(((unsigned long long)hi << 32) | lo);
+    }
+    typedef const __attribute__((address_space(4))) GemmArgs* ArgsPtr;
+    const auto& args = *(ArgsPtr)kernarg;
+    using OutT = std::conditional_t<FUSE == 2, float, double>;
+    char* smem = (char*)smem3;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int KT1 = args.kp / BK;
+    const int KT = KT1 * args.nseg;
+    const int total = args.total_tiles;
+    const int G = gridDim.x;
+    const int planes_per_tile = args.planes;
+#include "oz2_gemm_i8_producer.inc"
+        // ---- CRT ON THE PRODUCER WAVES.  The consumers keep their accumulators and their registers; the four
+        // producer waves -- one per SIMD, idle between LDS-DMA instructions -- accumulate the CRT of the PREVIOUS output tile beside the
+        // MFMAs of the current one: the FP64 chains run on the vector ALUs while the matrix pipes are busy, the re-read of the residue
+        // planes (written by this CU during the previous tile) comes from the L2 / Infinity Cache, and the stand-alone CRT pass and its
+        // launch disappear.  Unit of work: one column of the 256 x 256 tile (4 rows per lane: 256 contiguous bytes per residue plane,
+        // 2 KiB of C per wave); wave pw takes columns pw, pw + 4, ...  A three-stage pipeline moves one unit per K-step:
+        //   K-step j, start : stores of unit j - 2; loads of unit j (N residue words, 4 shifts, old C) -- all memory instructions sit
+        //                     BEFORE the K-step's LDS-DMA, so the end-of-K-step vmcnt wait (16 for the A waves: loads return in order)
+        //                     covers them and never waits for the DMA just issued;
+        //   K-step j, slots : the s_sleep pauses between the DMA groups become the FMA chains of unit j - 1 (3 planes per slot);
+        //   K-step j, end   : mod-P reduction, scalbn, axpby of unit j - 1; after the barrier the loaded registers change stage.
+        // The loads are inline asm (invisible to the compiler's waitcnt insertion, which would otherwise put a vmcnt(0) in front of the
+        // first use and stall the DMA pipeline); their destination registers are not touched between issue and the end-of-K-step wait
+        // (read-write operands: the value loaded and the value kept when no unit is loaded live in the SAME register, so no copy is
+        // placed at the merge before the data has arrived).
+        // Tile r's residues may be read one K-step after the consumers' vmcnt(0) + barrier that follow its last epilogue.  At small k the
+        // CRT falls behind and finishes in the drain loop after the last K-step, as does the last tile's.
+        typedef const __attribute__((address_space(4))) CrtArgs* CrtPtr;
+        CrtPtr cp = (CrtPtr)(kernarg + ((sizeof(GemmArgs) + 7) & ~size_t(7)));
+        asm volatile("" : "+s"(cp)::"memory");
+#define c (*cp)
+        using U = OutT;
+        const unsigned cN = c.N;
+        const bool use_dd = c.use_dd != 0;
+        const double cPhi = c.Phi, cPlo = c.Plo, cinvP = c.invP;
+        U al = (U)c.alpha[0], be = (U)c.beta[0];
+        int mode = c.mode;
+        if (mode == 5) {
+            al = *(const U*)c.alpha_dev;
+            be = *(const U*)c.beta_dev;
+            mode = 0;
+        }
+        const bool reads_c = mode == 0 || mode == 2 || mode == 4;
+        const int S = KT * planes_per_tile;  // K-steps per output tile
+        int c_vb = blockIdx.x, c_u = 0;      // CRT cursor: tile and next unit (0..63) to load
+        TileMap c_map = map_tile(c_vb, total, args.tiles_m, args.tiles_n);
+        int g = 0, ready_at = S + 1;         // K-steps completed; K-step from which the cursor tile's residues may be read
+        unsigned rvN[20], rvC[20];           // residue words (4 rows): stage "loaded" / stage "accumulating"
+        unsigned long long saN = 0, saC = 0; // four int16 shifts of A
+        int sBN = 0, sBC = 0;
+        v4i ocN[2], ocC[2];                  // old C (4 x U; float uses ocN[0] only)
+        U outv[4];
+        U *CcN = nullptr, *CcC = nullptr, *CcS = nullptr;  // this lane's first element of C per stage
+        int vrN = 0, vrC = 0, vrS = 0;       // its number of valid rows (0..4)
+        bool nval = false, cval = false, sval = false;
+        double Sh[4], Sl[4];
+#pragma unroll
+        for (int t = 0; t < 20; ++t) rvN[t] = rvC[t] = 0;
+        ocN[0] = ocN[1] = ocC[0] = ocC[1] = v4i{0, 0, 0, 0};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) outv[x] = (U)0;
+
+#define PCRT_MEM_SLOT()                                                                                                      \
+    do {                                                                                                                     \
+        asm volatile("" : "+s"(cp));                                                                                         \
+        if (sval) {                                                                                                          \
+            if (vrS == 4) {                                                                                                  \
+                typedef U VecU __attribute__((ext_vector_type(16 / sizeof(U))));                                             \
+                constexpr int PER = 16 / (int)sizeof(U);                                                                     \
+                _Pragma("unroll") for (int v = 0; v < 4 / PER; ++v) {                                                        \
+                    VecU ov;                                                                                                 \
+                    _Pragma("unroll") for (int x = 0; x < PER; ++x) ov[x] = outv[v * PER + x];                               \
+                    typedef VecU __attribute__((aligned(sizeof(U)))) VecUU;                                                  \
+                    __builtin_nontemporal_store(ov, (VecUU*)CcS + v);                                                        \
+                }                                                                                                            \
+            } else {                                                                                                         \
+                _Pragma("unroll") for (int x = 0; x < 4; ++x) if (x < vrS) CcS[x] = outv[x];                                 \
+            }                                                                                                                \
+            sval = false;                                                                                                    \
+        }                                                                                                                    \
+        nval = false;                                                                                                        \
+        if (c_vb < total && g >= ready_at) {                                                                                 \
+            const int col_ = c_map.tn * BN + 4 * c_u + pw;                                                                   \
+            const int i0_ = c_map.tm * BM;                                                                                   \
+            if (col_ < args.n) {                                                                                             \
+                const int8_t* ub_ = uniform(args.out + (size_t)col_ * args.ldo + i0_);                                       \
+                const unsigned vo_ = (unsigned)lane * 4u;                                                                    \
+                _Pragma("unroll") for (unsigned t = 0; t < 20; ++t) if (t < cN) {                                            \
+                    const int8_t* pb_ = uniform(ub_ + (size_t)t * args.strideO);                                             \
+                    asm volatile("global_load_dword %0, %1, %2 sc0" : "+v"(rvN[t]) : "v"(vo_), "s"(pb_) : "memory");         \
+                }                                                                                                            \
+                const int8_t* sp_ = uniform((const int8_t*)(c.sftA + i0_));                                                  \
+                const unsigned so_ = (unsigned)lane * 8u;                                                                    \
+                asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(saN) : "v"(so_), "s"(sp_) : "memory");                  \
+                int sw_;                                                                                                     \
+                const int8_t* sq_ = uniform((const int8_t*)c.sftB + 4 * (col_ >> 1));                                        \
+                asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sw_) : "s"(sq_) : "memory");          \
+                sBN = (int)(int16_t)((col_ & 1) ? (sw_ >> 16) : sw_);                                                         \
+                const int left_ = (int)args.m - (i0_ + 4 * lane);                                                            \
+                vrN = left_ < 0 ? 0 : left_ > 4 ? 4 : left_;                                                                 \
+                CcN = (U*)c.C + (size_t)col_ * c.ldc + (size_t)(i0_ + 4 * lane);                                             \
+                if (reads_c) {                                                                                               \
+                    if (vrN == 4) {                                                                                          \
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(ocN[0]) : "v"(CcN) : "memory");                \
+                        if (sizeof(U) == 8) asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "+v"(ocN[1]) : "v"(CcN) : "memory"); \
+                    } else {                                                                                                 \
+                        _Pragma("unroll") for (int x = 0; x < 4; ++x) if (x < vrN) {                                         \
+                            if (sizeof(U) == 8) {                                                                            \
+                                unsigned long long w_;                                                                       \
+                                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(w_) : "v"(CcN + x) : "memory");        \
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* ragged last tile row only */             \
+                                ocN[x >> 1][2 * (x & 1)] = (int)w_, ocN[x >> 1][2 * (x & 1) + 1] = (int)(w_ >> 32);           \
+                            } else {                                                                                         \
+                                unsigned w_;                                                                                 \
+                                asm volatile("global_load_dword %0, %1, off" : "=v"(w_) : "v"(CcN + x) : "memory");          \
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+                                ocN[0][x] = (int)w_;                                                                         \
+                            }                                                                                                \
+                        }                                                                                                    \
+                    }                                                                                                        \
+                }                                                                                                            \
+                nval = true;                                                                                                 \
+            }                                                                                                                \
+            if (++c_u == 64) {                                                                                               \
+                c_u = 0;                                                                                                     \
+                c_vb += G;                                                                                                   \
+                ready_at += S;                                                                                               \
+                if (c_vb < total) c_map = map_tile(c_vb, total, args.tiles_m, args.tiles_n);                                 \
+            }                                                                                                                \
+        }                                                                                                                    \
+    } while (0)
+#define PCRT_ACC(slot_)                                                                                                      \
+    do {                                                                                                                     \
+        asm volatile("" : "+s"(cp)); /* the table doubles of this slot only: hoisted, the 60 of them spill SGPRs into VGPR lanes */ \
+        if ((slot_) == 0) {                                                                                                  \
+            _Pragma("unroll") for (int x = 0; x < 4; ++x) Sh[x] = 0.0, Sl[x] = 0.0;                                          \
+        }                                                                                                                    \
+        _Pragma("unroll") for (unsigned t = 3 * (slot_); t < 3 * (slot_) + 3 && t < 20; ++t) if (t < cN) {                   \
+            const unsigned w_ = rvC[t];                                                                                      \
+            if (use_dd) {                                                                                                    \
+                const double qh_ = c.qh[t], ql_ = c.ql[t];                                                                   \
+                _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                                              \
+                    const double cd_ = (double)(int)(int8_t)(w_ >> (8 * x));                                                 \
+                    Sh[x] = fma(qh_, cd_, Sh[x]);                                                                            \
+                    Sl[x] = fma(ql_, cd_, Sl[x]);                                                                            \
+                }                                                                                                            \
+            } else {                                                                                                         \
+                const double q1_ = c.q1[t];                                                                                  \
+                _Pragma("unroll") for (int x = 0; x < 4; ++x) Sh[x] = fma(q1_, (double)(int)(int8_t)(w_ >> (8 * x)), Sh[x]); \
+            }                                                                                                                \
+        }                                                                                                                    \
+    } while (0)
+#define PCRT_FIN()                                                                                                           \
+    do {                                                                                                                     \
+        _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                                                      \
+            const double qq_ = rint(cinvP * Sh[x]);                                                                          \
+            const double R_ = use_dd ? fma(cPlo, qq_, fma(cPhi, qq_, Sh[x]) + Sl[x]) : fma(cPhi, qq_, Sh[x]);                 \
+            const int sA_ = (int)(int16_t)(saC >> (16 * x));                                                                 \
+            const U AB_ = scalb<U>((U)R_, sA_ + sBC);                                                                        \
+            U old_;                                                                                                          \
+            if (sizeof(U) == 8) {                                                                                            \
+                const unsigned long long b_ = (unsigned long long)(unsigned)ocC[x >> 1][2 * (x & 1)] |                       \
+                                              ((unsigned long long)(unsigned)ocC[x >> 1][2 * (x & 1) + 1] << 32);            \
+                __builtin_memcpy(&old_, &b_, sizeof(U) == 8 ? 8 : 4);                                                        \
+            } else {                                                                                                         \
+                const unsigned b_ = (unsigned)ocC[0][x];                                                                     \
+                __builtin_memcpy(&old_, &b_, sizeof(U) == 8 ? 4 : 4);                                                        \
+            }                                                                                                                \
+            switch (mode) {                                                                                                  \
+            case 1: outv[x] = AB_; break;                                                                                    \
+            case 2: outv[x] = old_ + AB_; break;                                                                             \
+            case 3: outv[x] = -AB_; break;                                                                                   \
+            case 4: outv[x] = old_ - AB_; break;                                                                             \
+            default: outv[x] = fmaU<U>(be, old_, al * AB_); break;                                                           \
+            }                                                                                                                \
+        }                                                                                                                    \
+        CcS = CcC, vrS = vrC, sval = true;                                                                                   \
+    } while (0)
+#define PCRT_ROTATE()                                                                                                        \
+    do {                                                                                                                     \
+        if (nval) {                                                                                                          \
+            _Pragma("unroll") for (int t = 0; t < 20; ++t) {                                                                 \
+                asm volatile("" : "+v"(rvN[t]));                                                                             \
+                rvC[t] = rvN[t];                                                                                             \
+            }                                                                                                                \
+            asm volatile("" : "+v"(saN), "+v"(ocN[0]), "+v"(ocN[1]));                                                        \
+            saC = saN, sBC = sBN, ocC[0] = ocN[0], ocC[1] = ocN[1], CcC = CcN, vrC = vrN;                                    \
+        }                                                                                                                    \
+        cval = nval;                                                                                                         \
+        ++g;                                                                                                                 \
+    } while (0)
+
+        for (int vb = blockIdx.x; vb < total; vb += G) {
+            for (int kt = 0; kt < S; ++kt) {
+                const bool issued = more;
+                PCRT_MEM_SLOT();
+                if (issued) PRODUCER_BEGIN();
+#pragma unroll
+                for (int gq = 0; gq < 8; ++gq) {
+                    if (issued) {
+                        if (isB) {
+                            if (gq < 4) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) PRODUCER_DMA(fsrc, gq * 4 + q, fdst);
+                            }
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) PRODUCER_DMA(fsrc, gq * 2 + q, fdst);
+                        }
+                    }
+                    if (cval) {
+                        if (gq < 7) PCRT_ACC(gq);
+                    } else if (isB ? gq < 4 : true) {
+                        if (isB) __builtin_amdgcn_s_sleep(OZ2_SLEEP_B);
+                        else __builtin_amdgcn_s_sleep(OZ2_SLEEP_A);
+                    }
+                }
+                if (cval) PCRT_FIN();
+                if (issued) PRODUCER_ADVANCE();
+                if (!isB && issued) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                PCRT_ROTATE();
+            }
+        }
+        // the consumers finish the last tile's epilogue, wait for their stores and meet the producers here; then drain the pipeline
+        __builtin_amdgcn_s_barrier();
+        g = 0x3fffffff;
+        while (c_vb < total || cval || sval) {
+            PCRT_MEM_SLOT();
+            if (cval) {
+#pragma unroll
+                for (int gq = 0; gq < 7; ++gq) PCRT_ACC(gq);
+                PCRT_FIN();
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PCRT_ROTATE();
+            g = 0x3fffffff;
+        }
+#undef PCRT_MEM_SLOT
+#undef PCRT_ACC
+#undef PCRT_FIN
+#undef PCRT_ROTATE
+#undef c
+#include "oz2_gemm_i8_producer_undef.inc"
+}
+
 // FUSE != 0 (EPI_MOD only; 1: double, 2: float output): TILE-STATIONARY order -- a workgroup runs all args.planes residue planes of one
 // output tile back to back (at any moment the 256 workgroups still work on the same few planes of a chunk of 256 tiles, so the L2 /
 // Infinity Cache sharing of map_tile is unchanged) and then accumulates the CRT for that tile itself (i8_crt_tail).
@@ -404,92 +667,12 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     const int G = gridDim.x;
 
     if (wave >= 8) {  // ------------------------------ producer waves: LDS-DMA only
-        // Wave pw issues DMA instructions Q = 16 pw .. 16 pw + 15 of every K-tile (1 KiB = 8 rows x 128 B each; 4096 16-byte
-        // LDS slots per stage: slot s <-> operand (s >= 2048: B), row (s & 2047) >> 3, physical chunk s & 7 holding logical
-        // chunk (s & 7) ^ ((row >> 1) & 7)), i.e. waves 0,1 fetch A and waves 2,3 fetch B.  Per tile: a wave-uniform base
-        // pointer per K segment and 16 per-lane byte offsets (row * kp + chunk, B rows clamped to the rows that exist), so
-        // the K loop issues global_load_lds with SGPR base + VGPR offset and no address arithmetic.
-        const int pw = wave - 8;
-        const bool isB = pw >= 2;
-        unsigned doff[16];
-        const int8_t *g0, *g1, *g2;
-        auto uniform = [](const int8_t* ptr) {
-            const unsigned long long v = (unsigned long long)ptr;
-            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-            return (const int8_t*)(((unsigned long long)hi << 32) | lo);
-        };
-#define PRODUCER_SET_TILE(vb_)                                                                                               \
-    do {                                                                                                                     \
-        const TileMap tmap_ = map_tile((vb_), total, args.tiles_m, args.tiles_n);                                            \
-        const size_t off_ = isB ? (size_t)tmap_.plane * args.strideB + (size_t)tmap_.tn * BN * args.kp                       \
-                                : (size_t)tmap_.plane * args.strideA + (size_t)tmap_.tm * BM * args.kp;                      \
-        g0 = uniform((isB ? args.B[0] : args.A[0]) + off_);                                                                  \
-        g1 = uniform((isB ? args.B[1] : args.A[1]) + off_);                                                                  \
-        g2 = uniform((isB ? args.B[2] : args.A[2]) + off_);                                                                  \
-        const int nvalid_ = isB ? ((args.n - tmap_.tn * BN) < BN ? (args.n - tmap_.tn * BN) : BN) : BM;                       \
-        _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                                     \
-            const int pp_ = (((pw & 1) * 16 + q) * 64 + lane);                                                               \
-            int row_ = pp_ >> 3;                                                                                             \
-            const int c_ = (pp_ & 7) ^ ((row_ >> 1) & 7);                                                                    \
-            row_ = row_ < nvalid_ ? row_ : nvalid_ - 1;                                                                      \
-            doff[q] = (unsigned)row_ * (unsigned)args.kp + c_ * 16;                                                          \
-        }                                                                                                                    \
-    } while (0)
-#define PRODUCER_DMA(src_, q_, stage_)                                                                                       \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((src_) + doff[q_]),                     \
-                                     (__attribute__((address_space(3))) void*)((stage_) + (pw * 16 + (q_)) * 1024), 16, 0, OZ2_DMA_AUX)
-
-        // 2.5-stage ring of operand panels (5 x 32 KiB = all 160 KiB of LDS): panel h = 2 g + isB lives in slot h % 5.  The slot of
-        // A(g') held B(g'-3) and the slot of B(g') held A(g'-2), so during K-step g the A producers may fetch A(g+2) and the B
-        // producers B(g+1): 96 KiB in flight per CU instead of 64 -- the 2-stage version was bound by the DMA round trip
-        // (64 KiB per ~1.5 us of L2-miss latency = 43 GB/s per CU against the 60 GB/s a full-speed K-step consumes).
-        int vb_next = blockIdx.x;  // tile of the panel to fetch next
-        int pl_next = 0;           // FUSE: its residue plane
-        bool more = true;
-        PRODUCER_SET_TILE(vb_next);
-        int seg = 0, kin = 0;      // its segment / K-step inside the segment (no divisions in the loop)
-        int hs = isB ? 1 : 0;      // its slot
-#define PRODUCER_BEGIN()                                                                                                     \
-    do {                                                                                                                     \
-        fsrc = (seg == 0 ? g0 : seg == 1 ? g1 : g2) + (size_t)((OZ2_PROBE_LDS & 16) ? (kin & 7) : kin) * BK; /* probe bit 4: L2-resident operands */ \
-        fdst = smem + hs * TILE_BYTES - (isB ? TILE_BYTES : 0);   /* PRODUCER_DMA adds pw * 16 KiB */                         \
-    } while (0)
-#define PRODUCER_ADVANCE()                                                                                                   \
-    do {                                                                                                                     \
-        hs = hs + 2 >= 5 ? hs - 3 : hs + 2;                                                                                  \
-        if (++kin == KT1) {                                                                                                  \
-            kin = 0;                                                                                                         \
-            if (++seg == args.nseg) {                                                                                        \
-                seg = 0;                                                                                                     \
-                if (FUSE && ++pl_next < planes_per_tile) { /* same tile, next residue plane: the lane offsets stay */        \
-                    const size_t st_ = isB ? args.strideB : args.strideA;                                                    \
-                    g0 = uniform(g0 + st_), g1 = uniform(g1 + st_), g2 = uniform(g2 + st_);                                  \
-                } else {                                                                                                     \
-                    pl_next = 0;                                                                                             \
-                    vb_next += G;                                                                                            \
-                    more = vb_next < total;                                                                                  \
-                    if (more) PRODUCER_SET_TILE(vb_next);                                                                    \
-                }                                                                                                            \
-            }                                                                                                                \
-        }                                                                                                                    \
-    } while (0)
-#define PRODUCER_FETCH()                                                                                                     \
-    do {                                                                                                                     \
-        PRODUCER_BEGIN();                                                                                                    \
-        _Pragma("unroll") for (int q = 0; q < 16; ++q) PRODUCER_DMA(fsrc, q, fdst);                                          \
-        PRODUCER_ADVANCE();                                                                                                  \
-    } while (0)
-        const int8_t* fsrc = g0;
-        char* fdst = smem;
-        PRODUCER_FETCH();  // panel 0
-        bool ahead = false;
-        if (!isB && more) {
-            PRODUCER_FETCH();  // A(1)
-            ahead = true;
+        if constexpr (KBAR && FUSE != 0) {
+            i8_producer_crt<FUSE>((__attribute__((address_space(3))) char*)smem,  // CRT on the producer waves: out of line (see there)
+                                  (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr());
+            return;
         }
-        if (ahead) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+#include "oz2_gemm_i8_producer.inc"
         if constexpr (KBAR) {
         // ONE workgroup barrier per K-step (see the consumer branch).  Without per-segment barriers to pace them the producers space
         // their instructions with s_sleep (64 clocks per unit): bursts of LDS-DMA cost (all 16 at once: +7 % kernel time).
@@ -554,11 +737,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
         }
         __builtin_amdgcn_s_barrier();
         }
-#undef PRODUCER_FETCH
-#undef PRODUCER_BEGIN
-#undef PRODUCER_ADVANCE
-#undef PRODUCER_SET_TILE
-#undef PRODUCER_DMA
+#include "oz2_gemm_i8_producer_undef.inc"
         return;
     }
 
@@ -654,8 +833,11 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
             i8_epilogue<EPI>(acc, args, FUSE ? pl : tmap.plane, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane);
 #endif
             }
-            if constexpr (FUSE != 0) i8_crt_tail<OutT>(args, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane);
+            // FUSE: the producer waves accumulate the CRT of this tile during the next one; they read the residue planes one K-step
+            // after the barrier that follows this wait
+            if constexpr (FUSE != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        if constexpr (FUSE != 0) __builtin_amdgcn_s_barrier();  // the last tile's residues are complete: the producers drain
     };
     if (wm == 0) run.template operator()<false>();
     else run.template operator()<true>();
@@ -820,7 +1002,8 @@ bool gemm_i8_crt_fusable(size_t m, size_t n, unsigned N) {
 
 hipError_t launch_gemm_i8_mod_crt(hipStream_t stream, int dtype, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp,
                                   size_t m, size_t n, unsigned N, int8_t* out, size_t ldo, size_t strideO, const int16_t* sftA,
-                                  const int16_t* sftB, const void* alpha, const void* beta, bool scalars_on_device, void* C, size_t ldc) {
+                                  const int16_t* sftB, const void* alpha, const void* beta, bool scalars_on_device, void* C, size_t ldc,
+                                  int variant) {
     if (dtype != kF64 && dtype != kF32) return hipErrorInvalidValue;
     GemmArgs a{};
     a.A[0] = A;
@@ -845,7 +1028,9 @@ hipError_t launch_gemm_i8_mod_crt(hipStream_t stream, int dtype, const int8_t* A
     c.ldc = ldc;
     fill_crt_tables(c, dtype, kINT8, N);
     fill_crt_scalars(c, dtype, alpha, beta, scalars_on_device);
-    const bool kbar = a.kp <= OZ2_KBAR_MAX_KP;
+    // variant 1: CRT on the producer waves beside the next tile's MFMAs (K-step-barrier schedule at every k); variant 2: CRT tail on
+    // the consumer waves after each tile (ping-pong schedule; kept as the measured baseline of DESIGN.md 3.4)
+    const bool kbar = variant != 2;
     if (dtype == kF64) return kbar ? launch_sched<EPI_MOD, true, 1>(stream, a, c) : launch_sched<EPI_MOD, false, 1>(stream, a, c);
     return kbar ? launch_sched<EPI_MOD, true, 2>(stream, a, c) : launch_sched<EPI_MOD, false, 2>(stream, a, c);
 }

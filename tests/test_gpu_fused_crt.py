@@ -15,9 +15,10 @@ def rand(shape, dtype, rng, phi=1.0):
     return x.astype(dtype)
 
 
-@pytest.fixture
-def fused(monkeypatch):
-    monkeypatch.setenv("GEMMUL8_FUSED_CRT", "1")   # read by gemmul8_gemm on every call: fused whenever it is legal
+@pytest.fixture(params=["1", "2"], ids=["producer-crt", "consumer-tail"])
+def fused(monkeypatch, request):
+    # read by gemmul8_gemm on every call: fused whenever it is legal; 1 = CRT on the producer waves, 2 = CRT tail on the consumer waves
+    monkeypatch.setenv("GEMMUL8_FUSED_CRT", request.param)
 
 
 @pytest.mark.parametrize("dtype,N", [(np.float64, 2), (np.float64, 6), (np.float64, 7), (np.float64, 14), (np.float64, 16), (np.float64, 20),
@@ -101,11 +102,12 @@ def test_fused_equals_two_launch_path(monkeypatch, m, n, k, N, dtype):
     rng = np.random.default_rng(m + k)
     A, B, C0 = rand((m, k), dtype, rng), rand((k, n), dtype, rng), rand((m, n), dtype, rng)
     out = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):
         monkeypatch.setenv("GEMMUL8_FUSED_CRT", mode)
         out[mode] = gu.hip_gemm(A, B, N, alpha=-1.5, beta=0.5, C0=C0, want_intermediates=True)
-    assert np.array_equal(out["0"][1]["C_mid"], out["1"][1]["C_mid"])
-    assert gu.bits_equal(out["0"][0], out["1"][0])
+    for mode in ("1", "2"):
+        assert np.array_equal(out["0"][1]["C_mid"], out[mode][1]["C_mid"])
+        assert gu.bits_equal(out["0"][0], out[mode][0]), mode
     ref = A.astype(np.float64) @ B.astype(np.float64)
     ref = -1.5 * ref + 0.5 * C0
     err = np.max(np.abs(out["1"][0] - ref)) / np.max(np.abs(ref))
