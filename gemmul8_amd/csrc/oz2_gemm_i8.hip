@@ -235,6 +235,9 @@ __device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmAr
 // The CRT block is read from the kernel-argument segment through a pointer the compiler cannot see through: taken by value it
 // hoists the 60 table doubles into SGPRs at kernel entry and keeps them (spilled to VGPR lanes) across the K loop, which pushed
 // accumulator spills INTO the MFMA loop.
+#ifndef OZ2_PCRT_ABL
+#define OZ2_PCRT_ABL 0  // timing ablations of the producer-wave CRT (wrong results): 1 no CRT work at all (order + schedule only), 2 no residue re-reads, 4 no C stores
+#endif
 #ifndef OZ2_TAIL_ABL
 #define OZ2_TAIL_ABL 0  // timing ablations of the CRT tail (wrong results): 1 no residue re-reads, 2 no C stores, 4 no CRT chains, 8 no tail
 #endif
@@ -463,7 +466,9 @@ __device__ __attribute__((noinline)) void i8_producer_crt(__attribute__((address
     do {                                                                                                                     \
         asm volatile("" : "+s"(cp));                                                                                         \
         if (sval) {                                                                                                          \
-            if (vrS == 4) {                                                                                                  \
+            if (OZ2_PCRT_ABL & 4) {                                                                                          \
+                _Pragma("unroll") for (int x = 0; x < 4; ++x) asm volatile("" ::"v"(outv[x]));                               \
+            } else if (vrS == 4) {                                                                                                  \
                 typedef U VecU __attribute__((ext_vector_type(16 / sizeof(U))));                                             \
                 constexpr int PER = 16 / (int)sizeof(U);                                                                     \
                 _Pragma("unroll") for (int v = 0; v < 4 / PER; ++v) {                                                        \
@@ -486,7 +491,8 @@ __device__ __attribute__((noinline)) void i8_producer_crt(__attribute__((address
                 const unsigned vo_ = (unsigned)lane * 4u;                                                                    \
                 _Pragma("unroll") for (unsigned t = 0; t < 20; ++t) if (t < cN) {                                            \
                     const int8_t* pb_ = uniform(ub_ + (size_t)t * args.strideO);                                             \
-                    asm volatile("global_load_dword %0, %1, %2 sc0" : "+v"(rvN[t]) : "v"(vo_), "s"(pb_) : "memory");         \
+                    if (OZ2_PCRT_ABL & 2) rvN[t] = vo_ * 2654435761u + t;                                                     \
+                    else asm volatile("global_load_dword %0, %1, %2 sc0" : "+v"(rvN[t]) : "v"(vo_), "s"(pb_) : "memory");    \
                 }                                                                                                            \
                 const int8_t* sp_ = uniform((const int8_t*)(c.sftA + i0_));                                                  \
                 const unsigned so_ = (unsigned)lane * 8u;                                                                    \
@@ -592,6 +598,35 @@ __device__ __attribute__((noinline)) void i8_producer_crt(__attribute__((address
         for (int vb = blockIdx.x; vb < total; vb += G) {
             for (int kt = 0; kt < S; ++kt) {
                 const bool issued = more;
+                // K-steps without CRT work (most of them at large k: the CRT of a tile takes 64 + 2 of its planes * KT K-steps) run the
+                // compact loop body of the plain kernel: the CRT body is ~50 KiB of straight-line code, and walking through it every
+                // K-step evicted the consumers' MFMA loop from the instruction cache the CU pair shares (+10 % kernel time at every k)
+                if ((OZ2_PCRT_ABL & 1) || !(cval || sval || (c_vb < total && g >= ready_at))) {
+                    if (issued) {
+                        PRODUCER_BEGIN();
+                        if (isB) {
+#pragma unroll
+                            for (int gq = 0; gq < 4; ++gq) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) PRODUCER_DMA(fsrc, gq * 4 + q, fdst);
+                                __builtin_amdgcn_s_sleep(OZ2_SLEEP_B);
+                            }
+                        } else {
+#pragma unroll
+                            for (int gq = 0; gq < 8; ++gq) {
+#pragma unroll
+                                for (int q = 0; q < 2; ++q) PRODUCER_DMA(fsrc, gq * 2 + q, fdst);
+                                __builtin_amdgcn_s_sleep(OZ2_SLEEP_A);
+                            }
+                        }
+                        PRODUCER_ADVANCE();
+                    }
+                    if (!isB && issued) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    ++g;
+                    continue;
+                }
                 PCRT_MEM_SLOT();
                 if (issued) PRODUCER_BEGIN();
 #pragma unroll
@@ -625,7 +660,7 @@ __device__ __attribute__((noinline)) void i8_producer_crt(__attribute__((address
         // the consumers finish the last tile's epilogue, wait for their stores and meet the producers here; then drain the pipeline
         __builtin_amdgcn_s_barrier();
         g = 0x3fffffff;
-        while (c_vb < total || cval || sval) {
+        while (!(OZ2_PCRT_ABL & 1) && (c_vb < total || cval || sval)) {
             PCRT_MEM_SLOT();
             if (cval) {
 #pragma unroll
