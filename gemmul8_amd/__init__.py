@@ -100,6 +100,14 @@ def lib():
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.gemmul8_fused_crt_selected.restype = C.c_int
     L.gemmul8_fused_crt_selected.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_uint]
+    L.gemmul8_work_size_batched.restype = C.c_size_t
+    L.gemmul8_work_size_batched.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.c_size_t]
+    L.gemmul8_batched_item_bytes.restype = C.c_size_t
+    L.gemmul8_batched_item_bytes.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint]
+    L.gemmul8_gemm_batched.restype = C.c_int
+    L.gemmul8_gemm_batched.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
+                                       C.c_void_p, C.c_size_t, C.c_longlong, C.c_void_p, C.c_size_t, C.c_longlong, C.c_void_p,
+                                       C.c_void_p, C.c_size_t, C.c_longlong, C.c_size_t, C.c_uint, C.c_int, C.c_void_p]
     _lib = L
     return L
 

@@ -35,7 +35,8 @@ __global__ void __launch_bounds__(256) crt_kernel(const CrtArgs a) {
     struct alignas(sizeof(MID) * NV) Vec {
         MID v[NV];
     };
-    const MID* base = (const MID*)a.Cmid + (col * a.ld_mid + i0) * COMPS;
+    const size_t zw = blockIdx.z * a.bw;  // batched launch: item blockIdx.z
+    const MID* base = (const MID*)((const char*)a.Cmid + zw) + (col * a.ld_mid + i0) * COMPS;
     Vec c[20];
 #pragma unroll
     for (unsigned t = 0; t < 20; ++t)
@@ -78,8 +79,9 @@ __global__ void __launch_bounds__(256) crt_kernel(const CrtArgs a) {
         }
         mode = 0;
     }
-    const int sB = (int)a.sftB[col];
-    U* Cc = (U*)a.C + (col * a.ldc) * COMPS;
+    const int16_t* sftA_z = (const int16_t*)((const char*)a.sftA + zw);
+    const int sB = (int)((const int16_t*)((const char*)a.sftB + zw))[col];
+    U* Cc = (U*)((char*)a.C + blockIdx.z * a.bc) + (col * a.ldc) * COMPS;
     const bool full = i0 + ROWS <= a.m;  // all ROWS rows exist: the old and new C values move as one vector per thread
     const bool reads_c = mode == 0 || mode == 2 || mode == 4;
     U oldc[NV], outv[NV];
@@ -97,7 +99,7 @@ __global__ void __launch_bounds__(256) crt_kernel(const CrtArgs a) {
 #pragma unroll
     for (int e = 0; e < ROWS; ++e) {
         const size_t row = i0 + e;
-        const int sft = (row < a.m ? (int)a.sftA[row] : 0) + sB;
+        const int sft = (row < a.m ? (int)sftA_z[row] : 0) + sB;
         if constexpr (!CPLX) {
             const U AB = scalb<U>((U)crt_reduce(a, Sh[e], Sl[e]), sft);
             switch (mode) {
@@ -352,10 +354,12 @@ hipError_t launch_crt(hipStream_t stream, int dtype, int backend, unsigned N, si
     a.ldc = ldc;
     fill_crt_tables(a, dtype, backend, N);
     fill_crt_scalars(a, dtype, alpha, beta, scalars_on_device);
+    a.bw = g_batch.ws;
+    a.bc = g_batch.sc;
     const bool cplx = is_complex(dtype), i8 = backend == kINT8;
     const size_t rows_per_thread = 8 / ((cplx ? 2 : 1) * (i8 ? 1 : 2));
     const size_t threads = ((m + rows_per_thread - 1) / rows_per_thread) * n;
-    dim3 grid((unsigned)((threads + 255) / 256));
+    dim3 grid((unsigned)((threads + 255) / 256), 1, g_batch.batch);
 #define OZ2_CRT(U, CP, MID) hipLaunchKernelGGL((crt_kernel<U, CP, MID>), grid, dim3(256), 0, stream, a)
     if (i8) {
         switch (dtype) {

@@ -23,6 +23,7 @@ struct CrtArgs {
     const void* beta_dev;
     double Phi, Plo, invP;
     double q1[20], qh[20], ql[20];
+    size_t bw, bc;  // batched launch (crt_kernel, gridDim.z items): bytes between the items' workspaces / between their C matrices
 };
 
 // host side (oz2_crt.hip)

@@ -167,10 +167,10 @@ int gemmul8_scale_bounds(void* stream_, int dtype, int backend, int op_A, int op
     OZ2_HIP(launch_zero(stream, rowmax, 4 * (L->mp + np) + 8 * std::max(L->mp, np)));
     bool amax_zero = true;
     if (!skipA) {
-        OZ2_HIP(launch_extract(stream, dtype, backend, kmajA, conjA, m, k, A, lda, (int8_t*)L->A_bound, bstrideA, L->kp, L->sftA, amax, amax_zero));
+        OZ2_HIP(launch_extract(stream, dtype, backend, kmajA, conjA, m, k, A, lda, (int8_t*)L->A_bound, bstrideA, L->kp, L->sftA, amax, amax_zero, g_batch.sa));
         if (!kmajA) amax_zero = false;
     }
-    if (!skipB) OZ2_HIP(launch_extract(stream, dtype, backend, kmajB, conjB, n, k, B, ldb, (int8_t*)L->B_bound, bstrideB, L->kp, L->sftB, amax, amax_zero));
+    if (!skipB) OZ2_HIP(launch_extract(stream, dtype, backend, kmajB, conjB, n, k, B, ldb, (int8_t*)L->B_bound, bstrideB, L->kp, L->sftB, amax, amax_zero, g_batch.sb));
     if (col_end > col_begin) {
         const int8_t* Ab = (const int8_t*)L->A_bound;
         const int8_t* Bb = (const int8_t*)L->B_bound + col_begin * L->kp;
@@ -221,8 +221,8 @@ int gemmul8_scale_finish(void* stream_, int dtype, int backend, int op_A, int op
     const bool kmajA = op_A != 0, kmajB = op_B == 0;
     const bool conjA = cplx && op_A == 2, conjB = cplx && op_B == 2;
     if (fastmode) {
-        if (!skipA) OZ2_HIP(launch_fast_shift(stream, dtype, backend, N, kmajA, m, k, A, lda, L->sftA));
-        if (!skipB) OZ2_HIP(launch_fast_shift(stream, dtype, backend, N, kmajB, n, k, B, ldb, L->sftB));
+        if (!skipA) OZ2_HIP(launch_fast_shift(stream, dtype, backend, N, kmajA, m, k, A, lda, L->sftA, g_batch.sa));
+        if (!skipB) OZ2_HIP(launch_fast_shift(stream, dtype, backend, N, kmajB, n, k, B, ldb, L->sftB, g_batch.sb));
     } else {
         int *rowmax, *colmax;
         void* amax;
@@ -232,10 +232,10 @@ int gemmul8_scale_finish(void* stream_, int dtype, int backend, int op_A, int op
     }
     if (!skipA)
         OZ2_HIP(launch_quantise(stream, dtype, backend, N, (int)t_begin, (int)t_end, kmajA, conjA, m, k, A, lda, L->sftA, (int8_t*)L->A_lo,
-                                L->sizeA, L->part_strideA, L->kp));
+                                L->sizeA, L->part_strideA, L->kp, g_batch.sa));
     if (!skipB)
         OZ2_HIP(launch_quantise(stream, dtype, backend, N, (int)t_begin, (int)t_end, kmajB, conjB, n, k, B, ldb, L->sftB, (int8_t*)L->B_lo,
-                                L->sizeB, L->part_strideB, L->kp));
+                                L->sizeB, L->part_strideB, L->kp, g_batch.sb));
     return GEMMUL8_OK;
 }
 
@@ -436,6 +436,56 @@ int gemmul8_gemm(void* stream_, int dtype, int backend, int op_A, int op_B, size
         timers_ns[2] = 0.0;
         OZ2_HIP(hipEventElapsedTime(&ms, T->ev[2], T->ev[3]));
         timers_ns[3] = ms * 1e6;
+    }
+    return GEMMUL8_OK;
+}
+
+// ---- strided batch as ONE set of launches (no counterpart in the reference; hipblas{S,D,C,Z}gemmStridedBatched in the hook).
+// The items' workspaces are consecutive blocks of gemmul8_batched_item_bytes; every kernel of the pipeline takes the item from
+// gridDim.z (the persistent GEMM kernels fold the items into their plane sequence), so that a batch of small matrices fills the
+// chip and costs ten launches instead of ten per item.  Results are bit-identical to per-item gemmul8_gemm calls.
+size_t gemmul8_batched_item_bytes(int is_complex, int backend, size_t m, size_t n, size_t k, unsigned N) {
+    return padding256(gemmul8_work_size(is_complex, backend, m, n, k, N, 0, 0, nullptr, nullptr));
+}
+size_t gemmul8_work_size_batched(int is_complex, int backend, size_t m, size_t n, size_t k, unsigned N, size_t batch) {
+    return gemmul8_batched_item_bytes(is_complex, backend, m, n, k, N) * batch + 256;
+}
+
+int gemmul8_gemm_batched(void* stream_, int dtype, int backend, int op_A, int op_B, size_t m, size_t n, size_t k, const void* alpha,
+                         const void* A, size_t lda, long long strideA, const void* B, size_t ldb, long long strideB, const void* beta,
+                         void* C, size_t ldc, long long strideC, size_t batch, unsigned N, int fastmode, void* work) {
+    if (dtype < 0 || dtype > 3 || backend < 0 || backend > 1) return GEMMUL8_E_ARG;
+    if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
+    if (!alpha || !beta || !A || !B || !C || !work) return GEMMUL8_E_ARG;
+    if (k > (size_t(1) << 17)) return GEMMUL8_E_ARG;
+    if (backend != kINT8) return GEMMUL8_E_UNSUPPORTED;  // the FP8 kernels take one item at a time
+    if (m == 0 || n == 0 || k == 0 || batch == 0) return GEMMUL8_OK;
+    const size_t esz = (is_f32(dtype) ? 4 : 8) * (is_complex(dtype) ? 2 : 1);
+    const size_t W = gemmul8_batched_item_bytes(is_complex(dtype), backend, m, n, k, N);
+    struct Guard {
+        ~Guard() { g_batch = BatchCtx{}; }
+    } guard;
+    char* w0 = align256(work);
+    for (size_t b0 = 0; b0 < batch; b0 += 65535) {  // gridDim.z limit
+        const size_t nb = std::min<size_t>(65535, batch - b0);
+        const char* Ab = (const char*)A + (long long)b0 * strideA * (long long)esz;
+        const char* Bb = (const char*)B + (long long)b0 * strideB * (long long)esz;
+        char* Cb = (char*)C + (long long)b0 * strideC * (long long)esz;
+        char* wb = w0 + b0 * W;
+        gemmul8_layout L;
+        int rc = gemmul8_get_layout(dtype, backend, m, n, k, N, wb, nullptr, nullptr, 0, 0, &L);
+        if (rc) return rc;
+        g_batch.batch = (unsigned)nb;
+        g_batch.ws = W;
+        g_batch.sa = (size_t)(strideA * (long long)esz);  // negative strides wrap: pointer arithmetic is modular
+        g_batch.sb = (size_t)(strideB * (long long)esz);
+        g_batch.sc = (size_t)(strideC * (long long)esz);
+        rc = gemmul8_scale(stream_, dtype, backend, op_A, op_B, m, n, k, Ab, lda, Bb, ldb, N, fastmode, 0, N, &L, 0, 0);
+        if (rc) return rc;
+        rc = gemmul8_lowprec_gemm(stream_, dtype, backend, m, n, k, N, 0, N, &L);
+        if (rc) return rc;
+        rc = gemmul8_crt(stream_, dtype, backend, N, m, n, L.C_mid, L.mp, L.sizeC, L.sftA, L.sftB, alpha, beta, Cb, ldc);
+        if (rc) return rc;
     }
     return GEMMUL8_OK;
 }

@@ -71,6 +71,8 @@ struct GemmArgs {
     int* colmax;
     int total_tiles;       // planes * tiles_m * tiles_n (tile-stationary order, FUSE != 0: tiles_m * tiles_n)
     int planes;            // FUSE != 0: residue planes every workgroup runs through per output tile
+    int ppi;               // planes per batch item (plane p = item p / ppi, modulus-relative plane p % ppi); = all planes for one GEMM
+    size_t bstride;        // bytes between the workspaces of consecutive batch items (every pointer above lives in the workspace)
     int moduli[20];
     int pinv32[20];
 };
@@ -88,6 +90,16 @@ struct GemmArgs {
 #ifndef OZ2_ABL_EPI
 #define OZ2_ABL_EPI 0  // 1: no stores, 2: every plane takes the p = 256 path (timing ablations only)
 #endif
+// plane p of a (batched) launch: byte offset of its item's workspace and its plane index inside the item
+struct PlaneRef {
+    size_t boff;
+    int tt;
+};
+template <typename Args> __device__ __forceinline__ PlaneRef plane_ref(const Args& args, int plane) {
+    const int p = __builtin_amdgcn_readfirstlane(plane);
+    const int b = p / args.ppi;
+    return {(size_t)b * args.bstride, p - b * args.ppi};
+}
 enum { RED_GENERIC = 0, RED_ODD = 1, RED_256 = 2 };
 // RED selects how an accumulator is reduced (uniform per plane): RED_256: p = 256, the symmetric residue IS the low byte;
 // RED_ODD: odd p, ONE exact FP64 quotient step for any int32 accumulator (v_cvt_f64_i32, v_mul_f64, v_rndne_f64, v_fma_f64,
@@ -96,10 +108,10 @@ enum { RED_GENERIC = 0, RED_ODD = 1, RED_256 = 2 };
 // v_mad_i32_i24 -- three instructions -- measured 10 % SLOWER at k = 1024: the dependent FP64 chains no longer overlap.)
 // RED_GENERIC: 32-bit multiply-high (even p other than 256: no INT8 modulus, kept for completeness).
 template <int EPI, int RED>
-__device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const GemmArgs& args, int plane, int i0, int j0, int lane) {
+__device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const GemmArgs& args, PlaneRef pl, int i0, int j0, int lane) {
     const int c16 = lane & 15;
     const int q = lane >> 4;
-    const int t = args.t_begin + plane;
+    const int t = args.t_begin + pl.tt;
     const int p = args.moduli[t];
     const int pinv = args.pinv32[t];
     const float invp = 1.0f / (float)p;
@@ -118,7 +130,7 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
     // j0 + 16 tj + c16: one 64-bit element offset per lane for the whole block, the (tg, tj) sub-blocks add 64 tg and 16 tj * ldo --
     // no per-store multiplies (v_mul_lo_u32 / v_mad_u64_u32 are quarter rate)
     const size_t e00 = (size_t)(j0 + c16) * args.ldo + i0 + q * 16;
-    const size_t po = (size_t)__builtin_amdgcn_readfirstlane(plane) * args.strideO, pr = (size_t)__builtin_amdgcn_readfirstlane(plane) * args.strideR;  // wave-uniform: scalar multiplies
+    const size_t po = pl.boff + (size_t)pl.tt * args.strideO, pr = pl.boff + (size_t)pl.tt * args.strideR;  // wave-uniform: scalar multiplies
     const size_t ejs = (size_t)16 * args.ldo;
 #pragma unroll
     for (int tj = 0; tj < 4; ++tj) {
@@ -176,16 +188,18 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
 }
 
 template <int EPI>
-__device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmArgs& args, int plane, int i0, int j0, int lane) {
+__device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmArgs& args, PlaneRef pl, int i0, int j0, int lane) {
     const int c16 = lane & 15;
     const int q = lane >> 4;
 
     if constexpr (EPI == EPI_MOD || EPI == EPI_CPLX) {
-        const int p = args.moduli[args.t_begin + plane];
-        if (p == 256 || OZ2_ABL_EPI == 2) i8_epilogue_mod<EPI, RED_256>(acc, args, plane, i0, j0, lane);
-        else if (p & 1) i8_epilogue_mod<EPI, RED_ODD>(acc, args, plane, i0, j0, lane);
-        else i8_epilogue_mod<EPI, RED_GENERIC>(acc, args, plane, i0, j0, lane);
+        const int p = args.moduli[args.t_begin + pl.tt];
+        if (p == 256 || OZ2_ABL_EPI == 2) i8_epilogue_mod<EPI, RED_256>(acc, args, pl, i0, j0, lane);
+        else if (p & 1) i8_epilogue_mod<EPI, RED_ODD>(acc, args, pl, i0, j0, lane);
+        else i8_epilogue_mod<EPI, RED_GENERIC>(acc, args, pl, i0, j0, lane);
     } else {
+        int* const rowmax_ = (int*)((char*)args.rowmax + pl.boff);
+        int* const colmax_ = (int*)((char*)args.colmax + pl.boff);
         // column max over this lane's 32 rows (masked to valid rows), then across the four lane quads
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
@@ -203,7 +217,7 @@ __device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmAr
             other = __shfl_xor(cm, 32);
             cm = other > cm ? other : cm;
             const int col = j0 + tj * 16 + c16;
-            if (q == 0 && col < args.n && cm > 0) atomicMax(args.colmax + col, cm);
+            if (q == 0 && col < args.n && cm > 0) atomicMax(colmax_ + col, cm);
         }
         // row max across the 16 lanes (columns) of each quad, one 16-row tile row at a time
 #pragma unroll
@@ -220,7 +234,7 @@ __device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmAr
                 }
                 w[r] = v;
             }
-            tile_rowmax_atomic16(w, args.rowmax, i0 + ti * 16, args.m, lane);
+            tile_rowmax_atomic16(w, rowmax_, i0 + ti * 16, args.m, lane);
         }
     }
 }
@@ -865,7 +879,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #pragma unroll
                 for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-            i8_epilogue<EPI>(acc, args, FUSE ? pl : tmap.plane, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane);
+            i8_epilogue<EPI>(acc, args, FUSE ? PlaneRef{0, pl} : plane_ref(args, tmap.plane), tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane);
 #endif
             }
             // FUSE: the producer waves accumulate the CRT of this tile during the next one; they read the residue planes one K-step
@@ -941,7 +955,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-        i8_epilogue<EPI>(acc, args, FUSE ? pl : tmap.plane, tmap.tm * BM + wm * 128, tmap.tn * BN + wn * 64, lane);
+        i8_epilogue<EPI>(acc, args, FUSE ? PlaneRef{0, pl} : plane_ref(args, tmap.plane), tmap.tm * BM + wm * 128, tmap.tn * BN + wn * 64, lane);
 #endif
         }
         if constexpr (FUSE != 0) i8_crt_tail<OutT>(args, tmap.tm * BM + wm * 128, tmap.tn * BN + wn * 64, lane);
@@ -1002,6 +1016,10 @@ static hipError_t launch_sched(hipStream_t stream, GemmArgs& a, const std::condi
 // other half's first K-steps -- overlap better) and 2.4 % slower at k = 8192, where the board is power-bound and removing stalls
 // buys nothing while the s_sleep-paced LDS-DMA is a little less smooth than the barrier-paced one.
 template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int planes) {
+    // batched call: the items' planes are one long plane sequence (item-major), the persistent tile loop runs over all of them
+    a.ppi = planes;
+    a.bstride = g_batch.ws;
+    planes *= (int)g_batch.batch;
     a.total_tiles = planes * a.tiles_m * a.tiles_n;
     if (a.total_tiles <= 0) return hipSuccess;
     if (a.kp * a.nseg <= OZ2_KBAR_MAX_KP) return launch_sched<EPI, true>(stream, a);
@@ -1052,6 +1070,7 @@ hipError_t launch_gemm_i8_mod_crt(hipStream_t stream, int dtype, const int8_t* A
     a.strideO = strideO;
     fill_common(a, kp, m, n);
     a.planes = (int)N;
+    a.ppi = (int)N;
     a.total_tiles = a.tiles_m * a.tiles_n;
     if (a.total_tiles <= 0) return hipSuccess;
     CrtArgs c{};

@@ -47,6 +47,8 @@ struct Abi {
     size_t (*work_size)(int, int, size_t, size_t, size_t, unsigned, int, int, size_t*, size_t*) = nullptr;
     int (*gemm)(void*, int, int, int, int, size_t, size_t, size_t, const void*, const void*, size_t, const void*, size_t, const void*, void*,
                 size_t, unsigned, int, void*, void*, void*, int, int, int, int, double*) = nullptr;
+    decltype(&::gemmul8_work_size_batched) work_size_batched = nullptr;
+    decltype(&::gemmul8_gemm_batched) gemm_batched = nullptr;
     decltype(&::gemmul8_comm_rccl_from_env) comm_from_env = nullptr;
     decltype(&::gemmul8_dist_create) dist_create = nullptr;
     decltype(&::gemmul8_dist_gemm) dist_gemm = nullptr;
@@ -82,12 +84,14 @@ const Abi& abi() {
         }
         r.work_size = (decltype(r.work_size))dlsym(h, "gemmul8_work_size");
         r.gemm = (decltype(r.gemm))dlsym(h, "gemmul8_gemm");
+        r.work_size_batched = (decltype(r.work_size_batched))dlsym(h, "gemmul8_work_size_batched");
+        r.gemm_batched = (decltype(r.gemm_batched))dlsym(h, "gemmul8_gemm_batched");
         r.comm_from_env = (decltype(r.comm_from_env))dlsym(h, "gemmul8_comm_rccl_from_env");
         r.dist_create = (decltype(r.dist_create))dlsym(h, "gemmul8_dist_create");
         r.dist_gemm = (decltype(r.dist_gemm))dlsym(h, "gemmul8_dist_gemm");
         r.dist_allgather_c = (decltype(r.dist_allgather_c))dlsym(h, "gemmul8_dist_allgather_c");
         r.dist_destroy = (decltype(r.dist_destroy))dlsym(h, "gemmul8_dist_destroy");
-        if (!r.work_size || !r.gemm || !r.comm_from_env || !r.dist_create || !r.dist_gemm || !r.dist_allgather_c || !r.dist_destroy) {
+        if (!r.work_size || !r.gemm || !r.work_size_batched || !r.gemm_batched || !r.comm_from_env || !r.dist_create || !r.dist_gemm || !r.dist_allgather_c || !r.dist_destroy) {
             std::fprintf(stderr, "[GEMMUL8 HOOK] libgemmul8.so lacks the C ABI entry points\n");
             std::abort();
         }
@@ -98,6 +102,8 @@ const Abi& abi() {
 }  // namespace
 #define gemmul8_work_size abi().work_size
 #define gemmul8_gemm abi().gemm
+#define gemmul8_work_size_batched abi().work_size_batched
+#define gemmul8_gemm_batched abi().gemm_batched
 #define gemmul8_comm_rccl_from_env abi().comm_from_env
 #define gemmul8_dist_create abi().dist_create
 #define gemmul8_dist_gemm abi().dist_gemm
@@ -616,7 +622,8 @@ hipblasStatus_t hipblasGemmExWithFlags_64(hipblasHandle_t handle, hipblasOperati
 
 // Strided-batched entry points (not hooked by the reference; PyTorch's bmm uses them).  alpha/beta are shared by the batch; element
 // strides are in units of the matrix type.  The items of a batch are independent, and below ~2048^3 one emulated GEMM is ten
-// latency-bound launches that leave most of the chip idle, so the batch is spread over GEMMUL8_BATCH_STREAMS lanes (default 4, 1 =
+// latency-bound launches that leave most of the chip idle.  INT8 backend: one set of launches for the whole batch (below).  Otherwise
+// (FP8 backend, GEMMUL8_BATCH_FUSED=0, GEMMUL8_DIST) the batch is spread over GEMMUL8_BATCH_STREAMS lanes (default 4, 1 =
 // serial loop on the handle's stream): lane 0 is the handle's stream with the handle's buffers, every other lane has its own
 // non-blocking stream and workspace; the lanes fork from the handle's stream with an event and join it again before the call
 // returns, so the call stays stream-ordered for the application (and capturable in a HIP graph after one warm-up call).
@@ -624,6 +631,34 @@ static bool emulate_batch(int dtype, size_t elem, hipblasHandle_t handle, hipbla
                           const void* alpha, const void* A, int lda, long long sa, const void* B, int ldb, long long sb, const void* beta,
                           void* C, int ldc, long long sc, int batch, hipblasStatus_t* status) {
     *status = HIPBLAS_STATUS_SUCCESS;
+    // First choice (INT8 backend, GEMMUL8_BATCH_FUSED != 0): the whole batch as ONE set of launches (gemmul8_gemm_batched: the items in
+    // gridDim.z of every kernel) -- a batch of small matrices then fills the chip and costs ten launches, not ten per item.
+    if (batch > 1 && env_u64("GEMMUL8_BATCH_FUSED", 1) != 0 && dist_kind_from_env() < 0) {
+        const TypeInfo& ti = kTypes[dtype];
+        const unsigned N = (unsigned)env_u64(ti.nmod, 0);
+        if (N < 2u || N > ti.max_moduli) return false;
+        const unsigned long long floor_flops = env_u64("GEMMUL8_MIN_FLOPS", 0);
+        if (floor_flops && 2.0 * (double)m * (double)n * (double)k < (double)floor_flops) return false;
+        const int backend = env_backend("GEMMUL8_BACKEND", 0, false);
+        if (backend == GEMMUL8_INT8 && k <= (1 << 17)) {
+            const bool fastmode = env_one(ti.fast);
+            auto sp = state_of(handle);
+            std::lock_guard<std::mutex> lk(sp->mtx);
+            init_max_workspace();
+            hipblasStatus_t st = HIPBLAS_STATUS_SUCCESS;
+            hipStream_t stream = handle_stream(handle, &st);
+            if (st != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
+            if ((st = order_streams(*sp, stream)) != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
+            const size_t need = gemmul8_work_size_batched(ti.cplx, backend, (size_t)m, (size_t)n, (size_t)k, N, (size_t)batch);
+            if ((st = grow(sp->wC, need, stream, "workC (batched)")) != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
+            sp->last.valid = false;  // the skip-scaling cache describes single calls; the planes are overwritten here
+            const int rc = gemmul8_gemm_batched(stream, dtype, backend, (int)ta, (int)tb, (size_t)m, (size_t)n, (size_t)k, alpha, A, (size_t)lda, sa,
+                                                B, (size_t)ldb, sb, beta, C, (size_t)ldc, sc, (size_t)batch, N, fastmode, sp->wC.ptr);
+            if (rc == 0) return true;
+            if (rc > 0) return *status = HIPBLAS_STATUS_INTERNAL_ERROR, true;
+            // negative: declined (nothing written) -- fall through to the per-item path
+        }
+    }
     auto item = [&](int b, const void** a, const void** bb, void** c) {
         *a = (const char*)A + (size_t)b * sa * elem, *bb = (const char*)B + (size_t)b * sb * elem, *c = (char*)C + (size_t)b * sc * elem;
     };

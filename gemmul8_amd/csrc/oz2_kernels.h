@@ -21,6 +21,16 @@ inline unsigned num_mat(int backend, unsigned N) {
 }
 ModTable make_mod_table(int backend);
 
+// Batched calls (gemmul8_gemm_batched: the items of a strided batch as ONE set of launches).  Every launcher puts the item index in
+// gridDim.z (the persistent GEMM kernels fold it into their tile index); item b works on workspace + b * ws and on operand + b *
+// xstride (a launcher argument, 0 by default).  Set by the batched driver around the phase calls of one host thread.
+struct BatchCtx {
+    unsigned batch = 1;
+    size_t ws = 0;                // bytes between the items' workspaces
+    size_t sa = 0, sb = 0, sc = 0;  // bytes between the items' A, B, C
+};
+inline thread_local BatchCtx g_batch;
+
 // ---- INT8 MFMA GEMM (oz2_gemm_i8.hip)
 hipError_t launch_gemm_i8_mod(hipStream_t stream, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp, size_t m,
                               size_t n, int t_begin, int t_end, int8_t* out, size_t ldo, size_t strideO);
@@ -52,14 +62,15 @@ hipError_t launch_gemm_f8_bound_cplx(hipStream_t stream, int stage, const int8_t
 // (tests/test_gpu_graph.py), and a kernel launch is cheaper on the host than the runtime's memset path
 hipError_t launch_zero(hipStream_t stream, void* p, size_t bytes);
 hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajor, bool conj, size_t rows, size_t k, const void* X,
-                          size_t ld, int8_t* lo, size_t part_stride, size_t kp, int16_t* sft0, void* scratch_amax, bool amax_is_zero = false);
+                          size_t ld, int8_t* lo, size_t part_stride, size_t kp, int16_t* sft0, void* scratch_amax, bool amax_is_zero = false,
+                          size_t xstride = 0);
 hipError_t launch_shift_finalize(hipStream_t stream, int backend, unsigned N, size_t rowsA, const int* maxA, int16_t* sftA, size_t rowsB,
                                  const int* maxB, int16_t* sftB);
 hipError_t launch_fast_shift(hipStream_t stream, int dtype, int backend, unsigned N, bool kmajor, size_t rows, size_t k, const void* X,
-                             size_t ld, int16_t* sft);
+                             size_t ld, int16_t* sft, size_t xstride = 0);
 hipError_t launch_quantise(hipStream_t stream, int dtype, int backend, unsigned N, int t_begin, int t_end, bool kmajor, bool conj,
                            size_t rows, size_t k, const void* X, size_t ld, const int16_t* sft, int8_t* lo, size_t plane_stride,
-                           size_t part_stride, size_t kp);
+                           size_t part_stride, size_t kp, size_t xstride = 0);
 
 // ---- CRT accumulation + inverse scaling (oz2_crt.hip)
 hipError_t launch_crt(hipStream_t stream, int dtype, int backend, unsigned N, size_t m, size_t n, const void* Cmid, size_t ld_mid,

@@ -113,12 +113,18 @@ struct StageArgs {
     int t_begin, t_end;
     int sqrtp[6];
     ModTable mt;
+    size_t bx, bw;        // batched launch (gridDim.z items): bytes between the items' operands X / between their workspaces
 };
+// item blockIdx.z of a batched launch: every workspace pointer moves by bw, the operand by bx (both 0 for a single GEMM).  The offsets
+// are applied at the few points of use: a modified COPY of the argument block lands in scratch memory (the quantise kernels ran 6x
+// slower that way).
+#define OZ2_ZW ((size_t)blockIdx.z * a.bw)
+#define OZ2_ZX ((size_t)blockIdx.z * a.bx)
 
 template <typename T, int MODE>
 __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0, const T (&v)[4], int s) {
     using E = ET<T>;
-    int8_t* out = a.lo + row * a.kp + k0;
+    int8_t* out = a.lo + OZ2_ZW + row * a.kp + k0;
     if constexpr (MODE == MODE_BOUND) {
         if (a.backend == kFP8) {
             // e4m3 round-up of |x|*2^s (< 2^8), computed in the input precision (scaling.hpp:77-82); complex: planes
@@ -275,7 +281,7 @@ __global__ void __launch_bounds__(256) stage_kmajor_kernel(const StageArgs a) {
     using E = ET<T>;
     using U = typename E::U;
     const size_t row = blockIdx.x;
-    const T* x = (const T*)a.X + row * a.ld;
+    const T* x = (const T*)((const char*)a.X + OZ2_ZX) + row * a.ld;
     int s;
     if constexpr (MODE == MODE_BOUND) {
         __shared__ U sm[4];
@@ -303,7 +309,7 @@ __global__ void __launch_bounds__(256) stage_kmajor_kernel(const StageArgs a) {
             am = sm[2] > am ? sm[2] : am;
             am = sm[3] > am ? sm[3] : am;
             s = (a.backend == kINT8 ? 5 : 7) - ilogb0(am);
-            if (threadIdx.x == 0) a.sft0[row] = (int16_t)s;
+            if (threadIdx.x == 0) ((int16_t*)((char*)a.sft0 + OZ2_ZW))[row] = (int16_t)s;
 #pragma unroll
             for (int it = 0; it < NC; ++it) {
                 const size_t k0 = (size_t)threadIdx.x * 4 + (size_t)it * 1024;
@@ -326,9 +332,9 @@ __global__ void __launch_bounds__(256) stage_kmajor_kernel(const StageArgs a) {
         am = sm[2] > am ? sm[2] : am;
         am = sm[3] > am ? sm[3] : am;
         s = (a.backend == kINT8 ? 5 : 7) - ilogb0(am);
-        if (threadIdx.x == 0) a.sft0[row] = (int16_t)s;
+        if (threadIdx.x == 0) ((int16_t*)((char*)a.sft0 + OZ2_ZW))[row] = (int16_t)s;
     } else {
-        s = -(int)a.sft[row];
+        s = -(int)((const int16_t*)((const char*)a.sft + OZ2_ZW))[row];
     }
     for (size_t k0 = (size_t)threadIdx.x * 4; k0 < a.kp; k0 += 1024) {
         T v[4];
@@ -363,7 +369,7 @@ __global__ void __launch_bounds__(256) stage_strided_kernel(const StageArgs a) {
         constexpr int KY = 256 / TR;  // k values fetched per pass
         const int rx = threadIdx.x % TR, ky = threadIdx.x / TR;
         const size_t row = r0 + rx;
-        const T* x = (const T*)a.X + row;
+        const T* x = (const T*)((const char*)a.X + OZ2_ZX) + row;
 #pragma unroll 4
         for (int it = 0; it < TK / KY; ++it) {
             const int kk = ky + KY * it;
@@ -381,13 +387,13 @@ __global__ void __launch_bounds__(256) stage_strided_kernel(const StageArgs a) {
         int s;
         if constexpr (MODE == MODE_BOUND) {
             using UB = typename std::conditional<sizeof(U) == 8, unsigned long long, unsigned>::type;
-            const UB bits = ((const UB*)a.amax)[row];
+            const UB bits = ((const UB*)((const char*)a.amax + OZ2_ZW))[row];
             U am;
             __builtin_memcpy(&am, &bits, sizeof(U));
             s = (a.backend == kINT8 ? 5 : 7) - ilogb0(am);
-            if (kt == 0 && c == 0) a.sft0[row] = (int16_t)s;
+            if (kt == 0 && c == 0) ((int16_t*)((char*)a.sft0 + OZ2_ZW))[row] = (int16_t)s;
         } else {
-            s = -(int)a.sft[row];
+            s = -(int)((const int16_t*)((const char*)a.sft + OZ2_ZW))[row];
         }
         T v[4];
 #pragma unroll
@@ -397,7 +403,9 @@ __global__ void __launch_bounds__(256) stage_strided_kernel(const StageArgs a) {
 }
 
 // per-row amax of a row-strided operand: grid (ceil(rows/64), ksplit), 256 threads = 64 rows x 4 k-lanes
-template <typename T> __global__ void __launch_bounds__(256) amax_strided_kernel(const T* X, size_t ld, size_t rows, size_t k, void* amax) {
+template <typename T> __global__ void __launch_bounds__(256) amax_strided_kernel(const T* X, size_t ld, size_t rows, size_t k, void* amax, size_t bx, size_t bw) {
+    X = (const T*)((const char*)X + blockIdx.z * bx);  // batched launch: item blockIdx.z
+    amax = (char*)amax + blockIdx.z * bw;
     using E = ET<T>;
     using U = typename E::U;
     using UB = typename std::conditional<sizeof(U) == 8, unsigned long long, unsigned>::type;
@@ -430,12 +438,12 @@ template <typename T> __global__ void __launch_bounds__(256) amax_strided_kernel
 
 template <typename T, int MODE> static hipError_t launch_stage(hipStream_t stream, bool kmajor, const StageArgs& a) {
     if (kmajor) {
-        dim3 grid((unsigned)a.rows);
+        dim3 grid((unsigned)a.rows, 1, g_batch.batch);
         hipLaunchKernelGGL((stage_kmajor_kernel<T, MODE>), grid, dim3(256), 0, stream, a);
     } else {
         const size_t blocks = (a.kp / StageTile<T>::TK) * ((a.rows + StageTile<T>::TR - 1) / StageTile<T>::TR);
         if (blocks > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
-        dim3 grid((unsigned)blocks);
+        dim3 grid((unsigned)blocks, 1, g_batch.batch);
         hipLaunchKernelGGL((stage_strided_kernel<T, MODE>), grid, dim3(256), 0, stream, a);
     }
     return hipGetLastError();
@@ -451,7 +459,8 @@ template <int MODE> static hipError_t dispatch_stage(hipStream_t stream, int dty
     return hipErrorInvalidValue;
 }
 
-__global__ void __launch_bounds__(256) zero_words_kernel(unsigned* p, size_t nwords) {
+__global__ void __launch_bounds__(256) zero_words_kernel(unsigned* p, size_t nwords, size_t bw) {
+    p = (unsigned*)((char*)p + blockIdx.z * bw);
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < nwords) p[i] = 0u;
 }
@@ -459,14 +468,17 @@ __global__ void __launch_bounds__(256) zero_words_kernel(unsigned* p, size_t nwo
 hipError_t launch_zero(hipStream_t stream, void* p, size_t bytes) {
     const size_t nwords = bytes / 4;
     if (nwords == 0) return hipSuccess;
-    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, stream, (unsigned*)p, nwords);
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((nwords + 255) / 256), 1, g_batch.batch), dim3(256), 0, stream, (unsigned*)p, nwords, g_batch.ws);
     return hipGetLastError();
 }
 
 hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajor, bool conj, size_t rows, size_t k, const void* X,
-                          size_t ld, int8_t* lo, size_t part_stride, size_t kp, int16_t* sft0, void* scratch_amax, bool amax_is_zero) {
+                          size_t ld, int8_t* lo, size_t part_stride, size_t kp, int16_t* sft0, void* scratch_amax, bool amax_is_zero,
+                          size_t xstride) {
     if (rows == 0) return hipSuccess;
     StageArgs a{};
+    a.bx = xstride;
+    a.bw = g_batch.ws;
     a.X = X;
     a.ld = ld;
     a.rows = rows;
@@ -491,12 +503,12 @@ hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajo
         if (ks < 1) ks = 1;
         if (ks > 65535) ks = 65535;
         const unsigned ksplit = (unsigned)ks;
-        dim3 grid((unsigned)((rows + 63) / 64), ksplit);
+        dim3 grid((unsigned)((rows + 63) / 64), ksplit, g_batch.batch);
         switch (dtype) {
-        case kF32: hipLaunchKernelGGL(amax_strided_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, ld, rows, k, scratch_amax); break;
-        case kF64: hipLaunchKernelGGL(amax_strided_kernel<double>, grid, dim3(256), 0, stream, (const double*)X, ld, rows, k, scratch_amax); break;
-        case kC32: hipLaunchKernelGGL(amax_strided_kernel<float2>, grid, dim3(256), 0, stream, (const float2*)X, ld, rows, k, scratch_amax); break;
-        case kC64: hipLaunchKernelGGL(amax_strided_kernel<double2>, grid, dim3(256), 0, stream, (const double2*)X, ld, rows, k, scratch_amax); break;
+        case kF32: hipLaunchKernelGGL(amax_strided_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, ld, rows, k, scratch_amax, xstride, g_batch.ws); break;
+        case kF64: hipLaunchKernelGGL(amax_strided_kernel<double>, grid, dim3(256), 0, stream, (const double*)X, ld, rows, k, scratch_amax, xstride, g_batch.ws); break;
+        case kC32: hipLaunchKernelGGL(amax_strided_kernel<float2>, grid, dim3(256), 0, stream, (const float2*)X, ld, rows, k, scratch_amax, xstride, g_batch.ws); break;
+        case kC64: hipLaunchKernelGGL(amax_strided_kernel<double2>, grid, dim3(256), 0, stream, (const double2*)X, ld, rows, k, scratch_amax, xstride, g_batch.ws); break;
         }
         e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -506,9 +518,11 @@ hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajo
 
 hipError_t launch_quantise(hipStream_t stream, int dtype, int backend, unsigned N, int t_begin, int t_end, bool kmajor, bool conj,
                            size_t rows, size_t k, const void* X, size_t ld, const int16_t* sft, int8_t* lo, size_t plane_stride,
-                           size_t part_stride, size_t kp) {
+                           size_t part_stride, size_t kp, size_t xstride) {
     if (rows == 0 || t_end <= t_begin) return hipSuccess;
     StageArgs a{};
+    a.bx = xstride;
+    a.bw = g_batch.ws;
     a.X = X;
     a.ld = ld;
     a.rows = rows;
@@ -531,7 +545,12 @@ hipError_t launch_quantise(hipStream_t stream, int dtype, int backend, unsigned 
 // ------------------------------------------------------------------ accurate-mode shift from the bound maxima
 // rows of A (blocks 0 .. blocksA-1) and columns of B (the remaining blocks) in ONE launch; either count may be 0
 __global__ void shift_finalize_kernel(size_t rowsA, const int* maxA, int16_t* sftA, unsigned blocksA, size_t rowsB, const int* maxB,
-                                      int16_t* sftB, float log2P, int float_max) {
+                                      int16_t* sftB, float log2P, int float_max, size_t bw) {
+    {  // batched launch: item blockIdx.z (all four arrays live in the item's workspace)
+        const size_t o = blockIdx.z * bw;
+        maxA = (const int*)((const char*)maxA + o), maxB = (const int*)((const char*)maxB + o);
+        sftA = (int16_t*)((char*)sftA + o), sftB = (int16_t*)((char*)sftB + o);
+    }
     const bool isB = blockIdx.x >= blocksA;
     const size_t r = (size_t)(isB ? blockIdx.x - blocksA : blockIdx.x) * blockDim.x + threadIdx.x;
     if (r >= (isB ? rowsB : rowsA)) return;
@@ -549,8 +568,8 @@ hipError_t launch_shift_finalize(hipStream_t stream, int backend, unsigned N, si
     const unsigned bA = (unsigned)((rowsA + 255) / 256), bB = (unsigned)((rowsB + 255) / 256);
     if (bA + bB == 0) return hipSuccess;
     const float log2P = backend == kINT8 ? GEMMUL8_LOG2P_INT8[N - 2] : GEMMUL8_LOG2P_FP8[N - 2];
-    hipLaunchKernelGGL(shift_finalize_kernel, dim3(bA + bB), dim3(256), 0, stream, rowsA, maxA, sftA, bA, rowsB, maxB, sftB, log2P,
-                       backend == kFP8 ? 1 : 0);
+    hipLaunchKernelGGL(shift_finalize_kernel, dim3(bA + bB, 1, g_batch.batch), dim3(256), 0, stream, rowsA, maxA, sftA, bA, rowsB, maxB, sftB, log2P,
+                       backend == kFP8 ? 1 : 0, g_batch.ws);
     return hipGetLastError();
 }
 
@@ -595,7 +614,9 @@ __device__ __forceinline__ int fast_sft(float amax, float vecnrm, float log2P) {
 }
 
 // K-major: one 256-thread block per row (scaling_fast_real.hpp:142-164)
-template <typename T> __global__ void __launch_bounds__(256) fast_shift_kmajor_kernel(const T* X, size_t ld, size_t k, int16_t* sft, float log2P) {
+template <typename T> __global__ void __launch_bounds__(256) fast_shift_kmajor_kernel(const T* X, size_t ld, size_t k, int16_t* sft, float log2P, size_t bx, size_t bw) {
+    X = (const T*)((const char*)X + blockIdx.z * bx);  // batched launch: item blockIdx.z
+    sft = (int16_t*)((char*)sft + blockIdx.z * bw);
     using E = ET<T>;
     using U = typename E::U;
     __shared__ U samax[32], ssum[32];
@@ -629,7 +650,9 @@ template <typename T> __global__ void __launch_bounds__(256) fast_shift_kmajor_k
 }
 
 // Row-strided: 32 rows x 32 k-lanes per block (scaling_fast_real.hpp:27-49)
-template <typename T> __global__ void __launch_bounds__(1024) fast_shift_strided_kernel(const T* X, size_t ld, size_t rows, size_t k, int16_t* sft, float log2P) {
+template <typename T> __global__ void __launch_bounds__(1024) fast_shift_strided_kernel(const T* X, size_t ld, size_t rows, size_t k, int16_t* sft, float log2P, size_t bx, size_t bw) {
+    X = (const T*)((const char*)X + blockIdx.z * bx);  // batched launch: item blockIdx.z
+    sft = (int16_t*)((char*)sft + blockIdx.z * bw);
     using E = ET<T>;
     using U = typename E::U;
     __shared__ U samax[32][33], ssum[32][33];
@@ -660,24 +683,24 @@ template <typename T> __global__ void __launch_bounds__(1024) fast_shift_strided
 }
 
 hipError_t launch_fast_shift(hipStream_t stream, int dtype, int backend, unsigned N, bool kmajor, size_t rows, size_t k, const void* X,
-                             size_t ld, int16_t* sft) {
+                             size_t ld, int16_t* sft, size_t xstride) {
     if (rows == 0) return hipSuccess;
     const float log2P = backend == kINT8 ? GEMMUL8_LOG2P_INT8[N - 2] : GEMMUL8_LOG2P_FP8[N - 2];
     if (kmajor) {
-        dim3 grid((unsigned)rows);
+        dim3 grid((unsigned)rows, 1, g_batch.batch);
         switch (dtype) {
-        case kF32: hipLaunchKernelGGL(fast_shift_kmajor_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, ld, k, sft, log2P); break;
-        case kF64: hipLaunchKernelGGL(fast_shift_kmajor_kernel<double>, grid, dim3(256), 0, stream, (const double*)X, ld, k, sft, log2P); break;
-        case kC32: hipLaunchKernelGGL(fast_shift_kmajor_kernel<float2>, grid, dim3(256), 0, stream, (const float2*)X, ld, k, sft, log2P); break;
-        case kC64: hipLaunchKernelGGL(fast_shift_kmajor_kernel<double2>, grid, dim3(256), 0, stream, (const double2*)X, ld, k, sft, log2P); break;
+        case kF32: hipLaunchKernelGGL(fast_shift_kmajor_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, ld, k, sft, log2P, xstride, g_batch.ws); break;
+        case kF64: hipLaunchKernelGGL(fast_shift_kmajor_kernel<double>, grid, dim3(256), 0, stream, (const double*)X, ld, k, sft, log2P, xstride, g_batch.ws); break;
+        case kC32: hipLaunchKernelGGL(fast_shift_kmajor_kernel<float2>, grid, dim3(256), 0, stream, (const float2*)X, ld, k, sft, log2P, xstride, g_batch.ws); break;
+        case kC64: hipLaunchKernelGGL(fast_shift_kmajor_kernel<double2>, grid, dim3(256), 0, stream, (const double2*)X, ld, k, sft, log2P, xstride, g_batch.ws); break;
         }
     } else {
-        dim3 grid((unsigned)((rows + 31) / 32));
+        dim3 grid((unsigned)((rows + 31) / 32), 1, g_batch.batch);
         switch (dtype) {
-        case kF32: hipLaunchKernelGGL(fast_shift_strided_kernel<float>, grid, dim3(1024), 0, stream, (const float*)X, ld, rows, k, sft, log2P); break;
-        case kF64: hipLaunchKernelGGL(fast_shift_strided_kernel<double>, grid, dim3(1024), 0, stream, (const double*)X, ld, rows, k, sft, log2P); break;
-        case kC32: hipLaunchKernelGGL(fast_shift_strided_kernel<float2>, grid, dim3(1024), 0, stream, (const float2*)X, ld, rows, k, sft, log2P); break;
-        case kC64: hipLaunchKernelGGL(fast_shift_strided_kernel<double2>, grid, dim3(1024), 0, stream, (const double2*)X, ld, rows, k, sft, log2P); break;
+        case kF32: hipLaunchKernelGGL(fast_shift_strided_kernel<float>, grid, dim3(1024), 0, stream, (const float*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
+        case kF64: hipLaunchKernelGGL(fast_shift_strided_kernel<double>, grid, dim3(1024), 0, stream, (const double*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
+        case kC32: hipLaunchKernelGGL(fast_shift_strided_kernel<float2>, grid, dim3(1024), 0, stream, (const float2*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
+        case kC64: hipLaunchKernelGGL(fast_shift_strided_kernel<double2>, grid, dim3(1024), 0, stream, (const double2*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
         }
     }
     return hipGetLastError();

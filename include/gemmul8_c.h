@@ -123,6 +123,18 @@ GEMMUL8_API int gemmul8_lowprec_gemm_crt(void *stream, int dtype, int backend, s
                              const gemmul8_layout *L, const void *alpha, const void *beta, void *C, size_t ldc);
 GEMMUL8_API int gemmul8_fused_crt_selected(int dtype, int backend, size_t m, size_t n, unsigned num_moduli);
 
+/* A strided batch of GEMMs (same shape, alpha / beta shared; strides in ELEMENTS of the matrix type, as in
+ * hipblas{S,D,C,Z}gemmStridedBatched) as ONE set of launches: every kernel of the pipeline takes the item from gridDim.z, the
+ * persistent GEMM kernels run over the items' residue planes in one launch.  `work` holds gemmul8_work_size_batched bytes (the items'
+ * workspaces are consecutive blocks of gemmul8_batched_item_bytes).  INT8 backend; GEMMUL8_E_UNSUPPORTED for FP8 (call gemmul8_gemm per
+ * item).  Bit-identical to per-item gemmul8_gemm calls.  No counterpart in the reference (it hooks no batched entry point). */
+GEMMUL8_API size_t gemmul8_batched_item_bytes(int is_complex, int backend, size_t m, size_t n, size_t k, unsigned num_moduli);
+GEMMUL8_API size_t gemmul8_work_size_batched(int is_complex, int backend, size_t m, size_t n, size_t k, unsigned num_moduli, size_t batch);
+GEMMUL8_API int gemmul8_gemm_batched(void *stream, int dtype, int backend, int op_A, int op_B, size_t m, size_t n, size_t k,
+                         const void *alpha, const void *A, size_t lda, long long strideA, const void *B, size_t ldb,
+                         long long strideB, const void *beta, void *C, size_t ldc, long long strideC, size_t batch,
+                         unsigned num_moduli, int fastmode, void *work);
+
 /* Multi-GPU exchange variant (A) of the moduli-sharded plan (include/gemmul8_dist.h): the rank's FP64 partial CRT sums over its
  * moduli [t_begin, t_end) -- C_mid points at plane t_begin -- as two double planes (hi: error-free chain, lo: rounded chain;
  * same FMAs and order as gemmul8_crt restricted to those moduli), written in column blocks of col_block columns, block b at

@@ -47,7 +47,13 @@ static void one_thread(int id) {
                         HIPBLAS_COMPUTE_64F, HIPBLAS_GEMM_DEFAULT) == HIPBLAS_STATUS_SUCCESS);
     CHECK(hipblasGemmEx(h, HIPBLAS_OP_N, HIPBLAS_OP_N, 100, 90, 80, &one, A.data(), HIP_R_16F, 100, B.data(), HIP_R_16F, 80, &zero, C.data(), HIP_R_16F, 100,
                         HIPBLAS_COMPUTE_32F, HIPBLAS_GEMM_DEFAULT) == HIPBLAS_STATUS_SUCCESS);  // not an emulated type: native
-    {  // batched: 7 items over the default 4 lanes (own streams and workspaces, fork / join events), then serial with one lane
+    {  // batched: one set of launches (INT8 backend default), then 7 items over the default 4 lanes (own streams and workspaces,
+       // fork / join events), then serial with one lane
+        const long emu_a = mock_emulated_calls();
+        CHECK(hipblasDgemmStridedBatched(h, HIPBLAS_OP_N, HIPBLAS_OP_N, 50, 40, 30, &one, A.data(), 50, 1500, B.data(), 30, 1200, &zero, C.data(), 50, 2000, 7) ==
+              HIPBLAS_STATUS_SUCCESS);
+        CHECK(mock_emulated_calls() >= emu_a + 7);
+        setenv("GEMMUL8_BATCH_FUSED", "0", 1);
         const long emu_b = mock_emulated_calls();
         CHECK(hipblasDgemmStridedBatched(h, HIPBLAS_OP_N, HIPBLAS_OP_N, 50, 40, 30, &one, A.data(), 50, 1500, B.data(), 30, 1200, &zero, C.data(), 50, 2000, 7) ==
               HIPBLAS_STATUS_SUCCESS);
@@ -56,6 +62,7 @@ static void one_thread(int id) {
         CHECK(hipblasDgemmStridedBatched(h, HIPBLAS_OP_N, HIPBLAS_OP_N, 50, 40, 30, &one, A.data(), 50, 1500, B.data(), 30, 1200, &zero, C.data(), 50, 2000, 3) ==
               HIPBLAS_STATUS_SUCCESS);
         unsetenv("GEMMUL8_BATCH_STREAMS");
+        unsetenv("GEMMUL8_BATCH_FUSED");
     }
     // outside the emulator's range (k > 2^17): native, not an error
     std::vector<double> Ak((size_t)4 * ((1 << 17) + 8)), Bk((size_t)((1 << 17) + 8) * 3);

@@ -127,6 +127,20 @@ EXPORT int gemmul8_gemm(void*, int dtype, int backend, int, int, size_t m, size_
     ++g_emulated_calls;
     return GEMMUL8_OK;
 }
+EXPORT size_t gemmul8_work_size_batched(int cplx, int backend, size_t m, size_t n, size_t k, unsigned N, size_t batch) {
+    return pad(gemmul8_work_size(cplx, backend, m, n, k, N, 0, 0, nullptr, nullptr)) * batch + 256;
+}
+EXPORT int gemmul8_gemm_batched(void*, int dtype, int backend, int, int, size_t m, size_t n, size_t k, const void* alpha, const void* A, size_t, long long,
+                                const void* B, size_t, long long, const void* beta, void* C, size_t ldc, long long sc, size_t batch, unsigned N, int, void* work) {
+    if (!alpha || !beta || !A || !B || !C || !work) return GEMMUL8_E_ARG;
+    if (backend != 0) return GEMMUL8_E_UNSUPPORTED;
+    std::memset(work, 0x55, gemmul8_work_size_batched(dtype >= 2, backend, m, n, k, N, batch));  // every byte of the batched workspace
+    const size_t es = dtype == 0 ? 4 : dtype == 3 ? 16 : 8;
+    for (size_t b = 0; b < batch; ++b)
+        for (size_t j = 0; j < n; ++j) std::memset((char*)C + ((long long)b * sc + (long long)(j * ldc)) * (long long)es, 0x44, m * es);
+    g_emulated_calls += (long)batch;
+    return GEMMUL8_OK;
+}
 EXPORT int gemmul8_comm_rccl_from_env(gemmul8_comm**) { return GEMMUL8_E_UNSUPPORTED; }
 EXPORT int gemmul8_dist_create(const gemmul8_comm*, const gemmul8_dist_engine*, int, int, int, int, int, int, size_t, size_t, size_t, unsigned, int,
                                gemmul8_dist_plan**) { return GEMMUL8_E_UNSUPPORTED; }
