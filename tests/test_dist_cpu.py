@@ -89,17 +89,37 @@ def _worker(rank, world, port, plan, N, fast, m, n, k, typ, opA, opB, grid_rows,
         dist.destroy_process_group()
 
 
+def _start_and_reap(procs, timeout):
+    """Start the ranks, wait, and KILL whatever is still alive afterwards: a rank that died (port taken, runtime error) leaves its peer
+    inside a collective, and multiprocessing joins non-daemon children at interpreter exit -- one flaky rendezvous then blocks the
+    whole pytest process until the collective's own timeout (half an hour)."""
+    for p in procs:
+        p.daemon = True
+        p.start()
+    import time
+    deadline = time.time() + timeout
+    for p in procs:
+        p.join(max(0.0, deadline - time.time()))
+        if p.exitcode not in (0, None):   # a rank failed: its peers will never finish
+            break
+    codes = [p.exitcode for p in procs]
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            p.join(10)
+    return codes
+
+
 def _run(world, plan, N, fast, m, n, k, typ="d", opA="N", opB="N", grid_rows=0):
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, plan, N, fast, m, n, k, typ, opA, opB, grid_rows, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
-    return q.get(timeout=10)
+    for attempt in range(2):   # the free port is chosen before the ranks bind it: one retry for the rare rendezvous collision
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, plan, N, fast, m, n, k, typ, opA, opB, grid_rows, q)) for r in range(world)]
+        codes = _start_and_reap(procs, 300)
+        if codes == [0] * len(procs):
+            return q.get(timeout=10)
+    raise AssertionError(f"ranks exited with {codes}")
 
 
 @pytest.mark.parametrize("world,grid_rows", [(2, 0), (4, 0), (4, 4), (3, 0), (8, 0), (2, 1)])
@@ -184,7 +204,11 @@ def test_unique_id_rendezvous_over_tcp():
         p.start()
     for p in procs:
         p.join(120)
-        assert p.exitcode == 0
+    codes = [p.exitcode for p in procs]
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert codes == [0] * len(procs), codes
     got = sorted(q.get(timeout=10) for _ in range(world))
     assert [g_[0] for g_ in got] == list(range(world))
     assert all(g_[1] == 0 and g_[2] == g_[0] and g_[3] == world for g_ in got), [(g_[0], g_[1]) for g_ in got]

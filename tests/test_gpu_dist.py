@@ -63,17 +63,37 @@ def _worker(rank, world, port, plan, grid_rows, N, fast, m, n, k, typ, q):
         dist.destroy_process_group()
 
 
+def _start_and_reap(procs, timeout):
+    """Start the ranks, wait, and KILL whatever is still alive afterwards: a rank that died (port taken, runtime error) leaves its peer
+    inside a collective, and multiprocessing joins non-daemon children at interpreter exit -- one flaky rendezvous then blocks the
+    whole pytest process until the collective's own timeout (half an hour)."""
+    for p in procs:
+        p.daemon = True
+        p.start()
+    import time
+    deadline = time.time() + timeout
+    for p in procs:
+        p.join(max(0.0, deadline - time.time()))
+        if p.exitcode not in (0, None):   # a rank failed: its peers will never finish
+            break
+    codes = [p.exitcode for p in procs]
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            p.join(10)
+    return codes
+
+
 def _run(plan, grid_rows, N, fast, m, n, k, typ="d"):
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, plan, grid_rows, N, fast, m, n, k, typ, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
-    return q.get(timeout=10)
+    for attempt in range(2):   # the free port is chosen before the ranks bind it: one retry for the rare rendezvous collision
+        q = ctx.Queue()
+        port = _port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, plan, grid_rows, N, fast, m, n, k, typ, q)) for r in range(2)]
+        codes = _start_and_reap(procs, 300)
+        if codes == [0] * len(procs):
+            return q.get(timeout=10)
+    raise AssertionError(f"ranks exited with {codes}")
 
 
 @pytest.mark.parametrize("plan,grid_rows", [("blocks", 0), ("blocks", 1), ("moduli", 0)])
@@ -151,9 +171,7 @@ def test_rccl_transport_of_the_library_world1():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_worker, args=(_port(), q))
-    p.start()
-    p.join(300)
-    assert p.exitcode == 0
+    assert _start_and_reap([p], 300) == [0]
     assert q.get(timeout=10)
 
 
