@@ -249,6 +249,10 @@ __device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmAr
 // The CRT block is read from the kernel-argument segment through a pointer the compiler cannot see through: taken by value it
 // hoists the 60 table doubles into SGPRs at kernel entry and keeps them (spilled to VGPR lanes) across the K loop, which pushed
 // accumulator spills INTO the MFMA loop.
+#ifndef OZ2_PRIO_MODE
+#define OZ2_PRIO_MODE 0  // wave priorities (experiment switch): 0 = s_setprio 1 around every MFMA segment (shipped), 1 = none, 2 = the lagging
+                        // half at priority 1 for the whole kernel, no flips, 3 = as 0 with the producer waves at priority 3
+#endif
 #ifndef OZ2_PCRT_ABL
 #define OZ2_PCRT_ABL 0  // timing ablations of the producer-wave CRT (wrong results): 1 no CRT work at all (order + schedule only), 2 no residue re-reads, 4 no C stores
 #endif
@@ -721,6 +725,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
                                   (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr());
             return;
         }
+        if (OZ2_PRIO_MODE == 3) __builtin_amdgcn_s_setprio(3);
 #include "oz2_gemm_i8_producer.inc"
         if constexpr (KBAR) {
         // ONE workgroup barrier per K-step (see the consumer branch).  Without per-segment barriers to pace them the producers space
@@ -798,6 +803,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     // accumulator tiles (128 registers); a K-step (128 bytes) is four segments (K half ks2) x (row half ah) of 16 MFMAs: the B
     // fragments of a K half are loaded in its first segment and kept for the second, the A fragments of 64 rows per segment.
     const int wm = wave >> 2, wn = wave & 3;
+    if (OZ2_PRIO_MODE == 2 && wm == 1) __builtin_amdgcn_s_setprio(1);
     const int r16 = lane & 15;
     const int q = lane >> 4;
     const int sw = (r16 >> 1) & 7;
@@ -839,10 +845,10 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     do {                                                                                                                     \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
-        __builtin_amdgcn_s_setprio(1);                                                                                       \
+        if (OZ2_PRIO_MODE == 0 || OZ2_PRIO_MODE == 3) __builtin_amdgcn_s_setprio(1);                                         \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                          \
             acc[((seg_) & 1) * 4 + i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[((seg_) & 1) * 4 + i][j], 0, 0, 0); \
-        __builtin_amdgcn_s_setprio(0);                                                                                       \
+        if (OZ2_PRIO_MODE == 0 || OZ2_PRIO_MODE == 3) __builtin_amdgcn_s_setprio(0);                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
     } while (0)
 #define OZ2_SET_PANELS()                                                                                                     \
@@ -935,13 +941,13 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_setprio(1);
+                    if (OZ2_PRIO_MODE == 0 || OZ2_PRIO_MODE == 3) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             acc[ah * 4 + i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[ah * 4 + i][j], 0, 0, 0);
-                    __builtin_amdgcn_s_setprio(0);
+                    if (OZ2_PRIO_MODE == 0 || OZ2_PRIO_MODE == 3) __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);

@@ -629,7 +629,7 @@ hipblasStatus_t hipblasGemmExWithFlags_64(hipblasHandle_t handle, hipblasOperati
 // returns, so the call stays stream-ordered for the application (and capturable in a HIP graph after one warm-up call).
 static bool emulate_batch(int dtype, size_t elem, hipblasHandle_t handle, hipblasOperation_t ta, hipblasOperation_t tb, int m, int n, int k,
                           const void* alpha, const void* A, int lda, long long sa, const void* B, int ldb, long long sb, const void* beta,
-                          void* C, int ldc, long long sc, int batch, hipblasStatus_t* status) {
+                          void* C, int ldc, long long sc, int batch, hipblasStatus_t* status, const hipStream_t* explicit_stream = nullptr) {
     *status = HIPBLAS_STATUS_SUCCESS;
     // First choice (INT8 backend, GEMMUL8_BATCH_FUSED != 0): the whole batch as ONE set of launches (gemmul8_gemm_batched: the items in
     // gridDim.z of every kernel) -- a batch of small matrices then fills the chip and costs ten launches, not ten per item.
@@ -646,7 +646,7 @@ static bool emulate_batch(int dtype, size_t elem, hipblasHandle_t handle, hipbla
             std::lock_guard<std::mutex> lk(sp->mtx);
             init_max_workspace();
             hipblasStatus_t st = HIPBLAS_STATUS_SUCCESS;
-            hipStream_t stream = handle_stream(handle, &st);
+            hipStream_t stream = explicit_stream ? *explicit_stream : handle_stream(handle, &st);
             if (st != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
             if ((st = order_streams(*sp, stream)) != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
             const size_t need = gemmul8_work_size_batched(ti.cplx, backend, (size_t)m, (size_t)n, (size_t)k, N, (size_t)batch);
@@ -667,7 +667,7 @@ static bool emulate_batch(int dtype, size_t elem, hipblasHandle_t handle, hipbla
     hipblasStatus_t st;
     // item 0 on the handle's stream decides whether the environment selects emulation for this call at all
     item(0, &Ai, &Bi, &Ci);
-    if (!try_emulate(dtype, handle, ta, tb, m, n, k, alpha, Ai, lda, Bi, ldb, beta, Ci, ldc, &st)) return false;
+    if (!try_emulate(dtype, handle, ta, tb, m, n, k, alpha, Ai, lda, Bi, ldb, beta, Ci, ldc, &st, explicit_stream)) return false;
     if (st != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
     int lanes = (int)env_u64("GEMMUL8_BATCH_STREAMS", 4);
     lanes = std::max(1, std::min({lanes, kMaxBatchLanes, batch}));
@@ -697,7 +697,7 @@ static bool emulate_batch(int dtype, size_t elem, hipblasHandle_t handle, hipbla
         item(b, &Ai, &Bi, &Ci);
         const int l = b % lanes;
         if (l == 0) {
-            const bool done = try_emulate(dtype, handle, ta, tb, m, n, k, alpha, Ai, lda, Bi, ldb, beta, Ci, ldc, &st);
+            const bool done = try_emulate(dtype, handle, ta, tb, m, n, k, alpha, Ai, lda, Bi, ldb, beta, Ci, ldc, &st, explicit_stream);
             if (!done) return *status = HIPBLAS_STATUS_INTERNAL_ERROR, true;
             if (st != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
         } else {
@@ -770,7 +770,7 @@ hipblasStatus_t hipblasGemmStridedBatchedEx(hipblasHandle_t handle, hipblasOpera
 
 // ---- hipblasLtMatmul (not hooked by the reference; PyTorch on ROCm routes most float32 matmuls through hipBLASLt, so without
 // this GEMMUL8_NUM_MOD_S is a no-op for them).  Only the plain case is emulated: D = alpha*op(A)*op(B) + beta*C with A, B, C, D of
-// one type in {float, double, complex float, complex double}, column-major order, no batch, default epilogue, no scale pointers,
+// one type in {float, double, complex float, complex double}, column-major order, single or strided-batched, default epilogue, no scale pointers,
 // host or device scalars; everything else goes to the real routine untouched.  C != D is served in place on D after a copy of C.
 #include <hipblaslt/hipblaslt.h>
 namespace {
@@ -778,6 +778,7 @@ struct LtLayout {
     int32_t type = -1, order = -1, batch = 1;
     uint64_t rows = 0, cols = 0;
     int64_t ld = 0;
+    int64_t stride = 0;  // STRIDED_BATCH_OFFSET, elements
 };
 // hipBLASLt (ROCm 7.2) cannot be asked what a matrix layout holds -- hipblasLtMatrixLayoutGetAttribute answers only the two batch
 // attributes -- so the hook records type / rows / cols / ld / order / batch when a layout is created or modified
@@ -835,7 +836,9 @@ bool lt_try(hipblasLtHandle_t handle, hipblasLtMatmulDesc_t desc, const void* al
     default: return lt_decline("not an S/D/C/Z matrix type");
     }
     if (a.order != HIPBLASLT_ORDER_COL || b.order != HIPBLASLT_ORDER_COL || c.order != HIPBLASLT_ORDER_COL || d.order != HIPBLASLT_ORDER_COL) return lt_decline("not column-major");
-    if (a.batch != 1 || b.batch != 1 || c.batch != 1 || d.batch != 1) return lt_decline("batched");
+    const int nb = d.batch;
+    if (nb < 1 || a.batch != nb || b.batch != nb || c.batch != nb) return lt_decline("batch counts differ between the layouts");
+    if (nb > 1 && d.stride == 0) return lt_decline("batched with overlapping outputs");
     const uint64_t m = d.rows, n = d.cols, k = (ta == HIPBLAS_OP_N) ? a.cols : a.rows;
     if ((ta == HIPBLAS_OP_N ? a.rows : a.cols) != m || (tb == HIPBLAS_OP_N ? b.cols : b.rows) != n || (tb == HIPBLAS_OP_N ? b.rows : b.cols) != k)
         return lt_decline("inconsistent dimensions");
@@ -849,9 +852,15 @@ bool lt_try(hipblasLtHandle_t handle, hipblasLtMatmulDesc_t desc, const void* al
     if (floor_flops && 2.0 * (double)m * (double)n * (double)k < (double)floor_flops) return false;
     if (k > (1u << 17) || (env_backend("GEMMUL8_BACKEND", 0, false) == 1 && k > 65536)) return false;  // outside the emulator's range
     if (haveC && C != D) {  // out-of-place form: bring C into D, then update D in place (beta = 0 never reads it, but the copy is harmless)
-        if (hipMemcpy2DAsync(D, (size_t)d.ld * esz, C, (size_t)c.ld * esz, m * esz, n, hipMemcpyDeviceToDevice, stream) != hipSuccess)
-            return *st = HIPBLAS_STATUS_INTERNAL_ERROR, true;
+        for (int bi = 0; bi < nb; ++bi)
+            if (hipMemcpy2DAsync((char*)D + (long long)bi * d.stride * (long long)esz, (size_t)d.ld * esz,
+                                 (const char*)C + (long long)bi * c.stride * (long long)esz, (size_t)c.ld * esz, m * esz, n,
+                                 hipMemcpyDeviceToDevice, stream) != hipSuccess)
+                return *st = HIPBLAS_STATUS_INTERNAL_ERROR, true;
     }
+    if (nb > 1)  // strided batch (torch.bmm in float32 arrives here): one set of launches, as for hipblas*gemmStridedBatched
+        return emulate_batch(dtype, esz, (hipblasHandle_t)handle, (hipblasOperation_t)ta, (hipblasOperation_t)tb, (int)m, (int)n, (int)k, alpha, A,
+                             (int)a.ld, (long long)a.stride, B, (int)b.ld, (long long)b.stride, beta, D, (int)d.ld, (long long)d.stride, nb, st, &stream);
     return try_emulate(dtype, (hipblasHandle_t)handle, (hipblasOperation_t)ta, (hipblasOperation_t)tb, (int)m, (int)n, (int)k, alpha, A, (int)a.ld, B,
                        (int)b.ld, beta, D, (int)d.ld, st, &stream);
 }
@@ -883,6 +892,7 @@ extern "C" hipblasStatus_t hipblasLtMatrixLayoutSetAttribute(hipblasLtMatrixLayo
             LtLayout& r = it->second;
             switch (attr) {
             case HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT: if (sizeInBytes >= 4) std::memcpy(&r.batch, buf, 4); break;
+            case HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET: if (sizeInBytes >= 8) std::memcpy(&r.stride, buf, 8); break;
             case HIPBLASLT_MATRIX_LAYOUT_TYPE: if (sizeInBytes >= 4) std::memcpy(&r.type, buf, 4); break;
             case HIPBLASLT_MATRIX_LAYOUT_ORDER: if (sizeInBytes >= 4) std::memcpy(&r.order, buf, 4); break;
             case HIPBLASLT_MATRIX_LAYOUT_ROWS: if (sizeInBytes >= 8) std::memcpy(&r.rows, buf, 8); break;

@@ -91,6 +91,26 @@ static void one_thread(int id) {
     const long nat1 = mock_native_calls();
     CHECK(hipblasLtMatmul(lt, (hipblasLtMatmulDesc_t)d, &one, A.data(), (hipblasLtMatrixLayout_t)la, B.data(), (hipblasLtMatrixLayout_t)lb2, &one, C.data(),
                           (hipblasLtMatrixLayout_t)lc, D.data(), (hipblasLtMatrixLayout_t)ld, nullptr, nullptr, 0, nullptr) == HIPBLAS_STATUS_SUCCESS);
+    {  // strided batch through hipblasLt (all four layouts with 3 items): emulated as one set of launches
+        hipblasLtMatrixLayout_t ba, bb, bc, bd;
+        CHECK(hipblasLtMatrixLayoutCreate(&ba, HIP_R_64F, 80, 100, 80) == HIPBLAS_STATUS_SUCCESS);
+        CHECK(hipblasLtMatrixLayoutCreate(&bb, HIP_R_64F, 80, 90, 80) == HIPBLAS_STATUS_SUCCESS);
+        CHECK(hipblasLtMatrixLayoutCreate(&bc, HIP_R_64F, 100, 90, 100) == HIPBLAS_STATUS_SUCCESS);
+        CHECK(hipblasLtMatrixLayoutCreate(&bd, HIP_R_64F, 100, 90, 104) == HIPBLAS_STATUS_SUCCESS);
+        const int32_t three = 3;
+        const int64_t strides[4] = {8000, 7200, 9000, 9360};
+        hipblasLtMatrixLayout_t ls[4] = {ba, bb, bc, bd};
+        for (int i = 0; i < 4; ++i) {
+            CHECK(hipblasLtMatrixLayoutSetAttribute(ls[i], HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &three, sizeof three) == HIPBLAS_STATUS_SUCCESS);
+            CHECK(hipblasLtMatrixLayoutSetAttribute(ls[i], HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &strides[i], sizeof(int64_t)) == HIPBLAS_STATUS_SUCCESS);
+        }
+        std::vector<double> D3(3 * 9360);
+        const long emu1 = mock_emulated_calls();
+        CHECK(hipblasLtMatmul(lt, (hipblasLtMatmulDesc_t)d, &one, A.data(), ba, B.data(), bb, &one, C.data(), bc, D3.data(), bd, nullptr, nullptr, 0,
+                              (hipStream_t)(uintptr_t)(0x2000 + id)) == HIPBLAS_STATUS_SUCCESS);
+        CHECK(mock_emulated_calls() >= emu1 + 3);
+        for (hipblasLtMatrixLayout_t l : ls) CHECK(hipblasLtMatrixLayoutDestroy(l) == HIPBLAS_STATUS_SUCCESS);
+    }
     void* db = mock_lt_desc(HIPBLAS_OP_T, HIPBLAS_OP_N, HIPBLASLT_EPILOGUE_BIAS);
     CHECK(hipblasLtMatmul(lt, (hipblasLtMatmulDesc_t)db, &one, A.data(), (hipblasLtMatrixLayout_t)la, B.data(), (hipblasLtMatrixLayout_t)lb, &one, C.data(),
                           (hipblasLtMatrixLayout_t)lc, D.data(), (hipblasLtMatrixLayout_t)ld, nullptr, nullptr, 0, nullptr) == HIPBLAS_STATUS_SUCCESS);

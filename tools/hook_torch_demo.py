@@ -24,6 +24,17 @@ reff = Af[:64].double() @ Bf.double()
 errf = float(((Cf[:64].double() - reff).abs().max() / reff.abs().max()).item())
 print(f"torch SGEMM {n}^3: sgemm normwise err {errf:.2e}")
 
+# float32 batched: torch.bmm -> hipblasLtMatmul with batched matrix layouts (or hipblasSgemmStridedBatched)
+Xf = torch.rand((5, 640, 512), dtype=torch.float32, device="cuda") - 0.5
+Yf = torch.rand((5, 512, 384), dtype=torch.float32, device="cuda") - 0.5
+Zf = torch.bmm(Xf, Yf)
+torch.cuda.synchronize()
+errbf = 0.0
+for i in range(5):
+    refbf = Xf[i].double() @ Yf[i].double()
+    errbf = max(errbf, float(((Zf[i].double() - refbf).abs().max() / refbf.abs().max()).item()))
+print(f"torch.bmm float32 5 x 640x384x512: batched-f32 normwise err {errbf:.2e}")
+
 # batched: torch.bmm -> hipblasDgemmStridedBatched / hipblasGemmStridedBatchedEx
 nb, b = 1024, 6
 X = torch.rand((b, nb, nb), dtype=torch.float64, device="cuda") - 0.5
