@@ -95,3 +95,15 @@ def test_batched_rejects_fp8_and_is_stream_ordered():
                                       one.ctypes.data, x.data_ptr(), 8, 64, 1, 8, 0, x.data_ptr())
     assert rc == -3
     assert g.lib().gemmul8_work_size_batched(0, g.INT8, 100, 100, 100, 14, 7) == 7 * g.lib().gemmul8_batched_item_bytes(0, g.INT8, 100, 100, 100, 14) + 256
+
+
+def test_python_wrapper_broadcasts():
+    """gemmul8_amd.gemm_batched: B with a batch dimension of 1 is shared by every item (stride 0)."""
+    import gemmul8_amd as g
+    rng = np.random.default_rng(21)
+    A = torch.from_numpy(rand((6, 96, 130), np.float64, rng)).cuda()    # six 130 x 96 matrices
+    B = torch.from_numpy(rand((1, 50, 96), np.float64, rng)).cuda()     # one 96 x 50 matrix
+    Cb, _ = g.gemm_batched(A, B, 14)
+    for b in range(6):
+        Ci, _, _ = g.gemm(A[b], B[0], 14)
+        assert torch.equal(Cb[b].view(torch.uint8), Ci.view(torch.uint8)), b
