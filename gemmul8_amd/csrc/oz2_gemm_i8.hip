@@ -16,7 +16,7 @@
 //
 // Kernel structure (CDNA4), see DESIGN.md 3.1 for the measurements behind each choice:
 //  * PERSISTENT: one workgroup per CU loops over 256x256 output tiles.  12 waves: 8 CONSUMER waves (2(M) x 4(N), wave tile
-//    128x64 = 4x2 v_mfma_i32_32x32x32_i8 accumulators = 128 registers/lane) + 4 PRODUCER waves (one per SIMD) that only
+//    128x64 = 8x4 v_mfma_i32_16x16x64_i8 accumulator tiles = 128 registers/lane) + 4 PRODUCER waves (one per SIMD) that only
 //    issue the LDS-DMA (global_load_lds_dwordx4, SGPR base + one VGPR offset per instruction), so the matrix pipe's feeders
 //    never block on the VMEM queue and spend no VALU cycles on addresses.  168 VGPRs -> 3 waves/SIMD.
 //  * BK = 128 bytes (every DMA row segment is a full 128-B line: the global->LDS path does 127 GB/s/CU with 128-B segments,
@@ -26,10 +26,10 @@
 //  * LDS rows are 128 B; the 16-B chunk index is XOR-swizzled with (row>>1)&7 on the DMA SOURCE address
 //    (the destination must stay lane-linear) and on the ds_read_b128 address: every 16-lane read group hits
 //    16 distinct 16-B bank slots (SQ_LDS_BANK_CONFLICT = 0).
-//  * Ping-pong schedule: each consumer alternates a LOAD segment (6 ds_read_b128) and an MFMA segment
-//    (8 MFMAs, s_setprio 1), one s_barrier after each; the wm=1 half runs one segment behind the wm=0 half
+//  * Ping-pong schedule (k > 4096; K-step-barrier schedule below that, see launch<EPI>): each consumer alternates a LOAD segment
+//    (4-8 ds_read_b128) and an MFMA segment (16 MFMAs, s_setprio 1), four of each per K-step, one s_barrier after each; the wm=1 half runs one segment behind the wm=0 half
 //    so on every SIMD one wave feeds the matrix pipe while its partner reads LDS.  With g counting K-steps across tiles:
-//      slot(wm=0: L_j(g)) = 8g+2j, M_j -> +1; wm=1 one slot later; the producers drain what K-step g+1 needs in slot 8g+7.
+//      slot(wm=0: L_j(g)) = 8g+2j, M_j -> +1 (j = 0..3); wm=1 one slot later; the producers drain what K-step g+1 needs in slot 8g+7.
 //      WAR: the slots refilled during K-step g held panels of K-steps g-1 (-> B(g+1)) and g-2/g-1 (-> A(g+2)), last read in
 //           wm=1's L3(g-1) (slot 8g-1) < the first DMA of K-step g (slot 8g).
 //      RAW: the producers' vmcnt wait + barrier closes slot 8g+7; wm=0's L0(g+1) opens slot 8g+8.
@@ -77,9 +77,8 @@ struct GemmArgs {
     int pinv32[20];
 };
 
-// Epilogues on a wave's 128 x (32*NJ) accumulator block (first row i0, first column j0).  Accumulator map of
-// v_mfma_i32_32x32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); MFMA rows <-> C rows i (A_lo rows),
-// MFMA cols <-> C cols j.
+// Epilogues on a wave's 128 x 64 accumulator block (first row i0, first column j0) = 8 x 4 tiles of v_mfma_i32_16x16x64_i8, whose
+// accumulator map is col = lane & 15, row = 4 * (lane >> 4) + reg; MFMA rows <-> C rows i (A_lo rows), MFMA cols <-> C cols j.
 #ifndef OZ2_DMA_AUX
 #define OZ2_DMA_AUX 0  // cache-policy bits of the LDS-DMA loads (1 = sc0, 2 = nt, 16 = sc1): sc0/sc1 measured neutral, nt 10 % slower
 #endif
