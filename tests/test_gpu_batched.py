@@ -107,3 +107,21 @@ def test_python_wrapper_broadcasts():
     for b in range(6):
         Ci, _, _ = g.gemm(A[b], B[0], 14)
         assert torch.equal(Cb[b].view(torch.uint8), Ci.view(torch.uint8)), b
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_batched_fuzz(seed):
+    """Random shapes / ops / types / modes / batch counts: the one-launch-set path against per-item calls, bitwise."""
+    rng = np.random.default_rng(1000 + seed)
+    dtype = [np.float64, np.float32, np.complex128, np.complex64][seed % 4]
+    N = int(rng.integers(2, 14 if np.dtype(dtype).itemsize in (4, 8) and dtype in (np.float32, np.complex64) else 21))
+    m, n, k = (int(rng.integers(1, 400)) for _ in range(3))
+    batch = int(rng.integers(2, 7))
+    opA, opB = rng.choice(["N", "T"] + (["C"] if np.dtype(dtype).kind == "c" else [])), rng.choice(["N", "T"])
+    fast = bool(rng.integers(0, 2))
+    A = torch.from_numpy(rand((batch,) + ((k, m) if opA == "N" else (m, k)), dtype, rng)).cuda()
+    B = torch.from_numpy(rand((batch,) + ((n, k) if opB == "N" else (k, n)), dtype, rng)).cuda()
+    C0 = torch.from_numpy(rand((batch, n, m), dtype, rng)).cuda()
+    alpha, beta = [(1.0, 0.0), (-1.0, 1.0), (0.75, -0.5)][seed % 3]
+    Cb, Ci = run_batched(A, B, C0, N, fast, str(opA), str(opB), alpha, beta)
+    assert torch.equal(Cb.view(torch.uint8), Ci.view(torch.uint8)), (dtype, N, m, n, k, batch, opA, opB, fast)
