@@ -649,14 +649,28 @@ static bool emulate_batch(int dtype, size_t elem, hipblasHandle_t handle, hipbla
             hipStream_t stream = explicit_stream ? *explicit_stream : handle_stream(handle, &st);
             if (st != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
             if ((st = order_streams(*sp, stream)) != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
-            const size_t need = gemmul8_work_size_batched(ti.cplx, backend, (size_t)m, (size_t)n, (size_t)k, N, (size_t)batch);
-            if ((st = grow(sp->wC, need, stream, "workC (batched)")) != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
-            sp->last.valid = false;  // the skip-scaling cache describes single calls; the planes are overwritten here
-            const int rc = gemmul8_gemm_batched(stream, dtype, backend, (int)ta, (int)tb, (size_t)m, (size_t)n, (size_t)k, alpha, A, (size_t)lda, sa,
-                                                B, (size_t)ldb, sb, beta, C, (size_t)ldc, sc, (size_t)batch, N, fastmode, sp->wC.ptr);
-            if (rc == 0) return true;
-            if (rc > 0) return *status = HIPBLAS_STATUS_INTERNAL_ERROR, true;
-            // negative: declined (nothing written) -- fall through to the per-item path
+            // the items' workspaces are consecutive: bound the buffer (GEMMUL8_BATCH_WORKSPACE_MB, default 4096) and run the batch in
+            // chunks of as many items as fit; if even that cannot be allocated the per-item path below takes over
+            const size_t item = gemmul8_work_size_batched(ti.cplx, backend, (size_t)m, (size_t)n, (size_t)k, N, 1) - 256;
+            const size_t budget = (size_t)env_u64("GEMMUL8_BATCH_WORKSPACE_MB", 4096) << 20;
+            const size_t per_chunk = std::max<size_t>(1, std::min<size_t>((size_t)batch, item ? budget / item : (size_t)batch));
+            if (grow(sp->wC, item * per_chunk + 256, stream, "workC (batched)") == HIPBLAS_STATUS_SUCCESS) {
+                sp->last.valid = false;  // the skip-scaling cache describes single calls; the planes are overwritten here
+                int rc = 0;
+                for (size_t b0 = 0; b0 < (size_t)batch && rc == 0; b0 += per_chunk) {
+                    const size_t nb = std::min(per_chunk, (size_t)batch - b0);
+                    rc = gemmul8_gemm_batched(stream, dtype, backend, (int)ta, (int)tb, (size_t)m, (size_t)n, (size_t)k, alpha,
+                                              (const char*)A + (long long)b0 * sa * (long long)elem, (size_t)lda, sa,
+                                              (const char*)B + (long long)b0 * sb * (long long)elem, (size_t)ldb, sb, beta,
+                                              (char*)C + (long long)b0 * sc * (long long)elem, (size_t)ldc, sc, nb, N, fastmode, sp->wC.ptr);
+                    if (rc < 0 && b0 > 0) rc = 1;  // declined after earlier chunks were written: cannot hand the call to another path
+                }
+                if (rc == 0) return true;
+                if (rc > 0) return *status = HIPBLAS_STATUS_INTERNAL_ERROR, true;
+                // negative on the first chunk: declined (nothing written) -- fall through to the per-item path
+            } else {
+                (void)hipGetLastError();  // allocation failed: clear the sticky error, use the per-item path
+            }
         }
     }
     auto item = [&](int b, const void** a, const void** bb, void** c) {

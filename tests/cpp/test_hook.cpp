@@ -112,9 +112,11 @@ int main() {
                          nullptr, 0, 0, 0, 0, nullptr) == 0);
             hipMemcpy(bref.data() + (size_t)b * m * n, C2, (size_t)m * n * 8, hipMemcpyDeviceToHost);
         }
-        for (int pass = 0; pass < 4; ++pass) {  // 0: one set of launches (gemmul8_gemm_batched), 1-2: stream lanes, 3: serial loop
+        for (int pass = 0; pass < 5; ++pass) {  // 0: one set of launches (gemmul8_gemm_batched), 1-2: stream lanes, 3: serial loop,
+                                                // 4: one launch set per chunk of 2 items (bounded workspace)
             if (pass == 1) setenv("GEMMUL8_BATCH_FUSED", "0", 1);
             if (pass == 3) setenv("GEMMUL8_BATCH_STREAMS", "1", 1);
+            if (pass == 4) unsetenv("GEMMUL8_BATCH_FUSED"), setenv("GEMMUL8_BATCH_WORKSPACE_MB", "80", 1);  // an item needs ~33 MiB
             hipMemset(dC, 0, bC.size() * 8);
             hipDeviceSynchronize();
             CHECK(hipblasDgemmStridedBatched(handle, HIPBLAS_OP_N, HIPBLAS_OP_N, m, n, k, &one, dA, m, (long long)m * k, dB, k, (long long)k * n, &zero,
@@ -129,6 +131,7 @@ int main() {
         }
         unsetenv("GEMMUL8_BATCH_STREAMS");
         unsetenv("GEMMUL8_BATCH_FUSED");
+        unsetenv("GEMMUL8_BATCH_WORKSPACE_MB");
         std::printf("hooked hipblasDgemmStridedBatched (7 items; one launch set, stream lanes, serial) == direct gemmul8_gemm per item (bitwise)\n");
         hipFree(dA), hipFree(dB), hipFree(dC);
     }
