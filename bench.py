@@ -324,7 +324,7 @@ def main():
             tf = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
             if tf and not multi and n == 8192 and N == 14:
                 recs = json.load(open(tf[-1]))
-                rec = recs.get("oz2::gemm_i8_kernel<0, false>") or recs.get("oz2::gemm_i8_kernel<0>")
+                rec = next((v for k_, v in sorted(recs.items()) if k_.startswith("oz2::gemm_i8_kernel<0")), None)  # <EPI_MOD, schedule, ...>
                 if rec:
                     roof["traffic"] = rec["hbm_side_bytes_per_launch"]
                     roof["traffic_source"] = "profiles/" + os.path.basename(tf[-1])
