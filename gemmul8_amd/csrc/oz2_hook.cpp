@@ -865,7 +865,21 @@ bool lt_try(hipblasLtHandle_t handle, hipblasLtMatmulDesc_t desc, const void* al
     const unsigned long long floor_flops = env_u64("GEMMUL8_MIN_FLOPS", 0);
     if (floor_flops && 2.0 * (double)m * (double)n * (double)k < (double)floor_flops) return false;
     if (k > (1u << 17) || (env_backend("GEMMUL8_BACKEND", 0, false) == 1 && k > 65536)) return false;  // outside the emulator's range
-    if (haveC && C != D) {  // out-of-place form: bring C into D, then update D in place (beta = 0 never reads it, but the copy is harmless)
+    // C is not read when the host scalars are beta = 0 and alpha = +-1 (the CRT's "C = +-AB" forms; every other form reads it, as the
+    // reference's does, inverse_scaling_real.hpp:171-187): then the out-of-place form needs no copy of C into D
+    bool c_unread = false;
+    if (pmode == HIPBLASLT_POINTER_MODE_HOST) {
+        double ar, ai = 0, br, bi2 = 0;
+        if (dtype == GEMMUL8_S || dtype == GEMMUL8_C) {
+            ar = ((const float*)alpha)[0], br = ((const float*)beta)[0];
+            if (dtype == GEMMUL8_C) ai = ((const float*)alpha)[1], bi2 = ((const float*)beta)[1];
+        } else {
+            ar = ((const double*)alpha)[0], br = ((const double*)beta)[0];
+            if (dtype == GEMMUL8_Z) ai = ((const double*)alpha)[1], bi2 = ((const double*)beta)[1];
+        }
+        c_unread = br == 0 && bi2 == 0 && ai == 0 && (ar == 1 || ar == -1);
+    }
+    if (haveC && C != D && !c_unread) {  // out-of-place form: bring C into D, then update D in place
         for (int bi = 0; bi < nb; ++bi)
             if (hipMemcpy2DAsync((char*)D + (long long)bi * d.stride * (long long)esz, (size_t)d.ld * esz,
                                  (const char*)C + (long long)bi * c.stride * (long long)esz, (size_t)c.ld * esz, m * esz, n,
