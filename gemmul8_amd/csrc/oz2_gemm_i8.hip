@@ -252,6 +252,9 @@ __device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmAr
 #define OZ2_PRIO_MODE 0  // wave priorities (experiment switch): 0 = s_setprio 1 around every MFMA segment (shipped), 1 = none, 2 = the lagging
                         // half at priority 1 for the whole kernel, no flips, 3 = as 0 with the producer waves at priority 3
 #endif
+#ifndef OZ2_MAX_KBAR
+#define OZ2_MAX_KBAR 0
+#endif
 #ifndef OZ2_PCRT_ABL
 #define OZ2_PCRT_ABL 0  // timing ablations of the producer-wave CRT (wrong results): 1 no CRT work at all (order + schedule only), 2 no residue re-reads, 4 no C stores
 #endif
@@ -1027,7 +1030,10 @@ template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int
     planes *= (int)g_batch.batch;
     a.total_tiles = planes * a.tiles_m * a.tiles_n;
     if (a.total_tiles <= 0) return hipSuccess;
-    if (a.kp * a.nseg <= OZ2_KBAR_MAX_KP) return launch_sched<EPI, true>(stream, a);
+    // (the bound GEMM keeps the ping-pong schedule at every k: with the row / column-maxima epilogue the K-step-barrier instantiation
+    // spills accumulators INSIDE its MFMA loop -- five 16-byte stores and six loads per K-step -- and ran the 4096^3 bound GEMM at
+    // half the rate of the residue GEMMs; OZ2_MAX_KBAR=1 restores it for A/B runs)
+    if ((EPI != EPI_MAX || OZ2_MAX_KBAR) && a.kp * a.nseg <= OZ2_KBAR_MAX_KP) return launch_sched<EPI, true>(stream, a);
     return launch_sched<EPI, false>(stream, a);
 }
 
