@@ -53,6 +53,12 @@ static void one_thread(int id) {
         CHECK(hipblasDgemmStridedBatched(h, HIPBLAS_OP_N, HIPBLAS_OP_N, 50, 40, 30, &one, A.data(), 50, 1500, B.data(), 30, 1200, &zero, C.data(), 50, 2000, 7) ==
               HIPBLAS_STATUS_SUCCESS);
         CHECK(mock_emulated_calls() >= emu_a + 7);
+        setenv("GEMMUL8_BATCH_WORKSPACE_MB", "1", 1);  // smaller than one item: chunks of a single item, the buffer is re-grown
+        const long emu_c = mock_emulated_calls();
+        CHECK(hipblasDgemmStridedBatched(h, HIPBLAS_OP_N, HIPBLAS_OP_N, 50, 40, 30, &one, A.data(), 50, 1500, B.data(), 30, 1200, &zero, C.data(), 50, 2000, 5) ==
+              HIPBLAS_STATUS_SUCCESS);
+        CHECK(mock_emulated_calls() >= emu_c + 5);
+        unsetenv("GEMMUL8_BATCH_WORKSPACE_MB");
         setenv("GEMMUL8_BATCH_FUSED", "0", 1);
         const long emu_b = mock_emulated_calls();
         CHECK(hipblasDgemmStridedBatched(h, HIPBLAS_OP_N, HIPBLAS_OP_N, 50, 40, 30, &one, A.data(), 50, 1500, B.data(), 30, 1200, &zero, C.data(), 50, 2000, 7) ==
