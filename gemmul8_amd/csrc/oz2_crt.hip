@@ -21,7 +21,13 @@ namespace oz2 {
 
 // U = float|double ; CPLX ; MID = int8_t|int16_t
 template <typename U, bool CPLX, typename MID>
-__global__ void __launch_bounds__(256) crt_kernel(const CrtArgs a) {
+#ifndef OZ2_CRT_BLOCK
+#define OZ2_CRT_BLOCK 256  // threads per block of crt_kernel: 128 / 256 / 512 / 1024 -> 455 / 377 / 414 / 380 us at config 2 (tools/crt_ab.py)
+#endif
+#ifndef OZ2_CRT_NT
+#define OZ2_CRT_NT 1      // non-temporal residue loads (plain loads: 393 us)
+#endif
+__global__ void __launch_bounds__(OZ2_CRT_BLOCK) crt_kernel(const CrtArgs a) {
     constexpr int COMPS = CPLX ? 2 : 1;
     constexpr int ROWS = 8 / (COMPS * (int)sizeof(MID));  // 8-byte residue vectors: 8 / 4 / 4 / 2 rows; wider ones cost occupancy
     constexpr int NV = ROWS * COMPS;  // values per thread and plane
@@ -42,7 +48,8 @@ __global__ void __launch_bounds__(256) crt_kernel(const CrtArgs a) {
     for (unsigned t = 0; t < 20; ++t)
         if (t < a.N) {
             static_assert(sizeof(Vec) == 8, "8-byte residue vectors");
-            const unsigned long long raw = __builtin_nontemporal_load((const unsigned long long*)(base + (size_t)t * a.plane_stride * COMPS));
+            const unsigned long long* src_ = (const unsigned long long*)(base + (size_t)t * a.plane_stride * COMPS);
+            const unsigned long long raw = OZ2_CRT_NT ? __builtin_nontemporal_load(src_) : *src_;
             __builtin_memcpy(&c[t], &raw, 8);
         }
 
@@ -359,8 +366,8 @@ hipError_t launch_crt(hipStream_t stream, int dtype, int backend, unsigned N, si
     const bool cplx = is_complex(dtype), i8 = backend == kINT8;
     const size_t rows_per_thread = 8 / ((cplx ? 2 : 1) * (i8 ? 1 : 2));
     const size_t threads = ((m + rows_per_thread - 1) / rows_per_thread) * n;
-    dim3 grid((unsigned)((threads + 255) / 256), 1, g_batch.batch);
-#define OZ2_CRT(U, CP, MID) hipLaunchKernelGGL((crt_kernel<U, CP, MID>), grid, dim3(256), 0, stream, a)
+    dim3 grid((unsigned)((threads + OZ2_CRT_BLOCK - 1) / OZ2_CRT_BLOCK), 1, g_batch.batch);
+#define OZ2_CRT(U, CP, MID) hipLaunchKernelGGL((crt_kernel<U, CP, MID>), grid, dim3(OZ2_CRT_BLOCK), 0, stream, a)
     if (i8) {
         switch (dtype) {
         case kF32: OZ2_CRT(float, false, int8_t); break;
