@@ -108,6 +108,8 @@ def lib():
     L.gemmul8_gemm_batched.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
                                        C.c_void_p, C.c_size_t, C.c_longlong, C.c_void_p, C.c_size_t, C.c_longlong, C.c_void_p,
                                        C.c_void_p, C.c_size_t, C.c_longlong, C.c_size_t, C.c_uint, C.c_int, C.c_void_p]
+    L.gemmul8_add_row_bias.restype = C.c_int
+    L.gemmul8_add_row_bias.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     _lib = L
     return L
 

@@ -345,6 +345,21 @@ hipError_t launch_crt_finish(hipStream_t stream, int dtype, int backend, unsigne
     return hipGetLastError();
 }
 
+// D(i, j) += bias[i]: the broadcast bias vector of a hipblasLtMatmul BIAS epilogue, applied after the emulated GEMM (the hook's only use)
+template <typename U> __global__ void __launch_bounds__(256) row_bias_kernel(U* D, size_t ldd, size_t m, const U* bias) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < m) D[(size_t)blockIdx.y * ldd + i] += bias[i];
+}
+hipError_t launch_row_bias(hipStream_t stream, int dtype, size_t m, size_t n, void* D, size_t ldd, const void* bias) {
+    if (m == 0 || n == 0) return hipSuccess;
+    if (n > 65535) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((m + 255) / 256), (unsigned)n);
+    if (dtype == kF32) hipLaunchKernelGGL(row_bias_kernel<float>, grid, dim3(256), 0, stream, (float*)D, ldd, m, (const float*)bias);
+    else if (dtype == kF64) hipLaunchKernelGGL(row_bias_kernel<double>, grid, dim3(256), 0, stream, (double*)D, ldd, m, (const double*)bias);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 hipError_t launch_crt(hipStream_t stream, int dtype, int backend, unsigned N, size_t m, size_t n, const void* Cmid, size_t ld_mid,
                       size_t plane_stride, const int16_t* sftA, const int16_t* sftB, const void* alpha, const void* beta,
                       bool scalars_on_device, void* C, size_t ldc) {

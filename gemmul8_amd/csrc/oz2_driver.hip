@@ -440,6 +440,13 @@ int gemmul8_gemm(void* stream_, int dtype, int backend, int op_A, int op_B, size
     return GEMMUL8_OK;
 }
 
+int gemmul8_add_row_bias(void* stream_, int dtype, size_t m, size_t n, void* D, size_t ldd, const void* bias) {
+    if (!D || !bias) return GEMMUL8_E_ARG;
+    if (dtype != kF32 && dtype != kF64) return GEMMUL8_E_UNSUPPORTED;
+    OZ2_HIP(launch_row_bias((hipStream_t)stream_, dtype, m, n, D, ldd, bias));
+    return GEMMUL8_OK;
+}
+
 // ---- strided batch as ONE set of launches (no counterpart in the reference; hipblas{S,D,C,Z}gemmStridedBatched in the hook).
 // The items' workspaces are consecutive blocks of gemmul8_batched_item_bytes; every kernel of the pipeline takes the item from
 // gridDim.z (the persistent GEMM kernels fold the items into their plane sequence), so that a batch of small matrices fills the

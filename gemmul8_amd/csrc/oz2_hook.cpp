@@ -49,6 +49,7 @@ struct Abi {
                 size_t, unsigned, int, void*, void*, void*, int, int, int, int, double*) = nullptr;
     decltype(&::gemmul8_work_size_batched) work_size_batched = nullptr;
     decltype(&::gemmul8_gemm_batched) gemm_batched = nullptr;
+    decltype(&::gemmul8_add_row_bias) add_row_bias = nullptr;
     decltype(&::gemmul8_comm_rccl_from_env) comm_from_env = nullptr;
     decltype(&::gemmul8_dist_create) dist_create = nullptr;
     decltype(&::gemmul8_dist_gemm) dist_gemm = nullptr;
@@ -86,12 +87,13 @@ const Abi& abi() {
         r.gemm = (decltype(r.gemm))dlsym(h, "gemmul8_gemm");
         r.work_size_batched = (decltype(r.work_size_batched))dlsym(h, "gemmul8_work_size_batched");
         r.gemm_batched = (decltype(r.gemm_batched))dlsym(h, "gemmul8_gemm_batched");
+        r.add_row_bias = (decltype(r.add_row_bias))dlsym(h, "gemmul8_add_row_bias");
         r.comm_from_env = (decltype(r.comm_from_env))dlsym(h, "gemmul8_comm_rccl_from_env");
         r.dist_create = (decltype(r.dist_create))dlsym(h, "gemmul8_dist_create");
         r.dist_gemm = (decltype(r.dist_gemm))dlsym(h, "gemmul8_dist_gemm");
         r.dist_allgather_c = (decltype(r.dist_allgather_c))dlsym(h, "gemmul8_dist_allgather_c");
         r.dist_destroy = (decltype(r.dist_destroy))dlsym(h, "gemmul8_dist_destroy");
-        if (!r.work_size || !r.gemm || !r.work_size_batched || !r.gemm_batched || !r.comm_from_env || !r.dist_create || !r.dist_gemm || !r.dist_allgather_c || !r.dist_destroy) {
+        if (!r.work_size || !r.gemm || !r.work_size_batched || !r.gemm_batched || !r.add_row_bias || !r.comm_from_env || !r.dist_create || !r.dist_gemm || !r.dist_allgather_c || !r.dist_destroy) {
             std::fprintf(stderr, "[GEMMUL8 HOOK] libgemmul8.so lacks the C ABI entry points\n");
             std::abort();
         }
@@ -104,6 +106,7 @@ const Abi& abi() {
 #define gemmul8_gemm abi().gemm
 #define gemmul8_work_size_batched abi().work_size_batched
 #define gemmul8_gemm_batched abi().gemm_batched
+#define gemmul8_add_row_bias abi().add_row_bias
 #define gemmul8_comm_rccl_from_env abi().comm_from_env
 #define gemmul8_dist_create abi().dist_create
 #define gemmul8_dist_gemm abi().dist_gemm
@@ -824,8 +827,15 @@ bool lt_try(hipblasLtHandle_t handle, hipblasLtMatmulDesc_t desc, const void* al
     uint32_t epi = 0;
     if (dget(desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof ta, &w) != HIPBLAS_STATUS_SUCCESS) return lt_decline("TRANSA unreadable");
     if (dget(desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof tb, &w) != HIPBLAS_STATUS_SUCCESS) return lt_decline("TRANSB unreadable");
-    if (dget(desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof epi, &w) != HIPBLAS_STATUS_SUCCESS || epi != HIPBLASLT_EPILOGUE_DEFAULT)
-        return lt_decline("epilogue is not the default one");
+    if (dget(desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof epi, &w) != HIPBLAS_STATUS_SUCCESS ||
+        (epi != HIPBLASLT_EPILOGUE_DEFAULT && epi != HIPBLASLT_EPILOGUE_BIAS))
+        return lt_decline("epilogue is neither the default one nor a plain bias");
+    // BIAS epilogue (what a float32 torch.nn.Linear issues): D = alpha*op(A)*op(B) + beta*C + bias, bias broadcast over the columns --
+    // emulated as the plain GEMM followed by the bias addition when the bias vector has the matrices' (real) type
+    const void* bias = nullptr;
+    if (epi == HIPBLASLT_EPILOGUE_BIAS) {
+        if (dget(desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof bias, &w) != HIPBLAS_STATUS_SUCCESS || !bias) return lt_decline("bias epilogue without a bias pointer");
+    }
     for (auto attr : {HIPBLASLT_MATMUL_DESC_A_SCALE_POINTER, HIPBLASLT_MATMUL_DESC_B_SCALE_POINTER, HIPBLASLT_MATMUL_DESC_C_SCALE_POINTER,
                       HIPBLASLT_MATMUL_DESC_D_SCALE_POINTER, HIPBLASLT_MATMUL_DESC_AMAX_D_POINTER}) {
         void* ptr = nullptr;
@@ -848,6 +858,14 @@ bool lt_try(hipblasLtHandle_t handle, hipblasLtMatmulDesc_t desc, const void* al
     case HIP_C_32F: dtype = GEMMUL8_C; break;
     case HIP_C_64F: dtype = GEMMUL8_Z; break;
     default: return lt_decline("not an S/D/C/Z matrix type");
+    }
+    if (bias) {
+        int32_t bt = a.type;
+        // an unset BIAS_DATA_TYPE reads back as 255 (invalid) in ROCm 7.2 and means "the type of D"
+        if (dget(desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof bt, &w) != HIPBLAS_STATUS_SUCCESS || (bt != a.type && bt != 255))
+            return lt_decline("bias vector of another type than the matrices");
+        if (dtype != GEMMUL8_S && dtype != GEMMUL8_D) return lt_decline("bias epilogue on a complex type");
+        if (d.batch != 1 || d.cols > 65535) return lt_decline("bias epilogue on a batched or very wide product");
     }
     if (a.order != HIPBLASLT_ORDER_COL || b.order != HIPBLASLT_ORDER_COL || c.order != HIPBLASLT_ORDER_COL || d.order != HIPBLASLT_ORDER_COL) return lt_decline("not column-major");
     const int nb = d.batch;
@@ -889,8 +907,12 @@ bool lt_try(hipblasLtHandle_t handle, hipblasLtMatmulDesc_t desc, const void* al
     if (nb > 1)  // strided batch (torch.bmm in float32 arrives here): one set of launches, as for hipblas*gemmStridedBatched
         return emulate_batch(dtype, esz, (hipblasHandle_t)handle, (hipblasOperation_t)ta, (hipblasOperation_t)tb, (int)m, (int)n, (int)k, alpha, A,
                              (int)a.ld, (long long)a.stride, B, (int)b.ld, (long long)b.stride, beta, D, (int)d.ld, (long long)d.stride, nb, st, &stream);
-    return try_emulate(dtype, (hipblasHandle_t)handle, (hipblasOperation_t)ta, (hipblasOperation_t)tb, (int)m, (int)n, (int)k, alpha, A, (int)a.ld, B,
-                       (int)b.ld, beta, D, (int)d.ld, st, &stream);
+    const bool done = try_emulate(dtype, (hipblasHandle_t)handle, (hipblasOperation_t)ta, (hipblasOperation_t)tb, (int)m, (int)n, (int)k, alpha, A,
+                                  (int)a.ld, B, (int)b.ld, beta, D, (int)d.ld, st, &stream);
+    if (done && bias && *st == HIPBLAS_STATUS_SUCCESS &&
+        gemmul8_add_row_bias(stream, dtype, (size_t)m, (size_t)n, D, (size_t)d.ld, bias) != 0)
+        *st = HIPBLAS_STATUS_INTERNAL_ERROR;
+    return done;
 }
 }  // namespace
 

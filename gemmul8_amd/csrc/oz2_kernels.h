@@ -77,6 +77,8 @@ hipError_t launch_crt(hipStream_t stream, int dtype, int backend, unsigned N, si
                       size_t plane_stride, const int16_t* sftA, const int16_t* sftB, const void* alpha, const void* beta,
                       bool scalars_on_device, void* C, size_t ldc);
 
+hipError_t launch_row_bias(hipStream_t stream, int dtype, size_t m, size_t n, void* D, size_t ldd, const void* bias);
+
 // multi-GPU exchange variant (A): per-rank FP64 partial CRT sums + the finish on the summed partials (oz2_crt.hip)
 hipError_t launch_crt_partial(hipStream_t stream, int dtype, int backend, unsigned N, unsigned t_begin, unsigned t_end, size_t m, size_t n,
                               const void* Cmid, size_t ld_mid, size_t plane_stride, double* out_hi, double* out_lo, size_t ld_out,

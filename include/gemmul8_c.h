@@ -135,6 +135,10 @@ GEMMUL8_API int gemmul8_gemm_batched(void *stream, int dtype, int backend, int o
                          long long strideB, const void *beta, void *C, size_t ldc, long long strideC, size_t batch,
                          unsigned num_moduli, int fastmode, void *work);
 
+/* D(i, j) += bias[i] for a column-major m x n real matrix: the broadcast bias of a hipblasLtMatmul BIAS epilogue, applied by the hook after
+ * the emulated GEMM (one more rounding than the vendor's fused form).  S / D only.  No counterpart in the reference. */
+GEMMUL8_API int gemmul8_add_row_bias(void *stream, int dtype, size_t m, size_t n, void *D, size_t ldd, const void *bias);
+
 /* Multi-GPU exchange variant (A) of the moduli-sharded plan (include/gemmul8_dist.h): the rank's FP64 partial CRT sums over its
  * moduli [t_begin, t_end) -- C_mid points at plane t_begin -- as two double planes (hi: error-free chain, lo: rounded chain;
  * same FMAs and order as gemmul8_crt restricted to those moduli), written in column blocks of col_block columns, block b at

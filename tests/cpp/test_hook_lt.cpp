@@ -124,17 +124,22 @@ template <typename T> int run_type(hipblasLtHandle_t lt, gemm_fn direct, ws_fn w
             return 1;
         }
     std::printf("hooked hipblasLtMatmul<%s> == direct gemmul8_gemm (bitwise), in place and out of place\n", name);
-    // (3) bias epilogue: not a plain GEMM -> native routine; the result is the native product + bias (differs from the emulation + bias only by rounding)
-    hipblasStatus_t rcb = lt_matmul<T>(lt, HIPBLAS_OP_N, m, n, k, one, A, m, B, k, zero, D, ldd, D, ldd, st, true, bias);
+    // (3) bias epilogue (what a float32 torch.nn.Linear issues): emulated GEMM + broadcast bias -- bitwise the direct result plus the bias
+    const hipblasStatus_t rcb = lt_matmul<T>(lt, HIPBLAS_OP_N, m, n, k, one, A, m, B, k, zero, D, ldd, D, ldd, st, true, bias);
     if (rcb == HIPBLAS_STATUS_SUCCESS) {
         hipMemcpy(got.data(), D, got.size() * sizeof(T), hipMemcpyDeviceToHost);
-        double e = 0;
         for (int j = 0; j < n; ++j)
-            for (int i = 0; i < m; ++i) e = std::fmax(e, std::fabs((double)got[(size_t)j * ldd + i] - ((double)ref[(size_t)j * ldd + i] + 0.25)));
-        std::printf("bias epilogue passed through: max |native+bias - (emulated+bias)| = %e\n", e);
-        CHECK(e < (sizeof(T) == 4 ? 1e-3 : 1e-11));
-    } else {
-        std::printf("bias epilogue: native library has no such algorithm for %s (status %d) -- passthrough reached the real routine\n", name, (int)rcb);
+            for (int i = 0; i < m; ++i) {
+                const size_t o = (size_t)j * ldd + i;
+                const T want = (T)(ref[o] + (T)0.25);
+                if (got[o] != want) {
+                    std::printf("FAILED %s bias epilogue: element (%d, %d) %a vs %a\n", name, i, j, (double)got[o], (double)want);
+                    return 1;
+                }
+            }
+        std::printf("hooked hipblasLtMatmul<%s> with a BIAS epilogue == direct gemmul8_gemm + bias (bitwise)\n", name);
+    } else {  // the heuristic query of the NATIVE library comes first in an application: no algorithm, no call to intercept
+        std::printf("bias epilogue: the native library offers no algorithm for %s (status %d) -- the application never reaches hipblasLtMatmul\n", name, (int)rcb);
     }
     // (4) GEMMUL8_MIN_FLOPS above this call: native
     setenv("GEMMUL8_MIN_FLOPS", "1000000000000", 1);

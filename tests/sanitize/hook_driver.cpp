@@ -17,6 +17,7 @@ long mock_live_allocs();
 hipblasStatus_t mock_create(hipblasHandle_t*);
 hipblasStatus_t mock_set_stream(hipblasHandle_t, hipStream_t);
 void* mock_lt_desc(int, int, unsigned);
+void* mock_lt_desc_bias(int, int, const void*, int);
 void mock_lt_free_desc(void*);
 }
 #define CHECK(x)                                                       \
@@ -117,7 +118,17 @@ static void one_thread(int id) {
         CHECK(mock_emulated_calls() >= emu1 + 3);
         for (hipblasLtMatrixLayout_t l : ls) CHECK(hipblasLtMatrixLayoutDestroy(l) == HIPBLAS_STATUS_SUCCESS);
     }
-    void* db = mock_lt_desc(HIPBLAS_OP_T, HIPBLAS_OP_N, HIPBLASLT_EPILOGUE_BIAS);
+    {  // bias epilogue with a bias vector of the matrices' type: emulated GEMM + bias addition
+        std::vector<double> bias(100, 0.5);
+        void* dbb = mock_lt_desc_bias(HIPBLAS_OP_T, HIPBLAS_OP_N, bias.data(), (int)HIP_R_64F);
+        const long emu2 = mock_emulated_calls();
+        CHECK(hipblasLtMatmul(lt, (hipblasLtMatmulDesc_t)dbb, &one, A.data(), (hipblasLtMatrixLayout_t)la, B.data(), (hipblasLtMatrixLayout_t)lb, &zero, C.data(),
+                              (hipblasLtMatrixLayout_t)lc, D.data(), (hipblasLtMatrixLayout_t)ld, nullptr, nullptr, 0, (hipStream_t)(uintptr_t)(0x2000 + id)) == HIPBLAS_STATUS_SUCCESS);
+        CHECK(mock_emulated_calls() > emu2);
+        CHECK(((const unsigned char*)D.data())[0] == 0x66);  // the mock's bias pass ran last
+        mock_lt_free_desc(dbb);
+    }
+    void* db = mock_lt_desc(HIPBLAS_OP_T, HIPBLAS_OP_N, HIPBLASLT_EPILOGUE_BIAS);  // no bias pointer: left to the native routine
     CHECK(hipblasLtMatmul(lt, (hipblasLtMatmulDesc_t)db, &one, A.data(), (hipblasLtMatrixLayout_t)la, B.data(), (hipblasLtMatrixLayout_t)lb, &one, C.data(),
                           (hipblasLtMatrixLayout_t)lc, D.data(), (hipblasLtMatrixLayout_t)ld, nullptr, nullptr, 0, nullptr) == HIPBLAS_STATUS_SUCCESS);
     CHECK(mock_native_calls() >= nat1 + 2);

@@ -71,9 +71,10 @@ EXPORT hipblasStatus_t hipblasDgemmStridedBatched(hipblasHandle_t, hipblasOperat
 }
 
 // ---- "real" hipBLASLt: descriptors are plain structs
-struct MockDesc { int32_t ta, tb; uint32_t epi; };
+struct MockDesc { int32_t ta, tb; uint32_t epi; const void* bias = nullptr; int32_t bias_type = -1; };
 struct MockLayout { uint32_t type; int32_t order, batch; uint64_t rows, cols; int64_t ld; };
 EXPORT void* mock_lt_desc(int ta, int tb, unsigned epi) { return new MockDesc{ta, tb, epi}; }
+EXPORT void* mock_lt_desc_bias(int ta, int tb, const void* bias, int bias_type) { return new MockDesc{ta, tb, (unsigned)HIPBLASLT_EPILOGUE_BIAS, bias, bias_type}; }
 EXPORT void mock_lt_free_desc(void* p) { delete (MockDesc*)p; }
 EXPORT hipblasStatus_t hipblasLtMatmulDescGetAttribute(hipblasLtMatmulDesc_t d, hipblasLtMatmulDescAttributes_t a, void* buf, size_t n, size_t* w) {
     const MockDesc* D = (const MockDesc*)d;
@@ -82,6 +83,8 @@ EXPORT hipblasStatus_t hipblasLtMatmulDescGetAttribute(hipblasLtMatmulDesc_t d, 
     case HIPBLASLT_MATMUL_DESC_TRANSA: std::memcpy(buf, &D->ta, 4); return HIPBLAS_STATUS_SUCCESS;
     case HIPBLASLT_MATMUL_DESC_TRANSB: std::memcpy(buf, &D->tb, 4); return HIPBLAS_STATUS_SUCCESS;
     case HIPBLASLT_MATMUL_DESC_EPILOGUE: std::memcpy(buf, &D->epi, 4); return HIPBLAS_STATUS_SUCCESS;
+    case HIPBLASLT_MATMUL_DESC_BIAS_POINTER: std::memcpy(buf, &D->bias, sizeof(void*)); return HIPBLAS_STATUS_SUCCESS;
+    case HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE: std::memcpy(buf, &D->bias_type, 4); return HIPBLAS_STATUS_SUCCESS;
     default: std::memset(buf, 0, n); return HIPBLAS_STATUS_SUCCESS;  // pointers NULL, pointer mode host
     }
 }
@@ -140,6 +143,14 @@ EXPORT int gemmul8_gemm_batched(void*, int dtype, int backend, int, int, size_t 
     for (size_t b = 0; b < batch; ++b)
         for (size_t j = 0; j < n; ++j) std::memset((char*)C + ((long long)b * sc + (long long)(j * ldc)) * (long long)es, 0x44, m * es);
     g_emulated_calls += (long)batch;
+    return GEMMUL8_OK;
+}
+EXPORT int gemmul8_add_row_bias(void*, int dtype, size_t m, size_t n, void* D, size_t ldd, const void* bias) {
+    if (!D || !bias) return GEMMUL8_E_ARG;
+    const size_t es = dtype == 0 ? 4 : 8;
+    volatile unsigned char sink = 0;
+    for (size_t i = 0; i < m * es; ++i) sink = sink + ((const unsigned char*)bias)[i];  // the whole bias vector must be readable
+    for (size_t j = 0; j < n; ++j) std::memset((char*)D + j * ldd * es, 0x66, m * es);
     return GEMMUL8_OK;
 }
 EXPORT int gemmul8_comm_rccl_from_env(gemmul8_comm**) { return GEMMUL8_E_UNSUPPORTED; }

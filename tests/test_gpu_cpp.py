@@ -36,11 +36,12 @@ def test_ld_preload_hook():
 
 
 def test_ld_preload_hook_hipblaslt_and_range_passthrough():
-    """hipblasLtMatmul interception (plain S / D matmul, in place and out of place: bitwise equal to the direct call; bias epilogue and
-    GEMMUL8_MIN_FLOPS floor: native) and the k > 2^17 passthrough of the hipBLAS hook."""
+    """hipblasLtMatmul interception (plain S / D matmul, in place and out of place: bitwise equal to the direct call; BIAS epilogue: direct
+    result + bias, bitwise; GEMMUL8_MIN_FLOPS floor: native) and the k > 2^17 passthrough of the hipBLAS hook."""
     assert os.path.exists(os.path.join(BIN, "test_hook_lt")), "tests/cpp not built (run __graft_entry__.build())"
     out = run([os.path.join(BIN, "test_hook_lt")], {"LD_PRELOAD": LIB, "GEMMUL8_NUM_MOD_D": "15", "GEMMUL8_NUM_MOD_S": "8"})
     assert "hipblasLtMatmul<float>" in out and "hipblasLtMatmul<double>" in out and "passed to the native routine" in out
+    assert "hipblasLtMatmul<float> with a BIAS epilogue == direct gemmul8_gemm + bias (bitwise)" in out
 
 
 @pytest.mark.parametrize("kind", ["blocks", "moduli", "fp64sum"])

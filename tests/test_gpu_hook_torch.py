@@ -22,9 +22,11 @@ def _run(extra_env):
     mb = re.search(r"bmm normwise err ([0-9.e+-]+)", out.stdout)
     ms = re.search(r"sgemm normwise err ([0-9.e+-]+)", out.stdout)
     msb = re.search(r"batched-f32 normwise err ([0-9.e+-]+)", out.stdout)
-    assert m and mb and ms and msb, out.stdout
+    mlin = re.search(r"linear-f32 normwise err ([0-9.e+-]+)", out.stdout)
+    assert m and mb and ms and msb and mlin, out.stdout
     _run.sgemm_err = float(ms.group(1))
     _run.sbmm_err = float(msb.group(1))
+    _run.lin_err = float(mlin.group(1))
     assert "graph replay equals eager: True" in out.stdout, out.stdout   # the hooked call captured in a HIP graph and replayed
     return float(m.group(1)), float(mb.group(1))
 
@@ -43,9 +45,10 @@ def test_torch_float32_matmul_is_emulated_under_ld_preload():
     """float32 matmuls: whichever library PyTorch picks (hipBLASLt's hipblasLtMatmul or hipBLAS) the hook catches the call --
     GEMMUL8_NUM_MOD_S=13 gives the correctly rounded float product where the native SGEMM carries ~sqrt(k) roundings."""
     _run({})
-    native, native_b = _run.sgemm_err, _run.sbmm_err
+    native, native_b, native_l = _run.sgemm_err, _run.sbmm_err, _run.lin_err
     _run({"LD_PRELOAD": SHIM, "GEMMUL8_NUM_MOD_S": "13"})
-    emulated, emulated_b = _run.sgemm_err, _run.sbmm_err
+    emulated, emulated_b, emulated_l = _run.sgemm_err, _run.sbmm_err, _run.lin_err
+    assert emulated_l < 0.5 * native_l, (native_l, emulated_l)   # float32 nn.Linear with bias: hipblasLtMatmul + BIAS epilogue, emulated too
     assert emulated_b < 0.25 * native_b, (native_b, emulated_b)   # float32 torch.bmm: hipblasLtMatmul with batched layouts, emulated too
     for prefer in ("1", "0"):
         _run({"LD_PRELOAD": SHIM, "GEMMUL8_NUM_MOD_S": "13", "TORCH_BLAS_PREFER_HIPBLASLT": prefer})

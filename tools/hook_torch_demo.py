@@ -35,6 +35,15 @@ for i in range(5):
     errbf = max(errbf, float(((Zf[i].double() - refbf).abs().max() / refbf.abs().max()).item()))
 print(f"torch.bmm float32 5 x 640x384x512: batched-f32 normwise err {errbf:.2e}")
 
+# float32 torch.nn.Linear with a bias: hipblasLtMatmul with the BIAS epilogue
+lin = torch.nn.Linear(512, 384, bias=True, device="cuda", dtype=torch.float32)
+xl = torch.rand((640, 512), dtype=torch.float32, device="cuda") - 0.5
+with torch.no_grad():
+    yl = lin(xl)
+    refl = xl.double() @ lin.weight.double().T + lin.bias.double()
+torch.cuda.synchronize()
+print(f"torch.nn.Linear float32 640x512 -> 384: linear-f32 normwise err {float(((yl.double() - refl).abs().max() / refl.abs().max()).item()):.2e}")
+
 # batched: torch.bmm -> hipblasDgemmStridedBatched / hipblasGemmStridedBatchedEx
 nb, b = 1024, 6
 X = torch.rand((b, nb, nb), dtype=torch.float64, device="cuda") - 0.5
