@@ -86,6 +86,10 @@ struct GemmArgs {
 #define OZ2_PROBE_LDS 0  // timing probes on REAL data (wrong results; tools/README.md): bit 0/1 B/A fragments re-read at ks == 0 only, bit 2 DMA in the
                         // first tile only, bit 3 no epilogue, bit 4 operands from the first 8 K-steps only (L2 hits); 0 in every shipped build
 #endif
+#ifndef OZ2_EPI_NT
+#define OZ2_EPI_NT 0  // 1: non-temporal residue stores (experiment: GEMM + CRT at 8192^2 x k, 14 planes: +3 % at k = 256 and 1024, +1 % at 512 and 1536,
+                     // -2.5 % at 2048, -1 % at 4096 / 8192 -- the CRT pass loses what the GEMM gains; not adopted)
+#endif
 #ifndef OZ2_ABL_EPI
 #define OZ2_ABL_EPI 0  // 1: no stores, 2: every plane takes the p = 256 path (timing ablations only)
 #endif
@@ -157,7 +161,14 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
             if (col < args.n && !(OZ2_ABL_EPI == 1 && args.kp > 0)) {
                 const size_t e = e00 + tj * ejs + tg * 64;  // first of 16 consecutive rows
                 if constexpr (EPI == EPI_MOD) {
+#if OZ2_EPI_NT
+                    {
+                        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(v4u{z[0], z[1], z[2], z[3]}, (v4u*)(args.out + po + e));
+                    }
+#else
                     *(uint4*)(args.out + po + e) = make_uint4(z[0], z[1], z[2], z[3]);
+#endif
                 } else {
                     const uint4 x4 = *(const uint4*)(args.rx + pr + e);
                     const uint4 y4 = *(const uint4*)(args.ry + pr + e);
