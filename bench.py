@@ -3,9 +3,11 @@
 
 One "step" = one whole emulated DGEMM C = A*B (8192^3, FP64 in/out, 14 moduli, INT8 MFMA backend,
 accurate mode = the reference's default: 15 INT8 GEMMs) with A, B already resident in HBM.
-N>1 (one process per GPU under torch.distributed.run, RCCL): A and B replicated on every rank, the output sharded in blocks
-over a rank grid by the C++ plans behind include/gemmul8_dist.h (every rank runs all moduli on its block; one
-all_reduce(MAX) of the row/column bounds); GEMMUL8_DIST_SHARD=moduli | fp64sum select the moduli-sharded plans.  "strong"
+N>1: one process per GPU over RCCL -- either started by the driver under torch.distributed.run, or by THIS file when it is called
+plainly as `python bench.py --gpus N` (self_launch).  A and B are replicated on every rank; ALL THREE C++ plans behind
+include/gemmul8_dist.h run in one invocation (`plans`: blocks = output blocks on a rank grid, one all_reduce(MAX) of the bounds;
+moduli = moduli sharded + INT8 residue exchange; fp64sum = moduli sharded + the FP64 reduce-scatter north_star names), each with its
+TFLOPS, GEMM roofline fraction, collective / exchange time and bytes; the headline `value` is the best bit-exact plan.  "strong"
 scaling: the problem is fixed, value = 2*n^3 / (max over ranks of the step time).
 
 Prints ONE JSON line (rank 0) with the driver's contract keys plus `roofline` (dominant kernel =
@@ -178,36 +180,155 @@ def run_other_config(args):
            "data": "synthetic U(-0.5,0.5)", "config": {"workload": f"{name} {n}^3, moduli={N}, {'FP8' if be == g.FP8 else 'INT8'} backend, "
                                                                       f"{'fast' if mode else 'accurate'} mode, op N/N, alpha=1, beta=0"},
            "phase_ms": {"scaling": tm[0] * 1e-6, "lowprec_gemm": tm[1] * 1e-6, "requantise": tm[2] * 1e-6, "inverse_scaling": tm[3] * 1e-6},
-           "roofline": {"bound": "mfma", "achieved": gcnt * 2.0 * n ** 3 / (tm[1] * 1e-6 + 1e-30) * 1e-9 if mode else None, "peak": 5000.0,
-                        "unit": "TOP/s", "lowprec_units_of_2mnk": gcnt, "lowprec_phase_ms": tm[1] * 1e-6,
-                        "lowprec_rate_TOPs": (3 * N) * 2.0 * n ** 3 / (tm[1] * 1e-6) * 1e-9},
+           "roofline": {"bound": "mfma", "kernel": "the residue GEMMs of the low-precision phase (3 per modulus; the accurate mode's bound GEMMs "
+                                                       "run inside the scaling phase and are not counted here)",
+                        "achieved": (3 * N) * 2.0 * n ** 3 / (tm[1] * 1e-6) * 1e-9, "peak": 5000.0,
+                        "frac": (3 * N) * 2.0 * n ** 3 / (tm[1] * 1e-6) * 1e-9 / 5000.0, "traffic": None, "traffic_measured_in_run": False,
+                        "unit": "TOP/s", "lowprec_units_of_2mnk_whole_call": gcnt, "lowprec_phase_ms": tm[1] * 1e-6},
            "max_rel_err": err,
            "native_same_gpu": {"lib": f"rocBLAS/hipBLASLt {name} via torch.matmul", "value": cflops * 2.0 * n ** 3 / nat_ms * 1e-9,
                                "unit": "TFLOPS", "ms": nat_ms, "max_rel_err": errn}}
     print(json.dumps(out))
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start N ranks of this file under torch.distributed.run on a free
+    port of 127.0.0.1 and relay their output / exit status.  With fewer than N visible GPUs (a single-GPU test box) the ranks share the
+    GPUs through the host-staged gloo TEST transport (GEMMUL8_DIST_BACKEND=gloo); the JSON line says which transport ran."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    ngpu = torch.cuda.device_count()
+    if ngpu < args.gpus and "GEMMUL8_DIST_BACKEND" not in env:
+        env["GEMMUL8_DIST_BACKEND"] = "gloo"
+        print(f"[bench] {ngpu} GPU(s) visible for --gpus {args.gpus}: the ranks share them over the gloo test transport", file=sys.stderr)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def event_pair():
+    return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+
+def run_plans(args, n, N, A, B, dev, stream, backend, rank, world):
+    """N > 1: every plan of include/gemmul8_dist.h in ONE invocation (blocks, moduli, fp64sum), each with `warmup` untimed and `steps`
+    timed calls bracketed by barrier + synchronize, max over ranks.  Returns (records by plan name, gathered C of the headline plan,
+    description of the transport)."""
+    import torch.distributed as dist
+    import gemmul8_amd as g
+    from gemmul8_amd import dist as gd
+    comm = gd.RcclComm() if backend == "nccl" else gd.TorchTransport(device=True)
+    rccl_ranks = comm.rccl_ranks()
+    peak = 5000.0
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def ev_ms(pairs):
+        v = [a.elapsed_time(b) for a, b in pairs]
+        return float(np.mean(v)) if v else None
+
+    results, gathered = {}, {}
+    Cmat = torch.zeros((n, n), dtype=torch.float64, device=dev)
+    for name in ("blocks", "moduli", "fp64sum"):
+        plan = gd.make_plan(comm, g.D, g.INT8, n, n, n, N, mode=name, fastmode=args.fast)
+        gemm_ev, ar_ev, xc_ev = [], [], []
+
+        def step(record):
+            if record:
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+                for x in e:
+                    x.record(stream)   # creates the handles; the plan re-records the ones its path reaches
+                plan.set_events(e[0], e[1])
+                plan.set_exchange_events(e[2:6])
+                plan.run(A, B, Cmat)
+                gemm_ev.append((e[0], e[1]))
+                ar_ev.append((e[2], e[3]))
+                xc_ev.append((e[4], e[5]))
+            else:
+                plan.set_events(None, None)
+                plan.set_exchange_events(None)
+                plan.run(A, B, Cmat)
+        Cmat.zero_()
+        for _ in range(args.warmup):
+            step(False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(True)
+        barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        ar_bytes, sent, recvd = plan.exchange_bytes()
+        has_ar = ar_bytes > 0
+        has_xc = name != "blocks"
+        gemm_ms = ev_ms(gemm_ev)
+        ops = plan.my_planes * 2.0 * plan.work_rows * plan.work_cols * n    # this rank's share of the low-precision GEMMs
+        ach = ops / (gemm_ms * 1e-3) * 1e-12 if gemm_ms else None
+        ms = dt / args.steps * 1e3
+        rec = {"value": 2.0 * n ** 3 / (ms * 1e-3) * 1e-12, "unit": "TFLOPS", "ms_per_step": ms, "parallelism": plan.describe(),
+               "gemm_launch_ms_rank0": gemm_ms, "gemm_ops_rank0": ops, "gemm_achieved_TOPs_rank0": ach, "gemm_frac_of_int8_peak_rank0": ach / peak if ach else None,
+               "bounds_allreduce_ms_rank0": ev_ms(ar_ev) if has_ar else 0.0, "exchange_ms_rank0": ev_ms(xc_ev) if has_xc else 0.0,
+               "allreduce_bytes": ar_bytes, "bytes_sent_rank0": sent, "bytes_received_rank0": recvd,
+               "workspace_bytes_rank0": plan.workspace_bytes()}
+        full = plan.gather_result(Cmat)
+        torch.cuda.synchronize()
+        if rank == 0:
+            gathered[name] = full.clone()
+            rec["max_rel_err"] = sampled_error(A, B, full, n)
+        results[name] = rec
+        plan.close()
+        barrier()
+    info = {"transport": "RCCL (ncclCommInitRank inside libgemmul8.so)" if backend == "nccl" else f"gloo TEST transport, host-staged ({world} ranks on {torch.cuda.device_count()} GPU(s))",
+            "rccl_ranks": rccl_ranks}
+    headline = None
+    if rank == 0:
+        ref = gathered["moduli"]
+        results["blocks"]["mismatches_vs_moduli"] = int((gathered["blocks"] != ref).sum().item())
+        results["moduli"]["mismatches_vs_moduli"] = 0
+        results["fp64sum"]["mismatches_vs_moduli"] = int((gathered["fp64sum"] != ref).sum().item())
+        results["fp64sum"]["elements"] = int(ref.numel())
+        exact = [k_ for k_ in ("blocks", "moduli") if results[k_]["mismatches_vs_moduli"] == 0]
+        headline = max(exact, key=lambda k_: results[k_]["value"])
+    comm.close()
+    return results, headline, info
+
+
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(self_launch(args))
+    if env_world is not None and int(env_world) != args.gpus and os.environ.get("GEMMUL8_BENCH_FORCE_PLAN", "0") != "1":
+        print(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={env_world} (launch one rank per GPU, or call plain "
+              f"`python bench.py --gpus N` and let this file start the ranks)", file=sys.stderr)
+        sys.exit(2)
     if args.config == 4:
         args.size, args.moduli = 16384, 16
     elif args.config != 2:
         return run_other_config(args)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("GEMMUL8_DIST_BACKEND", "nccl") != "nccl":
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # GEMMUL8_BENCH_FORCE_PLAN=1: take the multi-GPU code path (process group, plan, barrier, max-over-ranks timing, gather) even
+    # GEMMUL8_BENCH_FORCE_PLAN=1: take the multi-GPU code path (process group, plans, barrier, max-over-ranks timing, gather) even
     # with ONE rank, so that it can be exercised on the real RCCL backend of a single-GPU box (tests/test_gpu_dist.py)
     multi = world > 1 or os.environ.get("GEMMUL8_BENCH_FORCE_PLAN", "0") == "1"
+    backend = os.environ.get("GEMMUL8_DIST_BACKEND", "nccl")
     if multi:
         import torch.distributed as dist
         # RCCL ("nccl") is the product path; GEMMUL8_DIST_BACKEND=gloo only exists to smoke-test this file with
         # several ranks sharing one GPU (host-staged exchange), where NCCL refuses duplicate devices.
-        backend = os.environ.get("GEMMUL8_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -217,167 +338,152 @@ def main():
 
     n, N = args.size, args.moduli
     A, B = make_inputs(n, dev)
-    Cmat = torch.zeros((n, n), dtype=torch.float64, device=dev)
     lib = g.lib()
     stream = torch.cuda.current_stream(dev)
+    flops = 2.0 * n ** 3
+    peak = 5000.0  # dense INT8 MFMA TOPS (MI355X_MICROARCH.md: ~5 PF-class dense FP8/INT8)
+    workload = (f"DGEMM {n}x{n}x{n}, moduli={N}, INT8 backend, {'fast' if args.fast else 'accurate'} mode "
+                f"({N + (0 if args.fast else 1)} INT8 GEMMs), op N/N, alpha=1, beta=0, inputs resident in HBM")
+
+    if multi:
+        import torch.distributed as dist
+        results, headline, info = run_plans(args, n, N, A, B, dev, stream, backend, rank, world)
+        if rank == 0:
+            h = results[headline]
+            out = {
+                "metric": f"emulated DGEMM TFLOPS (N={n}, moduli={N})", "value": h["value"], "unit": "TFLOPS", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": h["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "int8", "dtype_detail": "int8 MFMA (i32 accumulate) + f64 CRT",
+                "data": "synthetic U(-0.5,0.5), seeds 12345/54321",
+                "config": {"workload": workload, "parallelism": h["parallelism"], "headline_plan": headline,
+                           "placement": "A, B replicated on every rank; C full-size on every rank, each rank updates the block it owns"},
+                "roofline": {"bound": "mfma", "kernel": "oz2::gemm_i8_kernel<EPI_MOD> (this rank's share, batched over its moduli)",
+                             "achieved": h["gemm_achieved_TOPs_rank0"], "peak": peak, "unit": "TOP/s", "frac": h["gemm_frac_of_int8_peak_rank0"],
+                             "traffic": None, "traffic_measured_in_run": False, "launch_ms": h["gemm_launch_ms_rank0"],
+                             "ops_per_launch": h["gemm_ops_rank0"]},
+                "plans": results, "max_rel_err": h["max_rel_err"],
+                "headline_rule": "best of the plans that are bit-identical to each other (blocks, moduli); fp64sum is reported with its mismatch count",
+            }
+            out.update(info)
+            print(json.dumps(out))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    # ---------------------------------------------------------------- one GPU
+    Cmat = torch.zeros((n, n), dtype=torch.float64, device=dev)
     one = np.array([1.0])
     zero = np.array([0.0])
-    gemm_events = []
+    tot, _, _ = g.work_size(False, g.INT8, n, n, n, N)
+    work = torch.empty(tot, dtype=torch.uint8, device=dev)
+    L = g.Layout()
+    g.check(lib.gemmul8_get_layout(g.D, g.INT8, n, n, n, N, work.data_ptr(), None, None, 0, 0, C.byref(L)))
+    phase_events = []
 
-    if not multi:
-        tot, _, _ = g.work_size(False, g.INT8, n, n, n, N)
-        work = torch.empty(tot, dtype=torch.uint8, device=dev)
-        L = g.Layout()
-        g.check(lib.gemmul8_get_layout(g.D, g.INT8, n, n, n, N, work.data_ptr(), None, None, 0, 0, C.byref(L)))
-
-        phase_events = []
-
-        def step(record):
-            st = stream.cuda_stream
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
-            if not args.fast:
-                g.check(lib.gemmul8_scale_bounds(st, g.D, g.INT8, 0, 0, n, n, n, A.data_ptr(), n, B.data_ptr(), n, N, 0, n, C.byref(L), 0, 0))
-            if record:
-                ev[0].record(stream)
-            g.check(lib.gemmul8_scale_finish(st, g.D, g.INT8, 0, 0, n, n, n, A.data_ptr(), n, B.data_ptr(), n, N, int(args.fast), 0, N,
-                                             C.byref(L), 0, 0))
-            if record:
-                ev[1].record(stream)
-            g.check(lib.gemmul8_lowprec_gemm(st, g.D, g.INT8, n, n, n, N, 0, N, C.byref(L)))
-            if record:
-                ev[2].record(stream)
-                gemm_events.append((ev[1], ev[2]))
-            g.check(lib.gemmul8_crt(st, g.D, g.INT8, N, n, n, L.C_mid, L.mp, L.sizeC, L.sftA, L.sftB, one.ctypes.data,
-                                    zero.ctypes.data, Cmat.data_ptr(), n))
-            if record:
-                ev[3].record(stream)
-                phase_events.append(ev)
-        parallelism = "single-gpu"
-    else:
-        from gemmul8_amd import dist as gd
-        # The sharded path lives in C++ behind include/gemmul8_dist.h; this file only creates the transport and the plan.
-        # GEMMUL8_DIST_SHARD = blocks (default: output blocks on a rank grid, one all_reduce(MAX) of the bounds, no bulk exchange),
-        # columns (its 1 x G grid), moduli (moduli sharded, INT8 residue exchange + column-block CRT; bit-identical too) or
-        # fp64sum (moduli sharded, FP64 partial sums + reduce-scatter: the exchange north_star names; last-bit differences).
-        # Placement: A and B are REPLICATED on every rank (same seeds), every rank updates its block of a full-size C.
-        comm = gd.RcclComm() if backend == "nccl" else gd.TorchTransport(device=True)
-        plan = gd.make_plan(comm, g.D, g.INT8, n, n, n, N, fastmode=args.fast)
-        ev_pool = []
-
-        def step(record):
-            if record:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                e1.record(stream)   # creates the handles; the plan re-records both around its low-precision GEMM launch
-                plan.set_events(e0, e1)
-                gemm_events.append((e0, e1))
-            else:
-                plan.set_events(None, None)
-            plan.run(A, B, Cmat)
-        parallelism = plan.describe()
-
-    def barrier():
-        if multi:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
+    def step(record):
+        st = stream.cuda_stream
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if record else None
+        if record:
+            ev[4].record(stream)   # start of the call
+        if not args.fast:
+            g.check(lib.gemmul8_scale_bounds(st, g.D, g.INT8, 0, 0, n, n, n, A.data_ptr(), n, B.data_ptr(), n, N, 0, n, C.byref(L), 0, 0))
+        if record:
+            ev[0].record(stream)
+        g.check(lib.gemmul8_scale_finish(st, g.D, g.INT8, 0, 0, n, n, n, A.data_ptr(), n, B.data_ptr(), n, N, int(args.fast), 0, N,
+                                         C.byref(L), 0, 0))
+        if record:
+            ev[1].record(stream)
+        g.check(lib.gemmul8_lowprec_gemm(st, g.D, g.INT8, n, n, n, N, 0, N, C.byref(L)))
+        if record:
+            ev[2].record(stream)
+        g.check(lib.gemmul8_crt(st, g.D, g.INT8, N, n, n, L.C_mid, L.mp, L.sizeC, L.sftA, L.sftB, one.ctypes.data,
+                                zero.ctypes.data, Cmat.data_ptr(), n))
+        if record:
+            ev[3].record(stream)
+            phase_events.append(ev)
 
     for _ in range(args.warmup):
         step(False)
-    barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
-    barrier()
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if multi:
-        import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        Cfull = plan.gather_result(Cmat)
-    else:
-        Cfull = Cmat
 
-    if rank == 0:
-        ms = dt / args.steps * 1e3
-        flops = 2.0 * n ** 3
-        value = flops / (ms * 1e-3) * 1e-12
-        planes_here = N if not multi else plan.my_planes
-        gemm_ms = float(np.mean([a.elapsed_time(b) for a, b in gemm_events])) if gemm_events else None
-        ops = planes_here * 2.0 * n ** 3
-        if multi:
-            ops = planes_here * 2.0 * plan.work_rows * plan.work_cols * n   # this rank's share of the low-precision GEMMs
-        peak = 5000.0  # dense INT8 MFMA TOPS (MI355X_MICROARCH.md: ~5 PF-class dense FP8/INT8)
-        roof = None
-        if gemm_ms:
-            ach = ops / (gemm_ms * 1e-3) * 1e-12
-            roof = {"bound": "mfma", "kernel": "oz2::gemm_i8_kernel<EPI_MOD> (batched over moduli)", "achieved": ach, "peak": peak,
-                    "unit": "TOP/s", "frac": ach / peak, "traffic": None, "launch_ms": gemm_ms, "ops_per_launch": ops,
-                    "algorithmic_bytes_per_launch": planes_here * 3.0 * n * n if not multi else None,
-                    # measured with tools/ubench/mfma_shapes.hip (profiles/r02_mfma_shapes.txt): a register-only loop of the kernel's
-                    # instruction (v_mfma_i32_16x16x64_i8) reaches the nominal peak on all-zero operands but is limited by the 1400 W
-                    # socket cap to this on uniformly distributed residues (v_mfma_i32_32x32x32_i8: 3448)
-                    "sustained_mfma_on_residue_data_TOPs": 3969.0}
-            # HBM-side bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
-            # WRITE_SIZE, tools/pmc_traffic.py); only valid for the configuration that was profiled
-            tf = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
-            if tf and not multi and n == 8192 and N == 14:
-                recs = json.load(open(tf[-1]))
-                rec = next((v for k_, v in sorted(recs.items()) if k_.startswith("oz2::gemm_i8_kernel<0")), None)  # <EPI_MOD, schedule, ...>
-                if rec:
-                    roof["traffic"] = rec["hbm_side_bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/" + os.path.basename(tf[-1])
-        out = {
-            "metric": f"emulated DGEMM TFLOPS (N={n}, moduli={N})", "value": value, "unit": "TFLOPS", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "int8", "dtype_detail": "int8 MFMA (i32 accumulate) + f64 CRT", "data": "synthetic U(-0.5,0.5), seeds 12345/54321",
-            "config": {"workload": f"DGEMM {n}x{n}x{n}, moduli={N}, INT8 backend, {'fast' if args.fast else 'accurate'} mode "
-                                   f"({N + (0 if args.fast else 1)} INT8 GEMMs), op N/N, alpha=1, beta=0, inputs resident in HBM",
-                       "parallelism": parallelism},
-            "roofline": roof,
-        }
-        if not multi and phase_events:
-            # the HBM-bound kernels beside the GEMM (events on the launch stream inside the timed region): algorithmic bytes / time
-            # against the 8 TB/s HBM3E peak (a plain device copy reaches 4.96 TB/s on this part, tools/hbm_probe.py)
-            q_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in phase_events]))
-            c_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in phase_events]))
-            q_bytes = 2.0 * (8.0 * n * n + N * n * n)   # quantise A and B: read the FP64 operand, write N int8 planes
-            c_bytes = N * n * n + 8.0 * n * n             # CRT: read N int8 planes, write the FP64 result
-            out["secondary_kernels"] = [
-                {"kernel": "oz2::stage_strided_kernel<double,MOD> + stage_kmajor_kernel<double,MOD> (+ shift_finalize; fast mode: + the norm kernels)",
-                 "bound": "hbm", "ms": q_ms, "algorithmic_bytes": q_bytes, "achieved": q_bytes / q_ms * 1e-6, "peak": 8000.0, "unit": "GB/s",
-                 "frac": q_bytes / q_ms * 1e-6 / 8000.0},
-                {"kernel": "oz2::crt_kernel<double>", "bound": "hbm", "ms": c_ms, "algorithmic_bytes": c_bytes, "achieved": c_bytes / c_ms * 1e-6,
-                 "peak": 8000.0, "unit": "GB/s", "frac": c_bytes / c_ms * 1e-6 / 8000.0}]
-        out["max_rel_err"] = sampled_error(A, B, Cfull, n)
-        if not multi:
-            nat, Cn = native_fp64(A, B)
-            nat["max_rel_err"] = sampled_error(A, B, Cn, n)
-            out["native_fp64_dgemm_same_gpu"] = nat
-            del Cn
-            # the other mode alongside (report both; the headline above is the mode selected by --fast)
-            other = not args.fast
-            for _ in range(2):
-                g.gemm(A, B, N, fastmode=other, C_out=Cmat, work=work)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(5):
-                g.gemm(A, B, N, fastmode=other, C_out=Cmat, work=work)
-            torch.cuda.synchronize()
-            oms = (time.perf_counter() - t1) / 5 * 1e3
-            out["other_mode"] = {"mode": "fast" if other else "accurate", "value": flops / oms * 1e-9, "unit": "TFLOPS", "ms_per_step": oms,
-                                 "max_rel_err": sampled_error(A, B, Cmat, n)}
-        if not args.no_cpu and not multi:
-            out["cpu_baseline"] = cpu_baseline_port(N, args.fast)
-            out["host_blas_dgemm"] = host_blas(n)
-        print(json.dumps(out))
-    if multi:
-        import torch.distributed as dist
-        dist.barrier()
-        plan.close()
-        comm.close()
-        dist.destroy_process_group()
+    ms = dt / args.steps * 1e3
+    value = flops / (ms * 1e-3) * 1e-12
+    gemm_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in phase_events]))
+    call_ms = sorted(e[4].elapsed_time(e[3]) for e in phase_events)
+    med_ms = float(call_ms[len(call_ms) // 2] if len(call_ms) % 2 else 0.5 * (call_ms[len(call_ms) // 2 - 1] + call_ms[len(call_ms) // 2]))
+    ops = N * flops
+    ach = ops / (gemm_ms * 1e-3) * 1e-12
+    roof = {"bound": "mfma", "kernel": "oz2::gemm_i8_kernel<EPI_MOD> (batched over moduli)", "achieved": ach, "peak": peak,
+            "unit": "TOP/s", "frac": ach / peak, "traffic": None, "traffic_measured_in_run": False, "launch_ms": gemm_ms, "ops_per_launch": ops,
+            "algorithmic_bytes_per_launch": N * 3.0 * n * n,
+            # measured with tools/ubench/mfma_shapes.hip (profiles/r02_mfma_shapes.txt): a register-only loop of the kernel's
+            # instruction (v_mfma_i32_16x16x64_i8) reaches the nominal peak on all-zero operands but is limited by the 1400 W
+            # socket cap to this on uniformly distributed residues (v_mfma_i32_32x32x32_i8: 3448)
+            "sustained_mfma_on_residue_data_TOPs": 3969.0}
+    # HBM-side bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 +
+    # WRITE_SIZE, tools/pmc_traffic.py) -- a committed constant of the profiled configuration, NOT measured in this run
+    tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if tf and n == 8192 and N == 14:
+        recs = json.load(open(tf[-1]))
+        rec = next((v for k_, v in sorted(recs.items()) if k_.startswith("oz2::gemm_i8_kernel<0")), None)  # <EPI_MOD, schedule, ...>
+        if rec:
+            roof["traffic"] = rec["hbm_side_bytes_per_launch"]
+            roof["traffic_source"] = "profiles/" + os.path.basename(tf[-1])
+    out = {
+        "metric": f"emulated DGEMM TFLOPS (N={n}, moduli={N})", "value": value, "unit": "TFLOPS", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "int8", "dtype_detail": "int8 MFMA (i32 accumulate) + f64 CRT", "data": "synthetic U(-0.5,0.5), seeds 12345/54321",
+        "config": {"workload": workload, "parallelism": "single-gpu"},
+        # the reference's protocol (testing/test_flops.hpp:169-206): median of per-call event timings
+        "ms_per_step_median_of_events": med_ms, "value_median_of_events": flops / (med_ms * 1e-3) * 1e-12,
+        "roofline": roof,
+    }
+    # the HBM-bound kernels beside the GEMM (events on the launch stream inside the timed region): algorithmic bytes / time
+    # against the 8 TB/s HBM3E peak (a 16-B-per-lane streaming copy reaches ~6.3 TB/s on this part, MI355X_MICROARCH.md)
+    q_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in phase_events]))
+    c_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in phase_events]))
+    q_bytes = 2.0 * (8.0 * n * n + N * n * n)   # quantise A and B: read the FP64 operand, write N int8 planes
+    c_bytes = N * n * n + 8.0 * n * n             # CRT: read N int8 planes, write the FP64 result
+    out["secondary_kernels"] = [
+        {"kernel": "oz2 quantise pair: A (row-strided) + B (K-major), <double,MOD> (+ shift_finalize; fast mode: + the norm kernels)",
+         "bound": "hbm", "ms": q_ms, "algorithmic_bytes": q_bytes, "achieved": q_bytes / q_ms * 1e-6, "peak": 8000.0, "unit": "GB/s",
+         "frac": q_bytes / q_ms * 1e-6 / 8000.0},
+        {"kernel": "oz2::crt_kernel<double>", "bound": "hbm", "ms": c_ms, "algorithmic_bytes": c_bytes, "achieved": c_bytes / c_ms * 1e-6,
+         "peak": 8000.0, "unit": "GB/s", "frac": c_bytes / c_ms * 1e-6 / 8000.0}]
+    if not args.fast:
+        b_ms = float(np.mean([e[4].elapsed_time(e[0]) for e in phase_events]))
+        b_bytes = 3.0 * 8.0 * n * n + 2.0 * n * n   # A read twice (amax, extract), B once; two 1-byte bound planes written
+        out["secondary_kernels"].append(
+            {"kernel": "accurate-mode bounds phase: amax + extract (A, B) + bound GEMM (1 INT8 GEMM) + zeroing", "bound": "hbm + mfma",
+             "ms": b_ms, "algorithmic_bytes": b_bytes, "lowprec_ops": flops})
+    out["phase_ms"] = {"bounds": float(np.mean([e[4].elapsed_time(e[0]) for e in phase_events])) if not args.fast else 0.0,
+                       "quantise": q_ms, "lowprec_gemm": gemm_ms, "crt": c_ms}
+    out["max_rel_err"] = sampled_error(A, B, Cmat, n)
+    nat, Cn = native_fp64(A, B)
+    nat["max_rel_err"] = sampled_error(A, B, Cn, n)
+    out["native_fp64_dgemm_same_gpu"] = nat
+    del Cn
+    # the other mode alongside (report both; the headline above is the mode selected by --fast)
+    other = not args.fast
+    for _ in range(2):
+        g.gemm(A, B, N, fastmode=other, C_out=Cmat, work=work)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        g.gemm(A, B, N, fastmode=other, C_out=Cmat, work=work)
+    torch.cuda.synchronize()
+    oms = (time.perf_counter() - t1) / 5 * 1e3
+    out["other_mode"] = {"mode": "fast" if other else "accurate", "value": flops / oms * 1e-9, "unit": "TFLOPS", "ms_per_step": oms,
+                         "max_rel_err": sampled_error(A, B, Cmat, n)}
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline_port(N, args.fast)
+        out["host_blas_dgemm"] = host_blas(n)
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -9,6 +9,9 @@
 //   C  = AB | C+AB | -AB | C-AB  for host scalars alpha=+-1, beta in {0,1};
 //        otherwise fma(beta, C, alpha*AB) (complex: nested fma order of template_math.hpp:61-75);
 //   device-pointer scalars always take the general form (inverse_scaling_real.hpp:211-216).
+//   beta == 0 in the general form: C is NOT read and enters the fma as +0 (BLAS semantics -- the hook serves callers such as
+//   torch.baddbmm(torch.empty(..), beta=0) whose C holds NaN garbage; the reference evaluates fma(0, C, alpha*AB), the same value for
+//   every finite C except the sign of an exact zero when C < 0).
 // Each thread handles ROWS consecutive rows of one column (8 bytes of every residue plane: 8 / 4 / 4 / 2 rows): one vector load per residue plane, all
 // N loads issued before the first use (the plane loop is fully unrolled over the 20-moduli maximum with a uniform guard).
 #include <hip/hip_runtime.h>
@@ -90,7 +93,8 @@ __global__ void __launch_bounds__(OZ2_CRT_BLOCK) crt_kernel(const CrtArgs a) {
     const int sB = (int)((const int16_t*)((const char*)a.sftB + zw))[col];
     U* Cc = (U*)((char*)a.C + blockIdx.z * a.bc) + (col * a.ldc) * COMPS;
     const bool full = i0 + ROWS <= a.m;  // all ROWS rows exist: the old and new C values move as one vector per thread
-    const bool reads_c = mode == 0 || mode == 2 || mode == 4;
+    const bool beta0 = be[0] == (U)0 && (!CPLX || be[1] == (U)0);
+    const bool reads_c = (mode == 0 && !beta0) || mode == 2 || mode == 4;
     U oldc[NV], outv[NV];
 #pragma unroll
     for (int e = 0; e < NV; ++e) oldc[e] = (U)0;
@@ -220,7 +224,8 @@ __global__ void __launch_bounds__(256) crt_finish_kernel(const CrtArgs a, const 
     U* Cc = (U*)a.C + (col * a.ldc + row) * COMPS;
     const double* ph = in_hi + (col * ld_in + row) * COMPS;
     const double* pl = in_lo + (col * ld_in + row) * COMPS;
-    const bool reads_c = mode == 0 || mode == 2 || mode == 4;
+    const bool beta0 = be[0] == (U)0 && (!CPLX || be[1] == (U)0);
+    const bool reads_c = (mode == 0 && !beta0) || mode == 2 || mode == 4;
     if constexpr (!CPLX) {
         const U AB = scalb<U>((U)crt_reduce(a, ph[0], pl[0]), sft);
         const U old = reads_c ? Cc[0] : (U)0;

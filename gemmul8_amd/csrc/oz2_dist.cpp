@@ -39,6 +39,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;  // optional: read-back of the communicator size
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -83,6 +84,7 @@ const Rccl& rccl() {
         OZ2_SYM(GetUniqueId, "ncclGetUniqueId");
         OZ2_SYM(CommInitRank, "ncclCommInitRank");
         OZ2_SYM(CommDestroy, "ncclCommDestroy");
+        OZ2_SYM(CommCount, "ncclCommCount");
         OZ2_SYM(AllReduce, "ncclAllReduce");
         OZ2_SYM(ReduceScatter, "ncclReduceScatter");
         OZ2_SYM(Send, "ncclSend");
@@ -155,42 +157,81 @@ bool recv_all(int fd, void* p, size_t n) {
     return true;
 }
 
-int exchange_id_tcp(const char* addr, int port, int rank, int world, ncclUniqueId* id) {
-    if (rank == 0) {
-        int ls = ::socket(AF_INET, SOCK_STREAM, 0);
-        if (ls < 0) return GEMMUL8_E_ARG;
-        int one = 1;
-        setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
-        sockaddr_in sa{};
-        sa.sin_family = AF_INET;
-        sa.sin_addr.s_addr = htonl(INADDR_ANY);
-        sa.sin_port = htons((uint16_t)port);
-        if (::bind(ls, (sockaddr*)&sa, sizeof sa) != 0 || ::listen(ls, world) != 0) {
-            std::fprintf(stderr, "[GEMMUL8 DIST] cannot listen on port %d\n", port);
-            ::close(ls);
-            return GEMMUL8_E_ARG;
-        }
-        bool ok = true;
-        for (int i = 1; i < world && ok; ++i) {
-            const int fd = ::accept(ls, nullptr, nullptr);
-            ok = fd >= 0 && send_all(fd, id, sizeof *id);
-            if (fd >= 0) ::close(fd);
-        }
-        ::close(ls);
-        return ok ? 0 : GEMMUL8_E_ARG;
-    }
+// Rank 0 listens on MASTER_ADDR only (not INADDR_ANY), every client introduces itself with a 16-byte hello {magic, rank, world,
+// nonce = MASTER_PORT} before it is handed the id, each rank is served once, and every accept / recv has a deadline: a stray
+// connection (port scanner, another job's retry) is dropped instead of starving a real rank, and a missing rank ends in an error
+// message after GEMMUL8_DIST_TIMEOUT seconds (default 120) instead of a silent hang inside ncclCommInitRank.
+struct IdHello {
+    uint32_t magic, rank, world, nonce;
+};
+constexpr uint32_t kHelloMagic = 0x384c5547u;  // "GUL8"
+void set_io_timeout(int fd, int seconds) {
+    timeval tv{};
+    tv.tv_sec = seconds;
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+    setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+}
+int rendezvous_timeout_s() {
+    const char* s = std::getenv("GEMMUL8_DIST_TIMEOUT");
+    const int v = s ? std::atoi(s) : 0;
+    return v > 0 ? v : 120;
+}
+
+int exchange_id_tcp(const char* addr, int port, int rank, int world, uint32_t nonce, ncclUniqueId* id) {
     addrinfo hints{}, *res = nullptr;
     hints.ai_family = AF_INET;
     hints.ai_socktype = SOCK_STREAM;
     const std::string ports = std::to_string(port);
-    if (getaddrinfo(addr, ports.c_str(), &hints, &res) != 0 || !res) return GEMMUL8_E_ARG;
-    int rc = GEMMUL8_E_ARG;
-    for (int attempt = 0; attempt < 600 && rc; ++attempt) {  // rank 0 may not be listening yet: retry for up to 60 s
-        const int fd = ::socket(AF_INET, SOCK_STREAM, 0);
-        if (fd < 0) break;
-        if (::connect(fd, res->ai_addr, res->ai_addrlen) == 0 && recv_all(fd, id, sizeof *id)) rc = 0;
-        ::close(fd);
-        if (rc) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    if (getaddrinfo(addr, ports.c_str(), &hints, &res) != 0 || !res) {
+        std::fprintf(stderr, "[GEMMUL8 DIST] cannot resolve MASTER_ADDR %s\n", addr);
+        return GEMMUL8_E_ARG;
+    }
+    const int limit = rendezvous_timeout_s();
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(limit);
+    int rc = GEMMUL8_E_INTERNAL;
+    if (rank == 0) {
+        int ls = ::socket(AF_INET, SOCK_STREAM, 0);
+        int one = 1;
+        if (ls >= 0) setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+        if (ls < 0 || ::bind(ls, res->ai_addr, res->ai_addrlen) != 0 || ::listen(ls, world) != 0) {
+            std::fprintf(stderr, "[GEMMUL8 DIST] cannot listen on %s:%d\n", addr, port);
+            if (ls >= 0) ::close(ls);
+            freeaddrinfo(res);
+            return GEMMUL8_E_INTERNAL;
+        }
+        std::vector<char> served((size_t)world, 0);
+        int left = world - 1;
+        while (left > 0) {
+            const auto now = std::chrono::steady_clock::now();
+            if (now >= deadline) break;
+            timeval tv{};
+            tv.tv_sec = (long)std::chrono::duration_cast<std::chrono::seconds>(deadline - now).count() + 1;
+            setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);  // bounds accept()
+            const int fd = ::accept(ls, nullptr, nullptr);
+            if (fd < 0) continue;  // timeout or a transient error: the deadline check ends the loop
+            set_io_timeout(fd, 5);
+            IdHello h{};
+            if (recv_all(fd, &h, sizeof h) && h.magic == kHelloMagic && h.world == (uint32_t)world && h.nonce == nonce && h.rank >= 1 &&
+                h.rank < (uint32_t)world && !served[h.rank] && send_all(fd, id, sizeof *id)) {
+                served[h.rank] = 1;
+                --left;
+            }
+            ::close(fd);
+        }
+        ::close(ls);
+        if (left == 0) rc = 0;
+        else std::fprintf(stderr, "[GEMMUL8 DIST] id rendezvous: %d of %d ranks did not connect to %s:%d within %d s\n", left, world - 1, addr, port, limit);
+    } else {
+        const IdHello h{kHelloMagic, (uint32_t)rank, (uint32_t)world, nonce};
+        while (rc && std::chrono::steady_clock::now() < deadline) {  // rank 0 may not be listening yet: retry until the deadline
+            const int fd = ::socket(AF_INET, SOCK_STREAM, 0);
+            if (fd < 0) break;
+            set_io_timeout(fd, 5);
+            if (::connect(fd, res->ai_addr, res->ai_addrlen) == 0 && send_all(fd, &h, sizeof h) && recv_all(fd, id, sizeof *id)) rc = 0;
+            ::close(fd);
+            if (rc) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        }
+        if (rc) std::fprintf(stderr, "[GEMMUL8 DIST] id rendezvous: rank %d got no id from %s:%d within %d s\n", rank, addr, port, limit);
     }
     freeaddrinfo(res);
     return rc;
@@ -266,6 +307,10 @@ struct gemmul8_dist_plan {
     double* red = nullptr;   //          [hi | lo][cw][mp] reduced block of this rank
     size_t cw = 0, blk = 0;
     void *ev_begin = nullptr, *ev_end = nullptr;  // optional hipEvent_t pair recorded around the low-precision GEMM launch
+    void* ev_x[4] = {nullptr, nullptr, nullptr, nullptr};  // optional: around the bounds all-reduce / around the bulk exchange
+    void mark(int i, void* stream) const {
+        if (ev_x[i] && hip_engine) (void)hipEventRecord((hipEvent_t)ev_x[i], (hipStream_t)stream);
+    }
     bool hip_engine = true;
     bool part_clean = false;  // the padding columns of `part` (world * cw > n) are zeroed once, on the first call's stream
     char* stage_send = nullptr;  // allgather_c staging (allocated on first use)
@@ -331,10 +376,11 @@ int gemmul8_comm_rccl_id_from_env(void* id128, int* rank_out, int* world_out) {
         const char* sport = std::getenv("GEMMUL8_DIST_PORT");
         int port = sport ? std::atoi(sport) : 0;
         if (!port) {
-            const char* mp = std::getenv("MASTER_PORT");
-            port = (mp ? std::atoi(mp) : 29500) + 17;
+            const char* mp0 = std::getenv("MASTER_PORT");
+            port = (mp0 ? std::atoi(mp0) : 29500) + 17;
         }
-        OZ2_RC(exchange_id_tcp(addr ? addr : "127.0.0.1", port, rank, world, &id));
+        const char* mp = std::getenv("MASTER_PORT");
+        OZ2_RC(exchange_id_tcp(addr ? addr : "127.0.0.1", port, rank, world, (uint32_t)(mp ? std::atoi(mp) : 29500), &id));
     }
     std::memcpy(id128, &id, sizeof id);
     if (rank_out) *rank_out = rank;
@@ -348,6 +394,13 @@ int gemmul8_comm_rccl_from_env(gemmul8_comm** out) {
     int rank = 0, world = 1;
     OZ2_RC(gemmul8_comm_rccl_id_from_env(&id, &rank, &world));
     return gemmul8_comm_rccl_create(&id, rank, world, out);
+}
+
+int gemmul8_comm_rccl_count(const gemmul8_comm* comm, int* count) {
+    if (!comm || !count) return GEMMUL8_E_ARG;
+    *count = -1;
+    if (comm->destroy != rccl_destroy || !rccl().CommCount) return GEMMUL8_OK;
+    return nccl_status(rccl().CommCount(static_cast<RcclCtx*>(comm->ctx)->comm, count), "ncclCommCount");
 }
 
 void gemmul8_comm_destroy(gemmul8_comm* comm) {
@@ -417,9 +470,10 @@ int gemmul8_dist_create(const gemmul8_comm* comm, const gemmul8_dist_engine* eng
         P->red = world > 1 ? (double*)P->alloc(P->blk * 8) : nullptr;
         ok = P->part && (world == 1 || P->red);
     }
-    if (!ok) {
+    if (!ok) {  // the arguments were valid: what failed is an allocation (or the layout of an allocated workspace)
+        std::fprintf(stderr, "[GEMMUL8 DIST] rank %d: plan workspace allocation failed (%zu bytes held so far)\n", rank, P->bytes);
         gemmul8_dist_destroy(P);
-        return GEMMUL8_E_ARG;
+        return GEMMUL8_E_INTERNAL;
     }
     *out = P;
     return GEMMUL8_OK;
@@ -437,6 +491,35 @@ size_t gemmul8_dist_workspace_bytes(const gemmul8_dist_plan* P) { return P ? P->
 int gemmul8_dist_set_events(gemmul8_dist_plan* P, void* ev_begin, void* ev_end) {
     if (!P) return GEMMUL8_E_ARG;
     P->ev_begin = ev_begin, P->ev_end = ev_end;
+    return GEMMUL8_OK;
+}
+
+int gemmul8_dist_set_exchange_events(gemmul8_dist_plan* P, void* const ev[4]) {
+    if (!P) return GEMMUL8_E_ARG;
+    for (int i = 0; i < 4; ++i) P->ev_x[i] = ev ? ev[i] : nullptr;
+    return GEMMUL8_OK;
+}
+
+int gemmul8_dist_exchange_bytes(const gemmul8_dist_plan* P, size_t* allreduce_bytes, size_t* sent, size_t* received) {
+    if (!P) return GEMMUL8_E_ARG;
+    const int world = P->comm.world, rank = P->comm.rank;
+    size_t ar = 0, tx = 0, rx = 0;
+    if (world > 1) {
+        if (!P->fast) ar = P->kind == GEMMUL8_DIST_BLOCKS ? 4 * (P->m + P->n) : 4 * (P->L.mp + pad256(P->n));
+        if (P->kind == GEMMUL8_DIST_MODULI) {
+            for (int s = 0; s < world; ++s) {
+                if (s == rank) continue;
+                tx += P->mods.size() * P->cols_of(s).size() * P->L.mp * P->mid;
+                rx += split_range(P->N, world, s).size() * P->cols.size() * P->L.mp * P->mid;
+            }
+        } else if (P->kind == GEMMUL8_DIST_MODULI_FP64SUM) {
+            tx = (size_t)(world - 1) * P->blk * 8;  // every other rank's block of this rank's partial sums
+            rx = (size_t)(world - 1) * P->blk * 8;  // the other ranks' partials of this rank's block
+        }
+    }
+    if (allreduce_bytes) *allreduce_bytes = ar;
+    if (sent) *sent = tx;
+    if (received) *received = rx;
     return GEMMUL8_OK;
 }
 
@@ -487,7 +570,9 @@ int gemmul8_dist_gemm(gemmul8_dist_plan* P, void* stream, const void* alpha, con
                     OZ2_RC(E.copy(P->mx + P->rows.b, rowmax, 4 * P->em, stream));
                     OZ2_RC(E.copy(P->mx + P->m + P->cols.b, colmax, 4 * P->en, stream));
                 }
+                P->mark(0, stream);
                 OZ2_RC(X.allreduce_max_i32(X.ctx, P->mx, P->m + P->n, stream));
+                P->mark(1, stream);
                 if (P->have) {
                     OZ2_RC(E.copy(rowmax, P->mx + P->rows.b, 4 * P->em, stream));
                     OZ2_RC(E.copy(colmax, P->mx + P->m + P->cols.b, 4 * P->en, stream));
@@ -507,7 +592,11 @@ int gemmul8_dist_gemm(gemmul8_dist_plan* P, void* stream, const void* alpha, con
     const unsigned t0 = (unsigned)P->mods.b, t1 = (unsigned)P->mods.e;
     if (!P->fast) {
         OZ2_RC(E.scale_bounds(stream, P->dtype, P->backend, P->opA, P->opB, P->m, P->n, P->k, A, lda, B, ldb, N, P->cols.b, P->cols.e, L, 0, 0));
-        if (world > 1) OZ2_RC(X.allreduce_max_i32(X.ctx, L->scratch, mp + np_, stream));
+        if (world > 1) {
+            P->mark(0, stream);
+            OZ2_RC(X.allreduce_max_i32(X.ctx, L->scratch, mp + np_, stream));
+            P->mark(1, stream);
+        }
     }
     OZ2_RC(E.scale_finish(stream, P->dtype, P->backend, P->opA, P->opB, P->m, P->n, P->k, A, lda, B, ldb, N, P->fast, t0, t1, L, 0, 0));
     if (P->ev_begin && P->hip_engine) (void)hipEventRecord((hipEvent_t)P->ev_begin, (hipStream_t)stream);
@@ -533,7 +622,11 @@ int gemmul8_dist_gemm(gemmul8_dist_plan* P, void* stream, const void* alpha, con
                 ops.push_back({(void*)(Cmid + (t * L->sizeC + sc.b * mp) * mid), sc.size() * mp * mid, s, 1});
             for (size_t t = st.b; t < st.e && ncols; ++t) ops.push_back({P->recv + t * slot, slot, s, 0});
         }
-        if (world > 1) OZ2_RC(X.sendrecv(X.ctx, (int)ops.size(), ops.data(), stream));
+        if (world > 1) {
+            P->mark(2, stream);
+            OZ2_RC(X.sendrecv(X.ctx, (int)ops.size(), ops.data(), stream));
+            P->mark(3, stream);
+        }
         if (!ncols) return GEMMUL8_OK;
         return E.crt(stream, P->dtype, P->backend, N, P->m, ncols, P->recv, mp, ncols * mp, L->sftA, L->sftB + P->cols.b, alpha, beta, Cs, ldc);
     }
@@ -548,7 +641,9 @@ int gemmul8_dist_gemm(gemmul8_dist_plan* P, void* stream, const void* alpha, con
                          P->part + half, mp, P->cw, P->blk));
     const double* red = P->part;
     if (world > 1) {
+        P->mark(2, stream);
         OZ2_RC(X.reduce_scatter_sum_f64(X.ctx, P->part, P->red, P->blk, stream));
+        P->mark(3, stream);
         red = P->red;
     }
     if (!ncols) return GEMMUL8_OK;
@@ -569,7 +664,7 @@ int gemmul8_dist_allgather_c(gemmul8_dist_plan* P, void* stream, void* C, size_t
             if (s != X.rank) others += P->rows_of(s).size() * P->cols_of(s).size() * esz;
         P->stage_send = (char*)P->alloc(std::max<size_t>(mine, 1));
         P->stage_recv = (char*)P->alloc(std::max<size_t>(others, 1));
-        if (!P->stage_send || !P->stage_recv) return GEMMUL8_E_ARG;
+        if (!P->stage_send || !P->stage_recv) return GEMMUL8_E_INTERNAL;
     }
     std::vector<gemmul8_p2p_op> ops;
     const size_t my_bytes = P->rows.size() * P->cols.size() * esz;

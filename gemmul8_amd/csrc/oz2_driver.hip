@@ -66,7 +66,14 @@ static bool scalars_on_device(const void* alpha);
 
 extern "C" {
 
-const char* gemmul8_version(void) { return "gemmul8-mi355x 0.2 (gfx950; v_mfma_i32_16x16x64_i8 / v_mfma_scale_f32_16x16x128_f8f6f4, fused epilogues)"; }
+int gemmul8_set_fp8_bound_mode(int mode) {
+    if (mode != 0 && mode != 1) return GEMMUL8_E_ARG;
+    const int old = get_f8_bound_mode();
+    set_f8_bound_mode(mode);
+    return old;
+}
+
+const char* gemmul8_version(void) { return "gemmul8-mi355x 0.3 (gfx950; v_mfma_i32_16x16x64_i8 / v_mfma_scale_f32_16x16x128_f8f6f4, fused epilogues)"; }
 
 size_t gemmul8_work_size(int is_complex, int backend, size_t m, size_t n, size_t k, unsigned N, int enA, int enB, size_t* wA,
                          size_t* wB) {

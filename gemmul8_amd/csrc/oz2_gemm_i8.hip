@@ -35,8 +35,9 @@
 //      RAW: the producers' vmcnt wait + barrier closes slot 8g+7; wm=0's L0(g+1) opens slot 8g+8.
 //  * Workgroup -> tile mapping is XCD-aware and chunked (oz2_gemm_common.hpp): the 32 CUs of an XCD share 8+4 operand
 //    panels through their L2 (measured TCC hit rate 81 %) and all XCDs work on one plane, so misses land in the Infinity Cache.
-//  * Cost split measured with real-data probes (OZ2_PROBE_LDS): MFMA + barriers alone run at the board's
-//    power-limited 3.3-3.4 POP/s; the L2 -> LDS operand path costs 12 %, the epilogue 6 %, the LDS reads 4 %.
+//  * Cost split measured with real-data probes (OZ2_PROBE_LDS; 16x16x64 kernel, k = 8192): the board's
+//    power-limited ceiling for this instruction on residue data is 3.97 POP/s, MFMA + barriers alone reach 93 % of it; the
+//    L2 -> LDS operand path costs 13 %, the per-segment barriers 7 %, the epilogue 6 %, the LDS reads 5 %.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -55,6 +55,7 @@ struct Abi {
     decltype(&::gemmul8_dist_gemm) dist_gemm = nullptr;
     decltype(&::gemmul8_dist_allgather_c) dist_allgather_c = nullptr;
     decltype(&::gemmul8_dist_destroy) dist_destroy = nullptr;
+    decltype(&::gemmul8_set_fp8_bound_mode) set_fp8_bound_mode = nullptr;
 };
 const Abi& abi() {
     static const Abi a = [] {
@@ -93,7 +94,8 @@ const Abi& abi() {
         r.dist_gemm = (decltype(r.dist_gemm))dlsym(h, "gemmul8_dist_gemm");
         r.dist_allgather_c = (decltype(r.dist_allgather_c))dlsym(h, "gemmul8_dist_allgather_c");
         r.dist_destroy = (decltype(r.dist_destroy))dlsym(h, "gemmul8_dist_destroy");
-        if (!r.work_size || !r.gemm || !r.work_size_batched || !r.gemm_batched || !r.add_row_bias || !r.comm_from_env || !r.dist_create || !r.dist_gemm || !r.dist_allgather_c || !r.dist_destroy) {
+        r.set_fp8_bound_mode = (decltype(r.set_fp8_bound_mode))dlsym(h, "gemmul8_set_fp8_bound_mode");
+        if (!r.work_size || !r.gemm || !r.work_size_batched || !r.gemm_batched || !r.add_row_bias || !r.comm_from_env || !r.dist_create || !r.dist_gemm || !r.dist_allgather_c || !r.dist_destroy || !r.set_fp8_bound_mode) {
             std::fprintf(stderr, "[GEMMUL8 HOOK] libgemmul8.so lacks the C ABI entry points\n");
             std::abort();
         }
@@ -112,6 +114,7 @@ const Abi& abi() {
 #define gemmul8_dist_gemm abi().dist_gemm
 #define gemmul8_dist_allgather_c abi().dist_allgather_c
 #define gemmul8_dist_destroy abi().dist_destroy
+#define gemmul8_set_fp8_bound_mode abi().set_fp8_bound_mode
 #endif
 
 namespace {
@@ -148,6 +151,7 @@ struct HandleState {
     hipStream_t last_stream = nullptr;
     hipEvent_t last_event = nullptr;
     bool have_stream = false;
+    bool is_lt = false;  // the key is a hipblasLtHandle_t: it has no stream of its own and must never reach hipblasGetStream
     BatchLane lanes[kMaxBatchLanes];  // lane 0 unused (= the handle's stream and buffers)
     hipEvent_t fork = nullptr;
 };
@@ -200,6 +204,10 @@ size_t g_maxA = 0, g_maxB = 0, g_maxC = 0;
 std::once_flag g_max_once;
 void init_max_workspace() {
     std::call_once(g_max_once, [] {
+        // GEMMUL8_FP8_BOUND=reference (this build only): the reference's (k+1)*2^-24 inflation of the FP8 bound GEMM instead of the
+        // engine-safe default (include/gemmul8_c.h, gemmul8_set_fp8_bound_mode)
+        if (const char* fb = std::getenv("GEMMUL8_FP8_BOUND"))
+            if (!std::strcmp(fb, "reference")) (void)gemmul8_set_fp8_bound_mode(1);
         const size_t mm = env_u64("GEMMUL8_MAX_M", 0), mn = env_u64("GEMMUL8_MAX_N", 0), mk = env_u64("GEMMUL8_MAX_K", 0);
         const unsigned mmod = (unsigned)env_u64("GEMMUL8_MAX_NUM_MOD", 2);
         const bool cplx = env_u64("GEMMUL8_NUM_MOD_Z", 0) > 0 || env_u64("GEMMUL8_NUM_MOD_C", 0) > 0;
@@ -311,11 +319,19 @@ struct DistKey {
                k == o.k && N == o.N;
     }
 };
+// One communicator and one plan cache serve every handle and stream of the process, so the sharded calls are CHAINED: each call
+// records `tail` on its stream when its last operation is enqueued and the next call -- on whatever stream -- first makes its
+// stream wait for it.  Two handles / streams issuing same-shape GEMMs therefore never overlap on a plan's workspaces, and the RCCL
+// operations of the one communicator execute in the order they were enqueued (mtx gives the enqueue order; every rank of an SPMD
+// job issues the same sequence).
 struct DistState {
     std::mutex mtx;
     gemmul8_comm* comm = nullptr;
     bool failed = false;
     std::vector<std::pair<DistKey, gemmul8_dist_plan*>> plans;  // most recently used last; at most 8
+    hipEvent_t tail = nullptr;      // completion of the most recent sharded call
+    hipStream_t tail_stream = nullptr;
+    bool have_tail = false;
 };
 DistState g_dist;
 
@@ -327,7 +343,11 @@ int dist_kind_from_env() {
     return GEMMUL8_DIST_BLOCKS;  // "1", "blocks"
 }
 
-// returns true when the sharded path took the call (status in *status); false -> single-GPU emulation
+// returns true when the sharded path took the call (status in *status); false -> single-GPU emulation.
+// Falling back is only safe when EVERY rank takes the same decision, i.e. for reasons that are a function of the call's arguments
+// and the environment (negative GEMMUL8_E_ARG / _NUM_MODULI / _UNSUPPORTED from plan creation, no communicator at all).  A
+// resource failure on one rank (GEMMUL8_E_INTERNAL: allocation, transport) is reported as HIPBLAS_STATUS_INTERNAL_ERROR instead: a
+// rank that silently computed alone would leave its peers waiting in a collective.
 bool try_dist(int kind, int dtype, int backend, hipblasOperation_t ta, hipblasOperation_t tb, int m, int n, int k, const void* alpha, const void* A,
               int lda, const void* B, int ldb, const void* beta, void* C, int ldc, unsigned N, bool fastmode, hipStream_t stream,
               hipblasStatus_t* status) {
@@ -336,12 +356,17 @@ bool try_dist(int kind, int dtype, int backend, hipblasOperation_t ta, hipblasOp
     if (!g_dist.comm) {
         const int rc = gemmul8_comm_rccl_from_env(&g_dist.comm);
         if (rc != 0 || !g_dist.comm) {
+            // decided before any collective has been issued; ncclCommInitRank itself fails on every rank when one is missing
             std::fprintf(stderr, "[GEMMUL8 HOOK] GEMMUL8_DIST is set but no RCCL communicator could be created (status %d; RANK/WORLD_SIZE/"
                                  "MASTER_ADDR/MASTER_PORT?): single-GPU emulation\n", rc);
             g_dist.failed = true;
             return false;
         }
     }
+    if (!g_dist.tail && hipEventCreateWithFlags(&g_dist.tail, hipEventDisableTiming) != hipSuccess) return *status = HIPBLAS_STATUS_INTERNAL_ERROR, true;
+    // chain behind the previous sharded call (any handle, any stream)
+    if (g_dist.have_tail && g_dist.tail_stream != stream && hipStreamWaitEvent(stream, g_dist.tail, 0) != hipSuccess)
+        return *status = HIPBLAS_STATUS_INTERNAL_ERROR, true;
     const DistKey key{kind, dtype, backend, (int)ta, (int)tb, fastmode ? 1 : 0, (size_t)m, (size_t)n, (size_t)k, N};
     gemmul8_dist_plan* plan = nullptr;
     for (size_t i = 0; i < g_dist.plans.size(); ++i)
@@ -352,17 +377,25 @@ bool try_dist(int kind, int dtype, int backend, hipblasOperation_t ta, hipblasOp
         }
     if (!plan) {
         if (g_dist.plans.size() >= 8) {  // plans own workspaces of the problem's size: keep only a few
-            (void)hipStreamSynchronize(stream);
+            // every earlier sharded call is an ancestor of `tail`: once it has completed no stream still uses the evicted plan
+            if (g_dist.have_tail && hipEventSynchronize(g_dist.tail) != hipSuccess) (void)hipDeviceSynchronize();
             gemmul8_dist_destroy(g_dist.plans.front().second);
             g_dist.plans.erase(g_dist.plans.begin());
         }
         const int rc = gemmul8_dist_create(g_dist.comm, nullptr, kind, 0, dtype, backend, (int)ta, (int)tb, (size_t)m, (size_t)n, (size_t)k, N,
                                            fastmode ? 1 : 0, &plan);
-        if (rc != 0 || !plan) return false;  // outside the emulator's range etc.: let the single-GPU path decide
+        if (rc == GEMMUL8_E_INTERNAL || rc > 0 || (rc == 0 && !plan)) {
+            std::fprintf(stderr, "[GEMMUL8 HOOK] GEMMUL8_DIST: creating the plan failed on this rank (status %d): returning an error (the other "
+                                 "ranks are entering the collective)\n", rc);
+            return *status = HIPBLAS_STATUS_INTERNAL_ERROR, true;
+        }
+        if (rc != 0) return false;  // a property of the arguments (outside the emulator's range): every rank declines alike
         g_dist.plans.emplace_back(key, plan);
     }
     int rc = gemmul8_dist_gemm(plan, stream, alpha, A, (size_t)lda, B, (size_t)ldb, beta, C, (size_t)ldc);
     if (rc == 0) rc = gemmul8_dist_allgather_c(plan, stream, C, (size_t)ldc);
+    if (hipEventRecord(g_dist.tail, stream) == hipSuccess) g_dist.tail_stream = stream, g_dist.have_tail = true;
+    else rc = rc ? rc : 1;
     *status = rc == 0 ? HIPBLAS_STATUS_SUCCESS : HIPBLAS_STATUS_INTERNAL_ERROR;
     return true;
 }
@@ -384,6 +417,7 @@ bool try_emulate(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, hipbl
 
     auto sp = state_of(handle);
     std::lock_guard<std::mutex> lk(sp->mtx);
+    if (explicit_stream) sp->is_lt = true;
     init_max_workspace();
     hipblasStatus_t st = HIPBLAS_STATUS_SUCCESS;
     hipStream_t stream = explicit_stream ? *explicit_stream : handle_stream(handle, &st);
@@ -442,7 +476,8 @@ bool try_emulate(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, hipbl
     return *status = HIPBLAS_STATUS_SUCCESS, true;
 }
 
-void release_state(hipblasHandle_t handle) {
+// lt: the key is a hipblasLtHandle_t (hipblasLtDestroy) -- hipblasGetStream on such an object would be a type confusion
+void release_state(hipblasHandle_t handle, bool lt = false) {
     std::shared_ptr<HandleState> sp;
     {
         std::lock_guard<std::mutex> g(g_map_mtx);
@@ -455,7 +490,7 @@ void release_state(hipblasHandle_t handle) {
     hipStream_t stream = nullptr;
     bool have = sp->have_stream;
     if (have) stream = sp->last_stream;
-    else {
+    else if (!lt && !sp->is_lt) {
         hipblasStatus_t st;
         stream = handle_stream(handle, &st);
         have = (st == HIPBLAS_STATUS_SUCCESS);
@@ -647,6 +682,7 @@ static bool emulate_batch(int dtype, size_t elem, hipblasHandle_t handle, hipbla
             const bool fastmode = env_one(ti.fast);
             auto sp = state_of(handle);
             std::lock_guard<std::mutex> lk(sp->mtx);
+            if (explicit_stream) sp->is_lt = true;
             init_max_workspace();
             hipblasStatus_t st = HIPBLAS_STATUS_SUCCESS;
             hipStream_t stream = explicit_stream ? *explicit_stream : handle_stream(handle, &st);
@@ -715,8 +751,10 @@ static bool emulate_batch(int dtype, size_t elem, hipblasHandle_t handle, hipbla
         const int l = b % lanes;
         if (l == 0) {
             const bool done = try_emulate(dtype, handle, ta, tb, m, n, k, alpha, Ai, lda, Bi, ldb, beta, Ci, ldc, &st, explicit_stream);
-            if (!done) return *status = HIPBLAS_STATUS_INTERNAL_ERROR, true;
-            if (st != HIPBLAS_STATUS_SUCCESS) return *status = st, true;
+            if (!done || st != HIPBLAS_STATUS_SUCCESS) {  // stop issuing items; the forked lanes are still joined below
+                *status = done ? st : HIPBLAS_STATUS_INTERNAL_ERROR;
+                break;
+            }
         } else {
             std::lock_guard<std::mutex> lk(sp->mtx);
             BatchLane& ln = sp->lanes[l];
@@ -883,8 +921,9 @@ bool lt_try(hipblasLtHandle_t handle, hipblasLtMatmulDesc_t desc, const void* al
     const unsigned long long floor_flops = env_u64("GEMMUL8_MIN_FLOPS", 0);
     if (floor_flops && 2.0 * (double)m * (double)n * (double)k < (double)floor_flops) return false;
     if (k > (1u << 17) || (env_backend("GEMMUL8_BACKEND", 0, false) == 1 && k > 65536)) return false;  // outside the emulator's range
-    // C is not read when the host scalars are beta = 0 and alpha = +-1 (the CRT's "C = +-AB" forms; every other form reads it, as the
-    // reference's does, inverse_scaling_real.hpp:171-187): then the out-of-place form needs no copy of C into D
+    // C is not read when the host scalar beta is 0 (the CRT's "C = +-AB" forms and its general form with beta == 0, oz2_crt.hip): then
+    // the out-of-place form needs no copy of C into D.  Device scalars: beta is unknown here, C is copied (the kernel still skips
+    // reading it when *beta == 0).
     bool c_unread = false;
     if (pmode == HIPBLASLT_POINTER_MODE_HOST) {
         double ar, ai = 0, br, bi2 = 0;
@@ -895,7 +934,8 @@ bool lt_try(hipblasLtHandle_t handle, hipblasLtMatmulDesc_t desc, const void* al
             ar = ((const double*)alpha)[0], br = ((const double*)beta)[0];
             if (dtype == GEMMUL8_Z) ai = ((const double*)alpha)[1], bi2 = ((const double*)beta)[1];
         }
-        c_unread = br == 0 && bi2 == 0 && ai == 0 && (ar == 1 || ar == -1);
+        (void)ar, (void)ai;
+        c_unread = br == 0 && bi2 == 0;
     }
     if (haveC && C != D && !c_unread) {  // out-of-place form: bring C into D, then update D in place
         for (int bi = 0; bi < nb; ++bi)
@@ -966,7 +1006,7 @@ extern "C" hipblasStatus_t hipblasLtMatrixLayoutDestroy(const hipblasLtMatrixLay
 
 // the per-handle state of an hipblasLt handle is released with the handle, as for hipblasDestroy
 extern "C" hipblasStatus_t hipblasLtDestroy(const hipblasLtHandle_t handle) {
-    release_state((hipblasHandle_t)handle);
+    release_state((hipblasHandle_t)handle, true);
     using Fn = hipblasStatus_t (*)(const hipblasLtHandle_t);
     static Fn real = real_fn<Fn>("hipblasLtDestroy");
     return real ? real(handle) : HIPBLAS_STATUS_NOT_INITIALIZED;

@@ -50,6 +50,8 @@ hipError_t launch_gemm_i8_max(hipStream_t stream, int nseg, const int8_t* const*
 hipError_t launch_gemm_f8(hipStream_t stream, int which, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp, size_t m,
                           size_t n, int t_begin, int t_end, int16_t* out, size_t ldo, size_t strideO, const int16_t* r0, const int16_t* r1,
                           size_t strideR, const int16_t* rx = nullptr, const int16_t* ry = nullptr);
+void set_f8_bound_mode(int mode);  // 0 = engine-safe inflation (default), 1 = the reference's (k+1) * 2^-24
+int get_f8_bound_mode();
 hipError_t launch_gemm_f8_max(hipStream_t stream, const int8_t* A, const int8_t* B, size_t kp, size_t k, size_t m, size_t n, int* rowmax,
                               int* colmax);
 hipError_t launch_gemm_f8_bound_cplx(hipStream_t stream, int stage, const int8_t* A, const int8_t* B, size_t kp, size_t k, size_t m, size_t n,

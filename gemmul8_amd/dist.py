@@ -96,6 +96,12 @@ def _lib():
         L.gemmul8_dist_allgather_c.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.gemmul8_dist_set_events.restype = C.c_int
         L.gemmul8_dist_set_events.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gemmul8_comm_rccl_count.restype = C.c_int
+        L.gemmul8_comm_rccl_count.argtypes = [C.POINTER(Comm), C.POINTER(C.c_int)]
+        L.gemmul8_dist_set_exchange_events.restype = C.c_int
+        L.gemmul8_dist_set_exchange_events.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.gemmul8_dist_exchange_bytes.restype = C.c_int
+        L.gemmul8_dist_exchange_bytes.argtypes = [C.c_void_p] + [C.POINTER(C.c_size_t)] * 3
         L.gemmul8_dist_workspace_bytes.restype = C.c_size_t
         L.gemmul8_dist_workspace_bytes.argtypes = [C.c_void_p]
         L.gemmul8_dist_destroy.restype = None
@@ -129,6 +135,12 @@ class RcclComm:
         g.check(L.gemmul8_comm_rccl_create(C.create_string_buffer(raw, 128), rank, world, C.byref(self.ptr)), "gemmul8_comm_rccl_create")
         self.rank, self.world = rank, world
 
+    def rccl_ranks(self):
+        """Size of the communicator as RCCL reports it (ncclCommCount)."""
+        n = C.c_int(-1)
+        g.check(_lib().gemmul8_comm_rccl_count(self.ptr, C.byref(n)), "gemmul8_comm_rccl_count")
+        return n.value
+
     def close(self):
         if self.ptr:
             _lib().gemmul8_comm_destroy(self.ptr)
@@ -148,6 +160,9 @@ class TorchTransport:
         self._keep = [ALLREDUCE_FN(self._allreduce), SENDRECV_FN(self._sendrecv), REDSCAT_FN(self._redscat), DESTROY_FN(lambda ctx: None)]
         self.struct = Comm(None, self.rank, self.world, *self._keep)
         self.ptr = C.pointer(self.struct)
+
+    def rccl_ranks(self):
+        return -1  # not an RCCL transport
 
     def close(self):
         pass
@@ -281,6 +296,21 @@ class DistGemm:
         """torch.cuda.Event pair (already recorded once, so that the handles exist) recorded around this rank's low-precision GEMM."""
         g.check(self.lib.gemmul8_dist_set_events(self.handle, e0.cuda_event if e0 is not None else None, e1.cuda_event if e1 is not None else None))
 
+    def set_exchange_events(self, events):
+        """Four torch.cuda.Event (already recorded once) or None: [0], [1] around the all-reduce(MAX) of the bound maxima, [2], [3]
+        around the bulk exchange (residue send/recv or FP64 reduce-scatter).  None clears."""
+        if events is None:
+            g.check(self.lib.gemmul8_dist_set_exchange_events(self.handle, None))
+            return
+        arr = (C.c_void_p * 4)(*[e.cuda_event if e is not None else None for e in events])
+        g.check(self.lib.gemmul8_dist_set_exchange_events(self.handle, arr))
+
+    def exchange_bytes(self):
+        """(all-reduce payload, bytes sent to other ranks, bytes received from other ranks) per call on this rank."""
+        v = [C.c_size_t(0) for _ in range(3)]
+        g.check(self.lib.gemmul8_dist_exchange_bytes(self.handle, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
     def gather_result(self, Cmat, stream=None):
         """Assemble the full C on every rank, in place."""
         if stream is None and Cmat.is_cuda:
@@ -305,9 +335,9 @@ class DistGemm:
                 f"ncclReduceScatter(sum)); A, B replicated on every rank")
 
 
-def make_plan(comm, dtype_code, backend, m, n, k, N, **kw):
-    """The plan bench.py and callers use: GEMMUL8_DIST_SHARD = blocks (default) | moduli | fp64sum."""
-    mode = os.environ.get("GEMMUL8_DIST_SHARD", "blocks")
+def make_plan(comm, dtype_code, backend, m, n, k, N, mode=None, **kw):
+    """A plan by name (blocks | columns | moduli | fp64sum); default: GEMMUL8_DIST_SHARD, else blocks."""
+    mode = mode or os.environ.get("GEMMUL8_DIST_SHARD", "blocks")
     if mode == "columns":  # the 1 x G grid of the block plan
         kw["grid_rows"] = 1
         mode = "blocks"

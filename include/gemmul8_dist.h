@@ -64,6 +64,8 @@ GEMMUL8_API int gemmul8_comm_rccl_create(const void *id128, int rank, int world,
 GEMMUL8_API int gemmul8_comm_rccl_id_from_env(void *id128, int *rank, int *world); /* the rendezvous alone: same 128 bytes on every rank */
 GEMMUL8_API int gemmul8_comm_rccl_from_env(gemmul8_comm **out);
 GEMMUL8_API void gemmul8_comm_destroy(gemmul8_comm *comm);
+/* Size of the RCCL communicator as the library reports it (ncclCommCount): *count = -1 when `comm` is not an RCCL transport. */
+GEMMUL8_API int gemmul8_comm_rccl_count(const gemmul8_comm *comm, int *count);
 
 /* Compute + memory provider of a plan.  NULL (the product) = the HIP phase entry points of gemmul8_c.h and hipMalloc /
  * hipMemcpyAsync / hipMemsetAsync.  The table exists so that the sharding and exchange arithmetic of this file -- which never
@@ -114,6 +116,13 @@ GEMMUL8_API int gemmul8_dist_allgather_c(gemmul8_dist_plan *plan, void *stream, 
 /* Measurement hook: two hipEvent_t (or NULL) that the next gemmul8_dist_gemm calls record on their stream right before and
  * after the low-precision GEMM launch of this rank (the dominant kernel: bench.py's roofline line). */
 GEMMUL8_API int gemmul8_dist_set_events(gemmul8_dist_plan *plan, void *ev_begin, void *ev_end);
+/* The same for the plan's collectives: ev[0], ev[1] around the all-reduce(MAX) of the bound maxima (accurate mode, world > 1),
+ * ev[2], ev[3] around the bulk exchange (moduli: grouped send/recv of residue blocks; fp64sum: reduce-scatter; blocks: none).
+ * ev = NULL clears; entries may be NULL.  An event that the call does not reach is left untouched. */
+GEMMUL8_API int gemmul8_dist_set_exchange_events(gemmul8_dist_plan *plan, void *const ev[4]);
+/* Bytes this rank moves per gemmul8_dist_gemm call: the all-reduce payload (bytes of the reduced vector), and what the bulk exchange
+ * sends to / receives from other ranks (fp64sum: the (world - 1) / world share of the reduce-scatter input / its output). */
+GEMMUL8_API int gemmul8_dist_exchange_bytes(const gemmul8_dist_plan *plan, size_t *allreduce_bytes, size_t *sent, size_t *received);
 GEMMUL8_API size_t gemmul8_dist_workspace_bytes(const gemmul8_dist_plan *plan);
 GEMMUL8_API void gemmul8_dist_destroy(gemmul8_dist_plan *plan);
 

