@@ -12,71 +12,108 @@
 //   beta == 0 in the general form: C is NOT read and enters the fma as +0 (BLAS semantics -- the hook serves callers such as
 //   torch.baddbmm(torch.empty(..), beta=0) whose C holds NaN garbage; the reference evaluates fma(0, C, alpha*AB), the same value for
 //   every finite C except the sign of an exact zero when C < 0).
-// Each thread handles ROWS consecutive rows of one column (8 bytes of every residue plane: 8 / 4 / 4 / 2 rows): one vector load per residue plane, all
-// N loads issued before the first use (the plane loop is fully unrolled over the 20-moduli maximum with a uniform guard).
+// Each thread handles ROWS consecutive rows of one column (LB = 8 bytes of every residue plane: 8 / 4 / 4 / 2 rows): one vector load per residue plane, all
+// N loads issued before the first use (the plane loop is fully unrolled over the 20-moduli maximum with a uniform guard); the results
+// leave through a per-wave LDS transposition so that every store instruction writes 1 KiB of contiguous memory (crt_wave_store).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "oz2_crt_common.hpp"
 #include "oz2_kernels.h"
 
 namespace oz2 {
 
-// U = float|double ; CPLX ; MID = int8_t|int16_t
-template <typename U, bool CPLX, typename MID>
+// U = float|double ; CPLX ; MID = int8_t|int16_t ; LB = bytes of every residue plane a thread loads (8 or 16)
 #ifndef OZ2_CRT_BLOCK
 #define OZ2_CRT_BLOCK 256  // threads per block of crt_kernel: 128 / 256 / 512 / 1024 -> 455 / 377 / 414 / 380 us at config 2 (tools/crt_ab.py)
 #endif
 #ifndef OZ2_CRT_NT
 #define OZ2_CRT_NT 1      // non-temporal residue loads (plain loads: 393 us)
 #endif
+#ifndef OZ2_CRT_LB
+#define OZ2_CRT_LB 8      // bytes per residue-plane load and thread (tools/crt_ab.py measures 8 against 16)
+#endif
+#ifndef OZ2_CRT_LDS_STORE
+#define OZ2_CRT_LDS_STORE 1  // 1: the wave's results go through LDS so that every store instruction writes 1 KiB of contiguous memory
+#endif
+
+// A thread's NV results are NV * sizeof(U) = J * 16 contiguous bytes of C, a wave's 64 threads own 64 * J * 16 contiguous bytes (when
+// they sit in one column).  Stored directly, store instruction j of the J would scatter 16-byte pieces at a J * 16-byte lane stride
+// (every instruction touches all of the wave's cache lines, a quarter or an eighth of each).  crt_wave_store sends the pieces through
+// the wave's private LDS slice and reads them back transposed: instruction j then writes bytes [1024 j, 1024 (j + 1)) -- lane-linear,
+// whole lines.  Chunk (lane l, piece j) lives at slot l * J + (j ^ f(l)), f(l) = (l / (16 / J)) % J: the 8 lanes of a
+// ds_write_b128 group hit 8 different 16-byte bank slots, and the read side is a permutation inside 256-byte blocks (conflict-free).
+template <int J> __device__ __forceinline__ unsigned crt_slot(unsigned l, unsigned j) {
+    if constexpr (J >= 2 && J <= 16) return l * J + (j ^ ((l / (16 / J)) % J));
+    else return l * J + j;
+}
+template <int J> __device__ __forceinline__ void crt_wave_store(char* lds_wave, const void* vals, char* gdst, unsigned lane) {
+    typedef unsigned V4 __attribute__((ext_vector_type(4)));
+    const V4* v = (const V4*)vals;
+    V4* ls = (V4*)lds_wave;
+#pragma unroll
+    for (unsigned j = 0; j < (unsigned)J; ++j) ls[crt_slot<J>(lane, j)] = v[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (unsigned j = 0; j < (unsigned)J; ++j) {
+        const unsigned c = j * 64u + lane;  // logical 16-byte chunk of the wave's output
+        const V4 x = ls[crt_slot<J>(c / J, c % J)];
+        __builtin_nontemporal_store(x, (V4*)(gdst + (size_t)c * 16));  // streaming: C is written once and not re-read by this kernel
+    }
+}
+
+template <typename U, bool CPLX, typename MID, int LB>
 __global__ void __launch_bounds__(OZ2_CRT_BLOCK) crt_kernel(const CrtArgs a) {
     constexpr int COMPS = CPLX ? 2 : 1;
-    constexpr int ROWS = 8 / (COMPS * (int)sizeof(MID));  // 8-byte residue vectors: 8 / 4 / 4 / 2 rows; wider ones cost occupancy
-    constexpr int NV = ROWS * COMPS;  // values per thread and plane
+    constexpr int ROWS = LB / (COMPS * (int)sizeof(MID));  // LB = 8: 8 / 4 / 4 / 2 rows; wider vectors cost registers
+    constexpr int NV = ROWS * COMPS;                       // values per thread and plane
+    constexpr int OUTB = NV * (int)sizeof(U);              // bytes of C per thread
+    constexpr int J = OUTB / 16;                           // 16-byte pieces per thread
+    static_assert(OUTB % 16 == 0 && J >= 1, "a thread's results are whole 16-byte pieces");
+    constexpr bool LDS_STORE = OZ2_CRT_LDS_STORE && J > 1;
+    __shared__ __attribute__((aligned(16))) char stage[LDS_STORE ? OZ2_CRT_BLOCK * OUTB : 16];
+
     const unsigned row_groups = (unsigned)((a.m + ROWS - 1) / ROWS);
+    const size_t total = (size_t)row_groups * a.n;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (size_t)row_groups * a.n) return;
-    const size_t col = gid / row_groups;
-    const size_t i0 = (gid - col * row_groups) * ROWS;
+    if (!LDS_STORE && gid >= total) return;
+    const bool active = gid < total;
+    const size_t gidc = active ? gid : total - 1;  // idle lanes of the last wave shadow a valid element (they never store)
+    const size_t col = gidc / row_groups;
+    const size_t i0 = (gidc - col * row_groups) * ROWS;
 
     // every plane's ROWS values first (planes are padded to 256 rows: the vector load never leaves the plane)
-    struct alignas(sizeof(MID) * NV) Vec {
+    struct alignas(LB) Vec {
         MID v[NV];
     };
+    static_assert(sizeof(Vec) == LB, "residue vectors of LB bytes");
+    // 64-bit lanes: with 32-bit vector elements the byte extraction keeps every plane's dwords live (112 -> 240 VGPRs)
+    typedef unsigned long long RawV2 __attribute__((ext_vector_type(2)));
+    using RawV = typename std::conditional<LB == 8, unsigned long long, RawV2>::type;
     const size_t zw = blockIdx.z * a.bw;  // batched launch: item blockIdx.z
     const MID* base = (const MID*)((const char*)a.Cmid + zw) + (col * a.ld_mid + i0) * COMPS;
     Vec c[20];
 #pragma unroll
     for (unsigned t = 0; t < 20; ++t)
         if (t < a.N) {
-            static_assert(sizeof(Vec) == 8, "8-byte residue vectors");
-            const unsigned long long* src_ = (const unsigned long long*)(base + (size_t)t * a.plane_stride * COMPS);
-            const unsigned long long raw = OZ2_CRT_NT ? __builtin_nontemporal_load(src_) : *src_;
-            __builtin_memcpy(&c[t], &raw, 8);
-        }
-
-    double Sh[NV], Sl[NV];
-#pragma unroll
-    for (int e = 0; e < NV; ++e) Sh[e] = 0.0, Sl[e] = 0.0;
-#pragma unroll
-    for (unsigned t = 0; t < 20; ++t) {
-        if (t < a.N) {
-            if (a.use_dd) {
-                const double qh = a.qh[t], ql = a.ql[t];
-#pragma unroll
-                for (int e = 0; e < NV; ++e) {
-                    const double cd = (double)c[t].v[e];
-                    Sh[e] = fma(qh, cd, Sh[e]);
-                    Sl[e] = fma(ql, cd, Sl[e]);
-                }
-            } else {
-                const double q1 = a.q1[t];
-#pragma unroll
-                for (int e = 0; e < NV; ++e) Sh[e] = fma(q1, (double)c[t].v[e], Sh[e]);
+            const RawV* src_ = (const RawV*)(base + (size_t)t * a.plane_stride * COMPS);
+#if defined(OZ2_CRT_ABL) && (OZ2_CRT_ABL & 2)  // timing probe: no residue loads
+            RawV raw;
+            {
+                const unsigned long long fake = (unsigned long long)gid * 0x9E3779B97F4A7C15ull + t;
+                __builtin_memcpy(&raw, &fake, 8);
+                if (LB == 16) __builtin_memcpy((char*)&raw + 8, &fake, 8);
             }
+            (void)src_;
+#else
+            const RawV raw = OZ2_CRT_NT ? __builtin_nontemporal_load(src_) : *src_;
+#endif
+            __builtin_memcpy(&c[t], &raw, LB);
         }
-    }
 
     U al[2] = {(U)a.alpha[0], (U)a.alpha[1]}, be[2] = {(U)a.beta[0], (U)a.beta[1]};
     int mode = a.mode;
@@ -95,49 +132,96 @@ __global__ void __launch_bounds__(OZ2_CRT_BLOCK) crt_kernel(const CrtArgs a) {
     const bool full = i0 + ROWS <= a.m;  // all ROWS rows exist: the old and new C values move as one vector per thread
     const bool beta0 = be[0] == (U)0 && (!CPLX || be[1] == (U)0);
     const bool reads_c = (mode == 0 && !beta0) || mode == 2 || mode == 4;
-    U oldc[NV], outv[NV];
+    U outv[NV];
+    // accumulate at most 8 values at a time (LB = 16: two passes over the loaded vectors): 2 x 8 FP64 accumulators
+    constexpr int PASS = NV > 8 ? 8 : NV;
 #pragma unroll
-    for (int e = 0; e < NV; ++e) oldc[e] = (U)0;
-    if (reads_c) {
-        if (full) {
-            __builtin_memcpy(oldc, Cc + i0 * COMPS, sizeof(oldc));
-        } else {
+    for (int p0 = 0; p0 < NV; p0 += PASS) {
+        double Sh[PASS], Sl[PASS];
 #pragma unroll
-            for (int e = 0; e < NV; ++e)
-                if (i0 + e / COMPS < a.m) oldc[e] = Cc[i0 * COMPS + e];
+        for (int e = 0; e < PASS; ++e) Sh[e] = 0.0, Sl[e] = 0.0;
+#pragma unroll
+        for (unsigned t = 0; t < 20; ++t) {
+            if (t < a.N) {
+                if (a.use_dd) {
+                    const double qh = a.qh[t], ql = a.ql[t];
+#pragma unroll
+                    for (int e = 0; e < PASS; ++e) {
+                        const double cd = (double)c[t].v[p0 + e];
+                        Sh[e] = fma(qh, cd, Sh[e]);
+                        Sl[e] = fma(ql, cd, Sl[e]);
+                    }
+                } else {
+                    const double q1 = a.q1[t];
+#pragma unroll
+                    for (int e = 0; e < PASS; ++e) Sh[e] = fma(q1, (double)c[t].v[p0 + e], Sh[e]);
+                }
+            }
+        }
+        // the old C values of this pass (after the accumulation: they are not live beside the residue vectors)
+        U oldc[NV];
+#pragma unroll
+        for (int e = 0; e < PASS; ++e) oldc[p0 + e] = (U)0;
+        if (reads_c && active) {
+            if (full) {
+                __builtin_memcpy(oldc + p0, Cc + i0 * COMPS + p0, PASS * sizeof(U));
+            } else {
+#pragma unroll
+                for (int e = p0; e < p0 + PASS; ++e)
+                    if (i0 + e / COMPS < a.m) oldc[e] = Cc[i0 * COMPS + e];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < PASS / COMPS; ++r) {
+            const int e = p0 / COMPS + r;  // row inside the thread's group
+            const size_t row = i0 + e;
+            const int sft = (row < a.m ? (int)sftA_z[row] : 0) + sB;
+            if constexpr (!CPLX) {
+                const U AB = scalb<U>((U)crt_reduce(a, Sh[r], Sl[r]), sft);
+                switch (mode) {
+                case 1: outv[e] = AB; break;
+                case 2: outv[e] = oldc[e] + AB; break;
+                case 3: outv[e] = -AB; break;
+                case 4: outv[e] = oldc[e] - AB; break;
+                default: outv[e] = fmaU<U>(be[0], oldc[e], al[0] * AB); break;
+                }
+            } else {
+                const U x = scalb<U>((U)crt_reduce(a, Sh[2 * r], Sl[2 * r]), sft);
+                const U y = scalb<U>((U)crt_reduce(a, Sh[2 * r + 1], Sl[2 * r + 1]), sft);
+                const U cx = oldc[2 * e], cy = oldc[2 * e + 1];
+                switch (mode) {
+                case 1: outv[2 * e] = x, outv[2 * e + 1] = y; break;
+                case 2: outv[2 * e] = cx + x, outv[2 * e + 1] = cy + y; break;
+                case 3: outv[2 * e] = -x, outv[2 * e + 1] = -y; break;
+                case 4: outv[2 * e] = cx - x, outv[2 * e + 1] = cy - y; break;
+                default:
+                    outv[2 * e] = fmaU<U>(-be[1], cy, fmaU<U>(be[0], cx, fmaU<U>(-al[1], y, al[0] * x)));
+                    outv[2 * e + 1] = fmaU<U>(be[1], cx, fmaU<U>(be[0], cy, fmaU<U>(al[1], x, al[0] * y)));
+                    break;
+                }
+            }
         }
     }
-#pragma unroll
-    for (int e = 0; e < ROWS; ++e) {
-        const size_t row = i0 + e;
-        const int sft = (row < a.m ? (int)sftA_z[row] : 0) + sB;
-        if constexpr (!CPLX) {
-            const U AB = scalb<U>((U)crt_reduce(a, Sh[e], Sl[e]), sft);
-            switch (mode) {
-            case 1: outv[e] = AB; break;
-            case 2: outv[e] = oldc[e] + AB; break;
-            case 3: outv[e] = -AB; break;
-            case 4: outv[e] = oldc[e] - AB; break;
-            default: outv[e] = fmaU<U>(be[0], oldc[e], al[0] * AB); break;
-            }
-        } else {
-            const U x = scalb<U>((U)crt_reduce(a, Sh[2 * e], Sl[2 * e]), sft);
-            const U y = scalb<U>((U)crt_reduce(a, Sh[2 * e + 1], Sl[2 * e + 1]), sft);
-            const U cx = oldc[2 * e], cy = oldc[2 * e + 1];
-            switch (mode) {
-            case 1: outv[2 * e] = x, outv[2 * e + 1] = y; break;
-            case 2: outv[2 * e] = cx + x, outv[2 * e + 1] = cy + y; break;
-            case 3: outv[2 * e] = -x, outv[2 * e + 1] = -y; break;
-            case 4: outv[2 * e] = cx - x, outv[2 * e + 1] = cy - y; break;
-            default:
-                outv[2 * e] = fmaU<U>(-be[1], cy, fmaU<U>(be[0], cx, fmaU<U>(-al[1], y, al[0] * x)));
-                outv[2 * e + 1] = fmaU<U>(be[1], cx, fmaU<U>(be[0], cy, fmaU<U>(al[1], x, al[0] * y)));
-                break;
-            }
+
+    if constexpr (LDS_STORE) {
+        // wave-uniform test: all 64 threads exist, sit in one column with all their rows inside m, and the wave's first byte of C is
+        // 16-byte aligned -> the wave's output is one contiguous, aligned block of 64 * OUTB bytes
+        const unsigned lane = threadIdx.x & 63u;
+        const size_t first = gid - lane, last = first + 63;
+        const size_t colf = first / row_groups;
+        const size_t i0f = (first - colf * row_groups) * ROWS;
+        char* wdst = (char*)((U*)((char*)a.C + blockIdx.z * a.bc) + (colf * a.ldc + i0f) * COMPS);
+        const bool wave_fast = last < total && last / row_groups == colf && i0f + (size_t)64 * ROWS <= a.m && ((uintptr_t)wdst & 15u) == 0;
+#if defined(OZ2_CRT_ABL) && (OZ2_CRT_ABL & 1)  // timing probe: no stores (the condition is never true)
+        if (wave_fast && outv[0] != (U)123.456) return;
+#endif
+        if (wave_fast) {
+            crt_wave_store<J>(stage + (size_t)(threadIdx.x >> 6) * 64 * OUTB, outv, wdst, lane);
+            return;
         }
+        if (!active) return;
     }
     if (full) {
-        // streaming stores: C is written once and not re-read by this kernel
         typedef U VecU __attribute__((ext_vector_type(NV)));
         VecU ov;
 #pragma unroll
@@ -384,10 +468,10 @@ hipError_t launch_crt(hipStream_t stream, int dtype, int backend, unsigned N, si
     a.bw = g_batch.ws;
     a.bc = g_batch.sc;
     const bool cplx = is_complex(dtype), i8 = backend == kINT8;
-    const size_t rows_per_thread = 8 / ((cplx ? 2 : 1) * (i8 ? 1 : 2));
+    const size_t rows_per_thread = OZ2_CRT_LB / ((cplx ? 2 : 1) * (i8 ? 1 : 2));
     const size_t threads = ((m + rows_per_thread - 1) / rows_per_thread) * n;
     dim3 grid((unsigned)((threads + OZ2_CRT_BLOCK - 1) / OZ2_CRT_BLOCK), 1, g_batch.batch);
-#define OZ2_CRT(U, CP, MID) hipLaunchKernelGGL((crt_kernel<U, CP, MID>), grid, dim3(OZ2_CRT_BLOCK), 0, stream, a)
+#define OZ2_CRT(U, CP, MID) hipLaunchKernelGGL((crt_kernel<U, CP, MID, OZ2_CRT_LB>), grid, dim3(OZ2_CRT_BLOCK), 0, stream, a)
     if (i8) {
         switch (dtype) {
         case kF32: OZ2_CRT(float, false, int8_t); break;

@@ -98,6 +98,53 @@ template <typename U> __device__ __forceinline__ U wave_max(U v) {
 // ------------------------------------------------------------------ stage kernel (extract / quantise)
 enum { MODE_BOUND = 0, MODE_MOD = 1 };
 
+#ifndef OZ2_STAGE_V16
+#define OZ2_STAGE_V16 0  // 1: INT8 residue planes leave as 16-byte stores (4 x 4 dword transpose over the lane quads) instead of one dword per
+                         // lane and plane.  Measured SLOWER (quantise pair 8192^2 x 14 planes: 702 vs 672 us, profiles/r03_hbm_ab.txt): the kernel is
+                         // bound by VALU issue, not by its store pattern, and the transposes add 16 operations per 4 planes -- kept for reference
+#endif
+#ifndef OZ2_STAGE_VLOAD
+#define OZ2_STAGE_VLOAD 1  // K-major operands: a thread's 4 consecutive elements as 16-byte non-temporal loads (672 -> 660 us); 0: element-wise loads
+#endif
+
+// 4 x 4 transpose of dwords over a lane quad (lanes 4i .. 4i+3): on return w[j] holds what lane j of the quad had in w[q], q = own lane
+// & 3.  Two butterfly stages of quad_perm DPP moves (full rate, no LDS): 16 VALU operations.  The four lanes of a quad own 16
+// consecutive k of one row and each produced one dword (4 residues) per plane: after the transpose lane q owns the 16 residues of plane
+// t0 + q -- ONE 16-byte store per lane instead of four dword stores.
+__device__ __forceinline__ void quad_transpose4(unsigned (&w)[4], unsigned q) {
+    const bool o1 = q & 1u, o2 = q & 2u;
+#pragma unroll
+    for (int p = 0; p < 4; p += 2) {  // exchange with lane ^ 1: pairs (w0, w1), (w2, w3)
+        const unsigned snd = o1 ? w[p] : w[p + 1];
+        const unsigned rcv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)snd, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+        w[p] = o1 ? rcv : w[p];
+        w[p + 1] = o1 ? w[p + 1] : rcv;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {     // exchange with lane ^ 2: pairs (w0, w2), (w1, w3)
+        const unsigned snd = o2 ? w[p] : w[p + 2];
+        const unsigned rcv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)snd, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+        w[p] = o2 ? rcv : w[p];
+        w[p + 2] = o2 ? w[p + 2] : rcv;
+    }
+}
+
+// v[0..3] = x[k0 .. k0+3], zero beyond k: 16-byte loads when the four elements exist and start on a 16-byte boundary
+template <typename T> __device__ __forceinline__ void load4(const T* x, size_t k0, size_t k, T (&v)[4]) {
+    const T* p = x + k0;
+    if (OZ2_STAGE_VLOAD && k0 + 4 <= k && (reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+        typedef unsigned V4 __attribute__((ext_vector_type(4)));
+        constexpr int NQ = (int)(4 * sizeof(T) / 16);
+        V4 r[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) r[i] = __builtin_nontemporal_load((const V4*)p + i);  // the operand is streamed: read once per kernel
+        __builtin_memcpy(v, r, sizeof(r));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (k0 + e < k) ? p[e] : ET<T>::zero();
+    }
+}
+
 struct StageArgs {
     const void* X;
     size_t ld;
@@ -234,9 +281,8 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
         // one pass over the moduli; FAST / WIDE are compile-time so the residue code is branch-free.  Complex: the residues of
         // Re, Im and wrapping(Re + Im) go to the three parts (INT8: the sum of the int8-cast values, mod.hpp:321-325).
         auto planes = [&]<bool FAST, bool WIDE>() {
-            for (int t = a.t_begin; t < a.t_end; ++t) {
+            auto residues = [&](int t, int (&rr)[4], int (&ri)[4], int (&rs)[4]) {
                 const ModConst mc = a.mt.mc[t];
-                int rr[4], ri[4], rs[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     rr[e] = FAST ? residue_sym_bytes_e0<WIDE>(rlo[e], rhi[e], nr[e], mc) : residue_sym_bytes128<WIDE>(Xr[e], nr[e], mc);
@@ -245,6 +291,43 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
                         rs[e] = WIDE ? wrapping(rr[e] + ri[e], mc.p) : wrapping((int)(int8_t)rr[e] + (int)(int8_t)ri[e], mc.p);
                     }
                 }
+            };
+            auto pack = [](const int (&r)[4]) {
+                return ((unsigned)r[0] & 0xFFu) | (((unsigned)r[1] & 0xFFu) << 8) | (((unsigned)r[2] & 0xFFu) << 16) | ((unsigned)r[3] << 24);
+            };
+            if constexpr (!WIDE && OZ2_STAGE_V16) {
+                // four planes per trip; the dwords of a lane quad (16 consecutive k of this row) are transposed so that lane q stores the
+                // 16 bytes of plane t + q: 256 contiguous bytes per plane and store instruction, a quarter of the store instructions
+                typedef unsigned V4 __attribute__((ext_vector_type(4)));
+                const unsigned q = threadIdx.x & 3u;
+                int8_t* oq = out - 4 * q;  // first byte of the quad's 16-byte run
+                for (int t = a.t_begin; t < a.t_end; t += 4) {
+                    unsigned wr[4] = {0u, 0u, 0u, 0u}, wi[4] = {0u, 0u, 0u, 0u}, ws[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (t + i < a.t_end) {
+                            int rr[4], ri[4], rs[4];
+                            residues(t + i, rr, ri, rs);
+                            wr[i] = pack(rr);
+                            if constexpr (E::cplx) wi[i] = pack(ri), ws[i] = pack(rs);
+                        }
+                    }
+                    quad_transpose4(wr, q);
+                    if constexpr (E::cplx) quad_transpose4(wi, q), quad_transpose4(ws, q);
+                    if (t + (int)q < a.t_end) {
+                        int8_t* o = oq + (size_t)(t + (int)q) * a.plane_stride;
+                        *(V4*)o = V4{wr[0], wr[1], wr[2], wr[3]};
+                        if constexpr (E::cplx) {
+                            *(V4*)(o + a.part_stride) = V4{wi[0], wi[1], wi[2], wi[3]};
+                            *(V4*)(o + 2 * a.part_stride) = V4{ws[0], ws[1], ws[2], ws[3]};
+                        }
+                    }
+                }
+                return;
+            }
+            for (int t = a.t_begin; t < a.t_end; ++t) {
+                int rr[4], ri[4], rs[4];
+                residues(t, rr, ri, rs);
                 if constexpr (WIDE) {
                     int8_t* o = out + (size_t)(t < 6 ? 2 * t : 12 + 3 * (t - 6)) * a.plane_stride;
                     put_fp8(o, t, rr);
@@ -253,9 +336,6 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
                         put_fp8(o + 2 * a.part_stride, t, rs);
                     }
                 } else {
-                    auto pack = [](const int (&r)[4]) {
-                        return ((unsigned)r[0] & 0xFFu) | (((unsigned)r[1] & 0xFFu) << 8) | (((unsigned)r[2] & 0xFFu) << 16) | ((unsigned)r[3] << 24);
-                    };
                     int8_t* o = out + (size_t)t * a.plane_stride;
                     *(unsigned*)o = pack(rr);
                     if constexpr (E::cplx) {
@@ -293,9 +373,9 @@ __global__ void __launch_bounds__(256) stage_kmajor_kernel(const StageArgs a) {
 #pragma unroll
             for (int it = 0; it < NC; ++it) {
                 const size_t k0 = (size_t)threadIdx.x * 4 + (size_t)it * 1024;
+                load4<T>(x, k0, a.k, vb[it]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    vb[it][e] = (k0 + e < a.k) ? x[k0 + e] : E::zero();
                     const U ar = (U)fabs(E::re(vb[it][e])), ai = (U)fabs(E::im(vb[it][e]));
                     am = ar > am ? ar : am;
                     am = ai > am ? ai : am;
@@ -338,8 +418,7 @@ __global__ void __launch_bounds__(256) stage_kmajor_kernel(const StageArgs a) {
     }
     for (size_t k0 = (size_t)threadIdx.x * 4; k0 < a.kp; k0 += 1024) {
         T v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (k0 + e < a.k) ? x[k0 + e] : E::zero();
+        load4<T>(x, k0, a.k, v);
         emit4<T, MODE>(a, row, k0, v, s);
     }
 }

@@ -190,7 +190,8 @@ def _check_multi_line(d, ranks, rccl):
         assert p["value"] > 0 and p["max_rel_err"] < 1e-9
     assert d["plans"]["blocks"]["mismatches_vs_moduli"] == 0            # both bit-identical to one GPU, hence to each other
     assert d["plans"]["blocks"]["bytes_sent_rank0"] == 0 and d["plans"]["moduli"]["bytes_sent_rank0"] > 0
-    assert d["plans"]["fp64sum"]["bytes_sent_rank0"] >= 8 * d["plans"]["moduli"]["bytes_sent_rank0"] * 0.9 or ranks == 1
+    # FP64 partial sums: 16 bytes (hi, lo) per element of the other ranks' column blocks against N / G residue bytes
+    assert d["plans"]["fp64sum"]["bytes_sent_rank0"] > d["plans"]["moduli"]["bytes_sent_rank0"] or ranks == 1
     assert d["plans"]["fp64sum"]["mismatches_vs_moduli"] <= 0.001 * d["plans"]["fp64sum"]["elements"]
     assert d["config"]["headline_plan"] in ("blocks", "moduli") and d["value"] == d["plans"][d["config"]["headline_plan"]]["value"]
     assert d["rccl_ranks"] == (ranks if rccl else -1)
