@@ -66,37 +66,40 @@ template <int J> __device__ __forceinline__ void crt_wave_store(char* lds_wave, 
     }
 }
 
-template <typename U, bool CPLX, typename MID, int LB>
-__global__ void __launch_bounds__(OZ2_CRT_BLOCK) crt_kernel(const CrtArgs a) {
-    constexpr int COMPS = CPLX ? 2 : 1;
-    constexpr int ROWS = LB / (COMPS * (int)sizeof(MID));  // LB = 8: 8 / 4 / 4 / 2 rows; wider vectors cost registers
-    constexpr int NV = ROWS * COMPS;                       // values per thread and plane
-    constexpr int OUTB = NV * (int)sizeof(U);              // bytes of C per thread
-    constexpr int J = OUTB / 16;                           // 16-byte pieces per thread
-    static_assert(OUTB % 16 == 0 && J >= 1, "a thread's results are whole 16-byte pieces");
-    constexpr bool LDS_STORE = OZ2_CRT_LDS_STORE && J > 1;
-    __shared__ __attribute__((aligned(16))) char stage[LDS_STORE ? OZ2_CRT_BLOCK * OUTB : 16];
+#ifndef OZ2_CRT_UNITS
+#define OZ2_CRT_UNITS 1  // row groups per thread; > 1: the residue vectors of group u + 1 are requested before group u is accumulated
+#endif
 
-    const unsigned row_groups = (unsigned)((a.m + ROWS - 1) / ROWS);
-    const size_t total = (size_t)row_groups * a.n;
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (!LDS_STORE && gid >= total) return;
-    const bool active = gid < total;
-    const size_t gidc = active ? gid : total - 1;  // idle lanes of the last wave shadow a valid element (they never store)
-    const size_t col = gidc / row_groups;
-    const size_t i0 = (gidc - col * row_groups) * ROWS;
-
-    // every plane's ROWS values first (planes are padded to 256 rows: the vector load never leaves the plane)
+template <typename MID, int LB, int COMPS> struct CrtVec {
+    static constexpr int NV = LB / (int)sizeof(MID);
     struct alignas(LB) Vec {
         MID v[NV];
     };
-    static_assert(sizeof(Vec) == LB, "residue vectors of LB bytes");
     // 64-bit lanes: with 32-bit vector elements the byte extraction keeps every plane's dwords live (112 -> 240 VGPRs)
     typedef unsigned long long RawV2 __attribute__((ext_vector_type(2)));
     using RawV = typename std::conditional<LB == 8, unsigned long long, RawV2>::type;
+};
+
+// position of thread-unit `gid`: column, first row (idle lanes of the last wave shadow the last valid unit; they never store)
+struct CrtPos {
+    size_t col, i0;
+    bool active;
+};
+template <int ROWS> __device__ __forceinline__ CrtPos crt_pos(size_t gid, size_t total, unsigned row_groups) {
+    CrtPos p;
+    p.active = gid < total;
+    const size_t g = p.active ? gid : total - 1;
+    p.col = g / row_groups;
+    p.i0 = (g - p.col * row_groups) * ROWS;
+    return p;
+}
+
+// every plane's ROWS values of one unit (planes are padded to 256 rows: the vector load never leaves the plane)
+template <typename MID, int LB, int COMPS>
+__device__ __forceinline__ void crt_load(const CrtArgs& a, const CrtPos& p, size_t gid, typename CrtVec<MID, LB, COMPS>::Vec (&c)[20]) {
+    using RawV = typename CrtVec<MID, LB, COMPS>::RawV;
     const size_t zw = blockIdx.z * a.bw;  // batched launch: item blockIdx.z
-    const MID* base = (const MID*)((const char*)a.Cmid + zw) + (col * a.ld_mid + i0) * COMPS;
-    Vec c[20];
+    const MID* base = (const MID*)((const char*)a.Cmid + zw) + (p.col * a.ld_mid + p.i0) * COMPS;
 #pragma unroll
     for (unsigned t = 0; t < 20; ++t)
         if (t < a.N) {
@@ -114,6 +117,19 @@ __global__ void __launch_bounds__(OZ2_CRT_BLOCK) crt_kernel(const CrtArgs a) {
 #endif
             __builtin_memcpy(&c[t], &raw, LB);
         }
+}
+
+template <typename U, bool CPLX, typename MID, int LB, bool LDS_STORE>
+__device__ __forceinline__ void crt_unit(const CrtArgs& a, const CrtPos& p, size_t gid, size_t total, unsigned row_groups,
+                                         const typename CrtVec<MID, LB, (CPLX ? 2 : 1)>::Vec (&c)[20], char* stage) {
+    constexpr int COMPS = CPLX ? 2 : 1;
+    constexpr int ROWS = LB / (COMPS * (int)sizeof(MID));
+    constexpr int NV = ROWS * COMPS;
+    constexpr int OUTB = NV * (int)sizeof(U);
+    constexpr int J = OUTB / 16;
+    const size_t col = p.col, i0 = p.i0;
+    const bool active = p.active;
+    const size_t zw = blockIdx.z * a.bw;
 
     U al[2] = {(U)a.alpha[0], (U)a.alpha[1]}, be[2] = {(U)a.beta[0], (U)a.beta[1]};
     int mode = a.mode;
@@ -133,8 +149,12 @@ __global__ void __launch_bounds__(OZ2_CRT_BLOCK) crt_kernel(const CrtArgs a) {
     const bool beta0 = be[0] == (U)0 && (!CPLX || be[1] == (U)0);
     const bool reads_c = (mode == 0 && !beta0) || mode == 2 || mode == 4;
     U outv[NV];
+
     // accumulate at most 8 values at a time (LB = 16: two passes over the loaded vectors): 2 x 8 FP64 accumulators
-    constexpr int PASS = NV > 8 ? 8 : NV;
+#ifndef OZ2_CRT_PASS
+#define OZ2_CRT_PASS 8
+#endif
+    constexpr int PASS = NV > OZ2_CRT_PASS ? OZ2_CRT_PASS : NV;
 #pragma unroll
     for (int p0 = 0; p0 < NV; p0 += PASS) {
         double Sh[PASS], Sl[PASS];
@@ -219,8 +239,8 @@ __global__ void __launch_bounds__(OZ2_CRT_BLOCK) crt_kernel(const CrtArgs a) {
             crt_wave_store<J>(stage + (size_t)(threadIdx.x >> 6) * 64 * OUTB, outv, wdst, lane);
             return;
         }
-        if (!active) return;
     }
+    if (!active) return;
     if (full) {
         typedef U VecU __attribute__((ext_vector_type(NV)));
         VecU ov;
@@ -232,6 +252,38 @@ __global__ void __launch_bounds__(OZ2_CRT_BLOCK) crt_kernel(const CrtArgs a) {
 #pragma unroll
         for (int e = 0; e < NV; ++e)
             if (i0 + e / COMPS < a.m) Cc[i0 * COMPS + e] = outv[e];
+    }
+}
+
+// UNITS row groups per thread (consecutive 256-thread slabs of one workgroup): the loads of unit u + 1 are issued before unit u is
+// accumulated, so every wave keeps residue vectors in flight while its FP64 pipe is busy (the kernel's FP64 work -- byte extraction,
+// conversion and two FMAs per residue -- is ~2/3 of its HBM time: without the overlap they add up instead of hiding each other)
+template <typename U, bool CPLX, typename MID, int LB, int UNITS>
+__global__ void __launch_bounds__(OZ2_CRT_BLOCK) crt_kernel(const CrtArgs a) {
+    constexpr int COMPS = CPLX ? 2 : 1;
+    constexpr int ROWS = LB / (COMPS * (int)sizeof(MID));  // LB = 8: 8 / 4 / 4 / 2 rows; wider vectors cost registers
+    constexpr int OUTB = ROWS * COMPS * (int)sizeof(U);     // bytes of C per thread
+    static_assert(OUTB % 16 == 0, "a thread's results are whole 16-byte pieces");
+    constexpr bool LDS_STORE = OZ2_CRT_LDS_STORE && OUTB > 16;
+    __shared__ __attribute__((aligned(16))) char stage[LDS_STORE ? OZ2_CRT_BLOCK * OUTB : 16];
+    using Vec = typename CrtVec<MID, LB, COMPS>::Vec;
+
+    const unsigned row_groups = (unsigned)((a.m + ROWS - 1) / ROWS);
+    const size_t total = (size_t)row_groups * a.n;
+    const size_t gid0 = (size_t)blockIdx.x * (OZ2_CRT_BLOCK * UNITS) + threadIdx.x;
+    if (!LDS_STORE && UNITS == 1 && gid0 >= total) return;
+    Vec cb[UNITS > 1 ? 2 : 1][20];
+    CrtPos pos[2];
+    pos[0] = crt_pos<ROWS>(gid0, total, row_groups);
+    crt_load<MID, LB, COMPS>(a, pos[0], gid0, cb[0]);
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
+        const size_t gid = gid0 + (size_t)u * OZ2_CRT_BLOCK;
+        if (u + 1 < UNITS) {
+            pos[(u + 1) & 1] = crt_pos<ROWS>(gid + OZ2_CRT_BLOCK, total, row_groups);
+            crt_load<MID, LB, COMPS>(a, pos[(u + 1) & 1], gid + OZ2_CRT_BLOCK, cb[(u + 1) & 1]);
+        }
+        crt_unit<U, CPLX, MID, LB, LDS_STORE>(a, pos[u & 1], gid, total, row_groups, cb[u & 1], stage);
     }
 }
 
@@ -470,8 +522,15 @@ hipError_t launch_crt(hipStream_t stream, int dtype, int backend, unsigned N, si
     const bool cplx = is_complex(dtype), i8 = backend == kINT8;
     const size_t rows_per_thread = OZ2_CRT_LB / ((cplx ? 2 : 1) * (i8 ? 1 : 2));
     const size_t threads = ((m + rows_per_thread - 1) / rows_per_thread) * n;
-    dim3 grid((unsigned)((threads + OZ2_CRT_BLOCK - 1) / OZ2_CRT_BLOCK), 1, g_batch.batch);
-#define OZ2_CRT(U, CP, MID) hipLaunchKernelGGL((crt_kernel<U, CP, MID, OZ2_CRT_LB>), grid, dim3(OZ2_CRT_BLOCK), 0, stream, a)
+    // small problems keep one unit per thread (more workgroups); large ones take the prefetching form
+    const bool multi = OZ2_CRT_UNITS > 1 && threads >= (size_t)OZ2_CRT_BLOCK * OZ2_CRT_UNITS * 2048;
+    const size_t per_block = (size_t)OZ2_CRT_BLOCK * (multi ? OZ2_CRT_UNITS : 1);
+    dim3 grid((unsigned)((threads + per_block - 1) / per_block), 1, g_batch.batch);
+#define OZ2_CRT(U, CP, MID)                                                                                                      \
+    do {                                                                                                                         \
+        if (multi) hipLaunchKernelGGL((crt_kernel<U, CP, MID, OZ2_CRT_LB, OZ2_CRT_UNITS>), grid, dim3(OZ2_CRT_BLOCK), 0, stream, a); \
+        else hipLaunchKernelGGL((crt_kernel<U, CP, MID, OZ2_CRT_LB, 1>), grid, dim3(OZ2_CRT_BLOCK), 0, stream, a);                \
+    } while (0)
     if (i8) {
         switch (dtype) {
         case kF32: OZ2_CRT(float, false, int8_t); break;

@@ -160,6 +160,7 @@ struct StageArgs {
     int t_begin, t_end;
     int sqrtp[6];
     ModTable mt;
+    double pairP[10], pairInvP[10];  // MODE_MOD, float-domain residues: product of the moduli pair (t_begin + 2j, t_begin + 2j + 1) and RN(1 / it)
     size_t bx, bw;        // batched launch (gridDim.z items): bytes between the items' operands X / between their workspaces
 };
 // item blockIdx.z of a batched launch: every workspace pointer moves by bw, the operand by bx (both 0 for a single GEMM).  The offsets
@@ -167,6 +168,141 @@ struct StageArgs {
 // slower that way).
 #define OZ2_ZW ((size_t)blockIdx.z * a.bw)
 #define OZ2_ZX ((size_t)blockIdx.z * a.bx)
+
+#ifndef OZ2_STAGE_KCHUNK
+#define OZ2_STAGE_KCHUNK 1  // K-major quantise: grid over (row, 1024-wide k chunk) instead of one workgroup looping over a whole row
+#endif
+#ifndef OZ2_STAGE_RTFAST
+#define OZ2_STAGE_RTFAST 1  // row-strided kernels: the row-tile index is the fast grid dimension: the workgroups in flight read whole columns (one sequential
+                           // window of the operand) and write 4 adjacent 128-byte runs per row and plane; 0 = k-tile index fastest (quantise A: 314 vs 283 us)
+#endif
+#ifndef OZ2_STAGE_FLOATRES
+#define OZ2_STAGE_FLOATRES 1  // 1: residues from a two-level FLOATING-POINT reduction (below); 0: the byte-wise integer path (v_dot4_u32_u8)
+#endif
+
+// FP8 residue planes: residues up to +-544 are split into 2-3 e4m3 planes of integers <= 16 (mod.hpp:159-189, 361-410)
+__device__ __forceinline__ void put_fp8_planes(const StageArgs& a, int8_t* o, int t, const int (&rr)[4]) {
+    if (t < 6) {
+        const int sq = a.sqrtp[t];
+        const float inv = 1.0f / (float)sq;
+        float hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fp8_split_sq(rr[e], sq, inv, hi[e], lo[e]);
+        *(unsigned*)o = fp8x2_from_floats(hi[0], hi[1]) | (fp8x2_from_floats(hi[2], hi[3]) << 16);
+        *(unsigned*)(o + a.plane_stride) = fp8x2_from_floats(lo[0], lo[1]) | (fp8x2_from_floats(lo[2], lo[3]) << 16);
+    } else {
+        int hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fp8_split_kara(rr[e], hi[e], lo[e]);
+        *(unsigned*)o = fp8x2_from_ints(hi[0], hi[1]) | (fp8x2_from_ints(hi[2], hi[3]) << 16);
+        *(unsigned*)(o + a.plane_stride) = fp8x2_from_ints(lo[0], lo[1]) | (fp8x2_from_ints(lo[2], lo[3]) << 16);
+        *(unsigned*)(o + 2 * a.plane_stride) =
+            fp8x2_from_ints(hi[0] + lo[0], hi[1] + lo[1]) | (fp8x2_from_ints(hi[2] + lo[2], hi[3] + lo[3]) << 16);
+    }
+}
+
+// Quantise + all residues of four consecutive k in the FLOATING-POINT domain.  The quantise kernels are bound by VALU issue, not by HBM
+// (profiles/r03_hbm_ab.txt, r03_valu_rates.txt): the integer path spends ~37 operations per element on trunc(x * 2^s) = +-M * 2^E and
+// ~7.75 per residue (two v_dot4_u32_u8 over the bytes of M, sign correction, quotient step, packing).  Here:
+//   xs = trunc(ldexp(x, s))                       2 FP64 operations per element; exact (a power-of-two scaling, then v_trunc_f64)
+//   level 1, per PAIR of moduli, P = p_t * p_t+1:  R = fma(-rint(xs * RN(1/P)), P, xs)      3 FP64 operations per pair
+//        q = rint(..) need not be the nearest integer: R = xs - q P is formed EXACTLY by the fma (an integer below 2^53) and
+//        R == xs (mod P); |R| <= P/2 + 2 for |xs| < 2^53.  |xs| >= 2^53 (num_moduli > 15 only; wave-uniform test): |R| <= |xs| 2^-52
+//        < 2^40, and one more step of the same form brings it to |R| <= P/2 + 1.
+//   level 2, per modulus: the single-fma quotient of finish_residue on the SIGNED R (|R| < 2^20.2: exact in fp32):
+//        qf = fma(float(R), RN(1/p), 1.5 * 2^23) rounds to 1.5 * 2^23 + q, q = rint(R / p) exactly (|R| * |RN(1/p) - 1/p| < 2^-4.9 / p
+//        stays clear of the 1/(2p) tie distance of an odd p; p = 256 / 1024: a tie gives +-p/2, the same byte / fixed below);
+//        its low 24 bits are 2^22 + q, so v_mad_i32_i24(bits, -p, R) = (R - q p) - p 2^22: the canonical residue in the low byte,
+//        the full value after adding p << 22 (mod 2^32).
+// ~10 operations per residue and 2 per element instead of ~14.7 and ~37: the kernels become HBM-bound.  Bit-identical planes
+// (tests/test_gpu_parity.py and the fuzz sweep compare every byte with the oracle).
+template <bool WIDE> __device__ __forceinline__ int residue_from_small(int Ri, float Rf, const ModConst& mc) {
+    const float qf = fmaf(Rf, mc.invp, 12582912.0f);
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(__float_as_int(qf)), "s"(-mc.p), "v"(Ri));
+    if constexpr (WIDE) {
+        r += (int)((unsigned)mc.p << 22);
+        if (!(mc.p & 1)) r = (r == -(mc.p >> 1)) ? (mc.p >> 1) : r;
+    }
+    return r;  // !WIDE: only the low byte is meaningful (the value is off by p * 2^22)
+}
+
+template <typename T> __device__ __forceinline__ void emit4_mod_float(const StageArgs& a, int8_t* out, const T (&v)[4], int s) {
+    using E = ET<T>;
+    double xr[4], xi[4];
+    bool big = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        xr[e] = trunc(ldexp(E::re(v[e]), s));
+        big |= fabs(xr[e]) >= 0x1.0p53;
+        if constexpr (E::cplx) {
+            xi[e] = trunc(ldexp(E::im(v[e]), s));
+            if (a.conj) xi[e] = -xi[e];
+            big |= fabs(xi[e]) >= 0x1.0p53;
+        } else {
+            xi[e] = 0.0;
+        }
+    }
+    auto run = [&]<bool WIDE, bool BIG>() {
+        for (int t = a.t_begin; t < a.t_end; t += 2) {
+            const double P = a.pairP[(t - a.t_begin) >> 1], invP = a.pairInvP[(t - a.t_begin) >> 1];
+            int Rr[4], Ri[4];
+            float Fr[4], Fi[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double R = fma(-rint(xr[e] * invP), P, xr[e]);
+                if constexpr (BIG) R = fma(-rint(R * invP), P, R);
+                Rr[e] = (int)R, Fr[e] = (float)R;
+                if constexpr (E::cplx) {
+                    double I = fma(-rint(xi[e] * invP), P, xi[e]);
+                    if constexpr (BIG) I = fma(-rint(I * invP), P, I);
+                    Ri[e] = (int)I, Fi[e] = (float)I;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int tt = t + u;
+                if (tt >= a.t_end) break;
+                const ModConst mc = a.mt.mc[tt];
+                int rr[4], ri[4], rs[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    rr[e] = residue_from_small<WIDE>(Rr[e], Fr[e], mc);
+                    if constexpr (E::cplx) {
+                        ri[e] = residue_from_small<WIDE>(Ri[e], Fi[e], mc);
+                        rs[e] = WIDE ? wrapping(rr[e] + ri[e], mc.p) : wrapping((int)(int8_t)rr[e] + (int)(int8_t)ri[e], mc.p);
+                    }
+                }
+                if constexpr (WIDE) {
+                    int8_t* o = out + (size_t)(tt < 6 ? 2 * tt : 12 + 3 * (tt - 6)) * a.plane_stride;
+                    put_fp8_planes(a, o, tt, rr);
+                    if constexpr (E::cplx) {
+                        put_fp8_planes(a, o + a.part_stride, tt, ri);
+                        put_fp8_planes(a, o + 2 * a.part_stride, tt, rs);
+                    }
+                } else {
+                    auto pack = [](const int (&r)[4]) {
+                        return ((unsigned)r[0] & 0xFFu) | (((unsigned)r[1] & 0xFFu) << 8) | (((unsigned)r[2] & 0xFFu) << 16) | ((unsigned)r[3] << 24);
+                    };
+                    int8_t* o = out + (size_t)tt * a.plane_stride;
+                    *(unsigned*)o = pack(rr);
+                    if constexpr (E::cplx) {
+                        *(unsigned*)(o + a.part_stride) = pack(ri);
+                        *(unsigned*)(o + 2 * a.part_stride) = pack(rs);
+                    }
+                }
+            }
+        }
+    };
+    const bool anybig = __any(big);
+    if (a.backend == kFP8) {
+        if (anybig) run.template operator()<true, true>();
+        else run.template operator()<true, false>();
+    } else {
+        if (anybig) run.template operator()<false, true>();
+        else run.template operator()<false, false>();
+    }
+}
 
 template <typename T, int MODE>
 __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0, const T (&v)[4], int s) {
@@ -217,6 +353,8 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
             *(unsigned*)(out + a.part_stride) = wi;
             *(unsigned*)(out + 2 * a.part_stride) = wd;
         }
+    } else if constexpr (OZ2_STAGE_FLOATRES) {
+        emit4_mod_float<T>(a, out, v, s);
     } else {
         uint64_t Mr[4], Mi[4];
         int Er[4], Ei[4];
@@ -258,26 +396,7 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
                 if constexpr (E::cplx) Xi[e] = shifted_bytes(Mi[e], Ei[e], ni[e]);
             }
         }
-        // FP8: residues up to +-544 are split into 2-3 e4m3 planes of integers <= 16 (mod.hpp:159-189, 361-410)
-        auto put_fp8 = [&](int8_t* o, int t, const int (&rr)[4]) {
-            if (t < 6) {
-                const int sq = a.sqrtp[t];
-                const float inv = 1.0f / (float)sq;
-                float hi[4], lo[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) fp8_split_sq(rr[e], sq, inv, hi[e], lo[e]);
-                *(unsigned*)o = fp8x2_from_floats(hi[0], hi[1]) | (fp8x2_from_floats(hi[2], hi[3]) << 16);
-                *(unsigned*)(o + a.plane_stride) = fp8x2_from_floats(lo[0], lo[1]) | (fp8x2_from_floats(lo[2], lo[3]) << 16);
-            } else {
-                int hi[4], lo[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) fp8_split_kara(rr[e], hi[e], lo[e]);
-                *(unsigned*)o = fp8x2_from_ints(hi[0], hi[1]) | (fp8x2_from_ints(hi[2], hi[3]) << 16);
-                *(unsigned*)(o + a.plane_stride) = fp8x2_from_ints(lo[0], lo[1]) | (fp8x2_from_ints(lo[2], lo[3]) << 16);
-                *(unsigned*)(o + 2 * a.plane_stride) =
-                    fp8x2_from_ints(hi[0] + lo[0], hi[1] + lo[1]) | (fp8x2_from_ints(hi[2] + lo[2], hi[3] + lo[3]) << 16);
-            }
-        };
+        auto put_fp8 = [&](int8_t* o, int t, const int (&rr)[4]) { put_fp8_planes(a, o, t, rr); };
         // one pass over the moduli; FAST / WIDE are compile-time so the residue code is branch-free.  Complex: the residues of
         // Re, Im and wrapping(Re + Im) go to the three parts (INT8: the sum of the int8-cast values, mod.hpp:321-325).
         auto planes = [&]<bool FAST, bool WIDE>() {
@@ -360,6 +479,20 @@ template <typename T, int MODE>
 __global__ void __launch_bounds__(256) stage_kmajor_kernel(const StageArgs a) {
     using E = ET<T>;
     using U = typename E::U;
+    if constexpr (MODE == MODE_MOD && OZ2_STAGE_KCHUNK) {
+        // quantise: one workgroup per 1024-wide k chunk of a row, the chunk index fastest: the workgroups in flight walk through
+        // memory together (one row after the other) instead of streaming ~2000 rows at once
+        const unsigned nch = (unsigned)(a.kp / 1024 + (a.kp % 1024 != 0));
+        const size_t row = blockIdx.x / nch;
+        const size_t k0 = (size_t)(blockIdx.x - row * nch) * 1024 + (size_t)threadIdx.x * 4;
+        if (k0 >= a.kp) return;
+        const T* x = (const T*)((const char*)a.X + OZ2_ZX) + row * a.ld;
+        const int s = -(int)((const int16_t*)((const char*)a.sft + OZ2_ZW))[row];
+        T v[4];
+        load4<T>(x, k0, a.k, v);
+        emit4<T, MODE>(a, row, k0, v, s);
+        return;
+    }
     const size_t row = blockIdx.x;
     const T* x = (const T*)((const char*)a.X + OZ2_ZX) + row * a.ld;
     int s;
@@ -440,8 +573,13 @@ __global__ void __launch_bounds__(256) stage_strided_kernel(const StageArgs a) {
     constexpr int CH = TK / 4;                                          // 4-wide k chunks per row
     constexpr int RPP = 256 / CH;                                       // rows per pass
     __shared__ __attribute__((aligned(16))) T tile[TR][PITCH];
+#if OZ2_STAGE_RTFAST
+    const unsigned nrt = (unsigned)((a.rows + TR - 1) / TR);
+    const unsigned kt = blockIdx.x / nrt, rt = blockIdx.x - kt * nrt;
+#else
     const unsigned nkt = (unsigned)(a.kp / TK);
     const unsigned rt = blockIdx.x / nkt, kt = blockIdx.x - rt * nkt;
+#endif
     const size_t r0 = (size_t)rt * TR;
     const size_t kb = (size_t)kt * TK;
     {
@@ -517,7 +655,10 @@ template <typename T> __global__ void __launch_bounds__(256) amax_strided_kernel
 
 template <typename T, int MODE> static hipError_t launch_stage(hipStream_t stream, bool kmajor, const StageArgs& a) {
     if (kmajor) {
-        dim3 grid((unsigned)a.rows, 1, g_batch.batch);
+        size_t blocks = a.rows;
+        if (MODE == MODE_MOD && OZ2_STAGE_KCHUNK) blocks *= (a.kp + 1023) / 1024;
+        if (blocks > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
+        dim3 grid((unsigned)blocks, 1, g_batch.batch);
         hipLaunchKernelGGL((stage_kmajor_kernel<T, MODE>), grid, dim3(256), 0, stream, a);
     } else {
         const size_t blocks = (a.kp / StageTile<T>::TK) * ((a.rows + StageTile<T>::TR - 1) / StageTile<T>::TR);
@@ -616,6 +757,11 @@ hipError_t launch_quantise(hipStream_t stream, int dtype, int backend, unsigned 
     a.t_begin = t_begin;
     a.t_end = t_end;
     a.mt = make_mod_table(backend);
+    for (int t = t_begin, j = 0; t < t_end && j < 10; t += 2, ++j) {
+        const double P = (double)a.mt.mc[t].p * (t + 1 < t_end ? (double)a.mt.mc[t + 1].p : 1.0);
+        a.pairP[j] = P;
+        a.pairInvP[j] = 1.0 / P;
+    }
     for (int t = 0; t < 6; ++t) a.sqrtp[t] = GEMMUL8_SQRT_MODULI_FP8[t];
     (void)N;
     return dispatch_stage<MODE_MOD>(stream, dtype, kmajor, a);

@@ -34,6 +34,10 @@ calls = {
     # fast mode = 1 would add the norm kernels; the quantise kernels are the same in both modes: time them with the shifts the bounds left
     "finish": (lambda L: L.gemmul8_scale_finish(st, g.D, g.INT8, 0, 0, n, n, n, A.data_ptr(), n, B.data_ptr(), n, N, 0, 0, N, C.byref(Lo), 0, 0),
                2 * (8.0 + N) * n * n),
+    "finishA": (lambda L: L.gemmul8_scale_finish(st, g.D, g.INT8, 0, 0, n, n, n, A.data_ptr(), n, B.data_ptr(), n, N, 0, 0, N, C.byref(Lo), 0, 1),
+                (8.0 + N) * n * n),
+    "finishB": (lambda L: L.gemmul8_scale_finish(st, g.D, g.INT8, 0, 0, n, n, n, A.data_ptr(), n, B.data_ptr(), n, N, 0, 0, N, C.byref(Lo), 1, 0),
+                (8.0 + N) * n * n),
     "crt": (lambda L: L.gemmul8_crt(st, g.D, g.INT8, N, n, n, Lo.C_mid, Lo.mp, Lo.sizeC, Lo.sftA, Lo.sftB, one.ctypes.data, zero.ctypes.data, Cm.data_ptr(), n),
             (8.0 + N) * n * n),
 }
@@ -42,7 +46,7 @@ for ph in a.phases.split(","):
     ts = [[] for _ in libs]
     for r in range(a.rounds + 2):
         for i, L in enumerate(libs):
-            if ph == "finish":  # every timed call starts from the state the bounds phase leaves (shift_finalize negates in place)
+            if ph.startswith("finish"):  # every timed call starts from the state the bounds phase leaves (shift_finalize negates in place)
                 g.check(ref.gemmul8_scale_bounds(st, g.D, g.INT8, 0, 0, n, n, n, A.data_ptr(), n, B.data_ptr(), n, N, 0, n, C.byref(Lo), 0, 0))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); g.check(fn(L)); e1.record(); torch.cuda.synchronize()

@@ -65,6 +65,34 @@ template <int MODE> __global__ void __launch_bounds__(256) crtmix_k(const unsign
     }
 }
 
+// the quantise kernel's traffic shape: 32 bytes in per lane (4 doubles), one dword out to each of NP planes `plane_stride` bytes apart
+template <int NP> __global__ void __launch_bounds__(256) quantmix_k(const V4* __restrict__ src, char* __restrict__ dst, size_t plane_stride, size_t nthreads) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= nthreads) return;
+    const V4 a = __builtin_nontemporal_load(src + 2 * gid), b = __builtin_nontemporal_load(src + 2 * gid + 1);
+    unsigned x = a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w;
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+        x = x * 1664525u + 1013904223u;
+        *(unsigned*)(dst + (size_t)t * plane_stride + gid * 4) = x;
+    }
+}
+// the CRT shape with a parameterised plane stride (bytes): 8 bytes of each of 14 planes in, 64 bytes out lane-linear
+__global__ void __launch_bounds__(256) crtmix_stride_k(const char* __restrict__ planes, size_t plane_stride, V4* __restrict__ dst, size_t nthreads) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= nthreads) return;
+    unsigned long long c[14];
+#pragma unroll
+    for (int t = 0; t < 14; ++t) c[t] = __builtin_nontemporal_load((const unsigned long long*)(planes + t * plane_stride) + gid);
+    unsigned long long x = 0;
+#pragma unroll
+    for (int t = 0; t < 14; ++t) x += c[t] * (t + 1);
+    const size_t wbase = (gid & ~(size_t)63) * 4;
+    const unsigned lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(V4{(unsigned)x + j, (unsigned)(x >> 32), (unsigned)j, 7u}, dst + wbase + j * 64 + lane);
+}
+
 int main() {
     const size_t bytes = (size_t)2 << 30, n = bytes / 16;
     V4 *a, *b;
@@ -97,6 +125,21 @@ int main() {
         const double moved = 14.0 * pstride * 8 + nthr * 64.0;
         time([&] { crtmix_k<0><<<(unsigned)(nthr / 256), 256>>>((const unsigned long long*)a, pstride, b, nthr); }, moved, "crtmix 14 x 8 B in, 64 B out lane-strided");
         time([&] { crtmix_k<1><<<(unsigned)(nthr / 256), 256>>>((const unsigned long long*)a, pstride, b, nthr); }, moved, "crtmix 14 x 8 B in, 64 B out lane-linear");
+    }
+    // plane-stride experiments: 8192 x 8192 elements, planes of 64 MiB; stride = 64 MiB + pad
+    {
+        const size_t nel = (size_t)8192 * 8192;
+        char* big;
+        const size_t plane = nel;  // bytes
+        CK(hipMalloc(&big, 15 * (plane + (1 << 20))));
+        CK(hipMemset(big, 3, 15 * (plane + (1 << 20))));
+        for (size_t pad : {(size_t)0, (size_t)256, (size_t)4096, (size_t)8192, (size_t)(8192 + 256), (size_t)65536 + 4096 + 256, (size_t)(1 << 20) - 256}) {
+            char name[128];
+            snprintf(name, sizeof name, "quantmix 32 B in, 14 x 4 B out, stride 64 MiB + %zu", pad);
+            time([&] { quantmix_k<14><<<(unsigned)(nel / 4 / 256), 256>>>(a, big, plane + pad, nel / 4); }, 8.0 * nel + 14.0 * nel, name);
+            snprintf(name, sizeof name, "crtmix   14 x 8 B in, 64 B out, stride 64 MiB + %zu", pad);
+            time([&] { crtmix_stride_k<<<(unsigned)(nel / 8 / 256), 256>>>(big, plane + pad, b, nel / 8); }, 8.0 * nel + 14.0 * nel, name);
+        }
     }
     return 0;
 }
