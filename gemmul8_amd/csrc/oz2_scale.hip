@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "oz2_kernels.h"
@@ -561,7 +562,10 @@ __global__ void __launch_bounds__(256) stage_kmajor_kernel(const StageArgs a) {
 template <typename T> struct StageTile {
     // 16.6 KiB of LDS per workgroup for every type (8 workgroups per CU): 32 rows of float, 16 rows of the 8- and 16-byte
     // types (a 16-row read segment of doubles is still one full 128-B cache line)
-    static constexpr int TR = sizeof(T) == 4 ? 32 : 16;
+#ifndef OZ2_STAGE_TR8
+#define OZ2_STAGE_TR8 16  // rows per tile of the 8- and 16-byte element types
+#endif
+    static constexpr int TR = sizeof(T) == 4 ? 32 : OZ2_STAGE_TR8;
     static constexpr int TK = sizeof(T) == 16 ? 64 : 128;
 };
 template <typename T, int MODE>
@@ -692,6 +696,10 @@ hipError_t launch_zero(hipStream_t stream, void* p, size_t bytes) {
     return hipGetLastError();
 }
 
+#ifndef OZ2_EXTRACT_CHUNK_MB
+#define OZ2_EXTRACT_CHUNK_MB 0    // (measured SLOWER: bounds phase 725 -> 771 us at 128 MiB, 796 at 64 MiB, profiles/r03_hbm_ab_extract_chunking.txt) row-strided extract: amax -> extract per row block of at most this many MiB of the operand, so that the
+                                  // extract's read of the block is served by the 256 MiB Infinity Cache instead of HBM; 0 = one pass each
+#endif
 hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajor, bool conj, size_t rows, size_t k, const void* X,
                           size_t ld, int8_t* lo, size_t part_stride, size_t kp, int16_t* sft0, void* scratch_amax, bool amax_is_zero,
                           size_t xstride) {
@@ -710,30 +718,52 @@ hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajo
     a.amax = scratch_amax;
     a.backend = backend;
     a.conj = conj;
-    if (!kmajor) {
-        const size_t ub = is_f32(dtype) ? 4 : 8;
-        hipError_t e = amax_is_zero ? hipSuccess : launch_zero(stream, scratch_amax, ub * rows);
-        if (e != hipSuccess) return e;
+    if (kmajor) return dispatch_stage<MODE_BOUND>(stream, dtype, kmajor, a);
+
+    const size_t ub = is_f32(dtype) ? 4 : 8;                        // bytes of an amax slot
+    const size_t esz = ub * (is_complex(dtype) ? 2 : 1);            // bytes of an element
+    hipError_t e = amax_is_zero ? hipSuccess : launch_zero(stream, scratch_amax, ub * rows);
+    if (e != hipSuccess) return e;
+    // The operand is read twice (row maxima, then the bound plane).  Row blocks small enough for the Infinity Cache make the second
+    // read an on-die hit: block = a multiple of 256 rows with at most OZ2_EXTRACT_CHUNK_MB MiB (the batch items of a batched launch
+    // count: they run side by side).
+    size_t rb = rows;
+    const size_t row_bytes = k * esz * g_batch.batch;
+    if (OZ2_EXTRACT_CHUNK_MB > 0 && rows * row_bytes > ((size_t)OZ2_EXTRACT_CHUNK_MB << 20) * 3 / 2) {
+        rb = ((size_t)OZ2_EXTRACT_CHUNK_MB << 20) / row_bytes / 256 * 256;
+        if (rb < 256) rb = 256;
+    }
+    for (size_t r0 = 0; r0 < rows; r0 += rb) {
+        const size_t nr = std::min(rb, rows - r0);
+        const char* Xb = (const char*)X + r0 * esz;
+        void* amax_b = (char*)scratch_amax + r0 * ub;
         // enough workgroups to fill the chip at every size (~2048), at least 16 k values per workgroup: the per-thread chain of
         // dependent strided loads, not bandwidth, bounds this kernel when the grid is small (42 us at 1024^2 with k/512 splits)
-        const size_t row_groups = (rows + 63) / 64;
+        const size_t row_groups = (nr + 63) / 64;
         size_t ks = (2048 + row_groups - 1) / row_groups;
         const size_t ks_max = (k + 15) / 16;
         if (ks > ks_max) ks = ks_max;
         if (ks < 1) ks = 1;
         if (ks > 65535) ks = 65535;
-        const unsigned ksplit = (unsigned)ks;
-        dim3 grid((unsigned)((rows + 63) / 64), ksplit, g_batch.batch);
+        dim3 grid((unsigned)row_groups, (unsigned)ks, g_batch.batch);
         switch (dtype) {
-        case kF32: hipLaunchKernelGGL(amax_strided_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, ld, rows, k, scratch_amax, xstride, g_batch.ws); break;
-        case kF64: hipLaunchKernelGGL(amax_strided_kernel<double>, grid, dim3(256), 0, stream, (const double*)X, ld, rows, k, scratch_amax, xstride, g_batch.ws); break;
-        case kC32: hipLaunchKernelGGL(amax_strided_kernel<float2>, grid, dim3(256), 0, stream, (const float2*)X, ld, rows, k, scratch_amax, xstride, g_batch.ws); break;
-        case kC64: hipLaunchKernelGGL(amax_strided_kernel<double2>, grid, dim3(256), 0, stream, (const double2*)X, ld, rows, k, scratch_amax, xstride, g_batch.ws); break;
+        case kF32: hipLaunchKernelGGL(amax_strided_kernel<float>, grid, dim3(256), 0, stream, (const float*)Xb, ld, nr, k, amax_b, xstride, g_batch.ws); break;
+        case kF64: hipLaunchKernelGGL(amax_strided_kernel<double>, grid, dim3(256), 0, stream, (const double*)Xb, ld, nr, k, amax_b, xstride, g_batch.ws); break;
+        case kC32: hipLaunchKernelGGL(amax_strided_kernel<float2>, grid, dim3(256), 0, stream, (const float2*)Xb, ld, nr, k, amax_b, xstride, g_batch.ws); break;
+        case kC64: hipLaunchKernelGGL(amax_strided_kernel<double2>, grid, dim3(256), 0, stream, (const double2*)Xb, ld, nr, k, amax_b, xstride, g_batch.ws); break;
         }
         e = hipGetLastError();
         if (e != hipSuccess) return e;
+        StageArgs b = a;
+        b.X = Xb;
+        b.rows = nr;
+        b.lo = lo + r0 * kp;
+        b.sft0 = sft0 + r0;
+        b.amax = amax_b;
+        e = dispatch_stage<MODE_BOUND>(stream, dtype, kmajor, b);
+        if (e != hipSuccess) return e;
     }
-    return dispatch_stage<MODE_BOUND>(stream, dtype, kmajor, a);
+    return hipSuccess;
 }
 
 hipError_t launch_quantise(hipStream_t stream, int dtype, int backend, unsigned N, int t_begin, int t_end, bool kmajor, bool conj,
