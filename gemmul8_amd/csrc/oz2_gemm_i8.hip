@@ -42,6 +42,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <type_traits>
 
 #include "oz2_crt_common.hpp"
@@ -1132,8 +1133,18 @@ hipError_t launch_gemm_i8_cplx(hipStream_t stream, const int8_t* A, const int8_t
     return launch<EPI_CPLX>(stream, a, t_end - t_begin);
 }
 
+#ifndef OZ2_MAX_SMALL_TILES
+#define OZ2_MAX_SMALL_TILES 100  // the bound GEMM takes the 128 x 128-tile kernel when (batch x) its 256 x 256 tiles number at most this (of 256 CUs): bounds phase 33 -> 28 / 41 -> 32 / 66 -> 55 us at 512^3 / 1024^3 / 2048^3, but 98 -> 111 us at 3072^3 (144 tiles), profiles/r03_bound_ab.txt
+#endif
 hipError_t launch_gemm_i8_max(hipStream_t stream, int nseg, const int8_t* const* A, const int8_t* const* B, size_t kp, size_t m, size_t n,
                               int* rowmax, int* colmax) {
+    {
+        // GEMMUL8_BOUND_TILE = 128 | 256 forces one kernel (tests run every case through both; the maxima are identical)
+        const char* force = getenv("GEMMUL8_BOUND_TILE");
+        const size_t tiles = ((m + BM - 1) / BM) * ((n + BN - 1) / BN) * g_batch.batch;
+        const bool small = force && force[0] == '1' ? true : force && force[0] == '2' ? false : tiles <= (size_t)OZ2_MAX_SMALL_TILES;
+        if (small) return launch_gemm_i8_max_small(stream, nseg, A, B, kp, m, n, rowmax, colmax);
+    }
     GemmArgs a{};
     for (int s = 0; s < nseg; ++s) a.A[s] = A[s], a.B[s] = B[s];
     a.nseg = nseg;

@@ -320,6 +320,26 @@ def test_bounds_bit_exact(backend, dtype, opA, opB):
         gu.bounds_case(A, B, 13, opA=opA, opB=opB, backend=be, skip_layout=True)
 
 
+@pytest.mark.parametrize("tile", ["128", "256"])
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+def test_bound_gemm_both_tile_sizes(dtype, tile, monkeypatch):
+    """The INT8 bound GEMM has two kernels: the persistent 256 x 256-tile one and the 128 x 128-tile one that small products take
+    (oz2_gemm_i8_small.hip).  GEMMUL8_BOUND_TILE forces either; the exact integer maxima must equal the oracle's with both, on shapes
+    with ragged tile edges, several tiles per dimension, K-major and strided operands, and the complex K-concatenated products."""
+    import gemmul8_amd as g
+    import gpu_util as gu
+    monkeypatch.setenv("GEMMUL8_BOUND_TILE", tile)
+    rng = np.random.default_rng(11)
+    for (m, n, k), (opA, opB) in [((37, 41, 300), ("N", "N")), ((300, 520, 700), ("T", "N")), ((513, 255, 1025), ("N", "T")),
+                                  ((129, 385, 520), ("T", "T")), ((1, 1, 1), ("N", "N"))]:
+        if np.dtype(dtype).kind == "c" and opA == "T":
+            opA = "C"
+        A = rand((m, k) if opA == "N" else (k, m), dtype, rng, phi=2.0)
+        B = rand((k, n) if opB == "N" else (n, k), dtype, rng, phi=2.0)
+        gu.bounds_case(A, B, 14, opA=opA, opB=opB, backend=g.INT8)
+        gu.parity_case(A, B, 14, False, opA=opA, opB=opB)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.complex128])
 def test_bounds_fp8_exact_when_fp32_sums_are_exact(dtype):
     """Operands of one binade: every e4m3 bound value is a multiple of 8 in [64, 256], so the FP32 accumulation of the

@@ -10,7 +10,7 @@ for spec in "$@"; do
   src=${SRC:-oz2_gemm_i8}
   /opt/rocm/bin/hipcc $FLAGS $defs -c $src.hip -o build/${src}_$tag.o
   objs=""
-  for o in oz2_gemm_i8 oz2_gemm_f8 oz2_scale oz2_crt oz2_driver oz2_api oz2_hook oz2_dist; do
+  for o in oz2_gemm_i8 oz2_gemm_i8_small oz2_gemm_f8 oz2_scale oz2_crt oz2_driver oz2_api oz2_hook oz2_dist; do
     [ "$o" = "$src" ] && objs="$objs build/${src}_$tag.o" || objs="$objs build/$o.o"
   done
   /opt/rocm/lib/llvm/bin/clang++ -shared -fPIC -o ../lib/lib_$tag.so $objs -ldl -lpthread
