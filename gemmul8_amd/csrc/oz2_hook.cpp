@@ -13,7 +13,8 @@
 //       pre-sizing applied when a SKIP_SCALE switch is on                      hook.cu:232-281,656-662
 //   early outs: m|n|k <= 0 -> SUCCESS, null A/B/C -> INVALID_VALUE            hook.cu:616-617
 //   GEMMUL8_DIST (this build only)  blocks | moduli | fp64sum: shard every emulated GEMM over the ranks of an SPMD job (see try_dist)
-//   GEMMUL8_MIN_FLOPS (this build only) calls below 2*m*n*k of it use the native routine (default 0: emulate everything)
+//   GEMMUL8_MIN_FLOPS (this build only) calls with 2*m*n*k below it use the native routine; 0 = emulate every call (the reference's
+//                     behaviour); UNSET = automatic floor from the measured crossover sizes (below_floor)
 //   per-handle state under a mutex: three grow-only stream-ordered buffers (hipMallocAsync /
 //   hipFreeAsync), event hand-off when the handle's stream changes, skip-scaling cache
 //   (hook.cu:70-162,331-374,684-727); hipblasDestroy frees the state first (hook.cu:846-856).
@@ -400,6 +401,25 @@ bool try_dist(int kind, int dtype, int backend, hipblasOperation_t ta, hipblasOp
     return true;
 }
 
+// GEMMUL8_MIN_FLOPS (not in the reference).  Below ~2048^3 one emulated GEMM is ten latency-bound launches and the native routine is
+// faster (profiles/sweeps/r03_flops_dgemm_int8.csv: 1024^3 17 vs 48 TFLOPS, 2048^2 x 1024 44 vs 66; from 1024^2 x 8192 and 2048^2 x 4096
+// on the emulation wins).  A drop-in must not make an application slower by default, so with the variable UNSET calls below the
+// measured crossover go to the native routine: emulated time ~ 90 us + W / 160 TFLOPS against W / 70 TFLOPS native for D / Z
+// (W = real flops) gives W > 1.1e10; S / C (native 154, emulated ~250 TFLOPS): 3.6e10.  A strided batch runs as ONE set of launches
+// (no per-item launch cost) and is judged on its total work with a 4x higher bar (16 x 1024^3: 45 vs 49 native; 8 x 2048^3: 80 vs 65).
+// GEMMUL8_MIN_FLOPS=0 restores the reference's behaviour (emulate every call); any other value is a floor on 2*m*n*k per call.
+bool below_floor(int dtype, double m, double n, double k, double batch = 1.0) {
+    const char* s = std::getenv("GEMMUL8_MIN_FLOPS");
+    const double w = 2.0 * m * n * k;
+    if (s && *s) {
+        const unsigned long long f = env_u64("GEMMUL8_MIN_FLOPS", 0);
+        return f && w < (double)f;
+    }
+    static const double kAuto[4] = {3.6e10, 1.1e10, 3.6e10, 1.1e10};  // S, D, C, Z in real flops
+    const double real = w * (kTypes[dtype].cplx ? 4.0 : 1.0) * batch;
+    return real < kAuto[dtype] * (batch > 1.0 ? 4.0 : 1.0);
+}
+
 // explicit_stream: hipblasLtMatmul carries its stream as an argument (a hipblasLt handle has none)
 bool try_emulate(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, hipblasOperation_t tb, int m, int n, int k, const void* alpha,
                  const void* A, int lda, const void* B, int ldb, const void* beta, void* C, int ldc, hipblasStatus_t* status,
@@ -407,13 +427,20 @@ bool try_emulate(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, hipbl
     const TypeInfo& ti = kTypes[dtype];
     const unsigned N = (unsigned)env_u64(ti.nmod, 0);
     if (N < 2u || N > ti.max_moduli) return false;
-    // GEMMUL8_MIN_FLOPS (not in the reference; default 0 = emulate every call like the reference): calls with 2*m*n*k below it go to
-    // the native routine -- below ~2048^3 the emulation is launch-bound (ten kernels) and slower than native (profiles/sweeps)
-    const unsigned long long floor_flops = env_u64("GEMMUL8_MIN_FLOPS", 0);
-    if (floor_flops && 2.0 * (double)m * (double)n * (double)k < (double)floor_flops) return false;
+    if (below_floor(dtype, m, n, k)) return false;
     const bool fastmode = env_one(ti.fast);
     const bool enA = env_one("GEMMUL8_SKIP_SCALE_A"), enB = env_one("GEMMUL8_SKIP_SCALE_B");
     const int backend = env_backend("GEMMUL8_BACKEND", 0, false);
+    if (backend == GEMMUL8_FP8) {
+        // the FP8 backend exists for parity with the reference; on this chip it is dominated: three FP8 GEMMs per modulus at about the
+        // INT8 MFMA rate against one INT8 GEMM (profiles/sweeps/*_types_backends.csv: SGEMM 8192^3 126 vs 276 TFLOPS, native 153;
+        // DGEMM 67 vs 152, native 73).  Say so once.
+        static std::once_flag told;
+        std::call_once(told, [] {
+            std::fprintf(stderr, "[GEMMUL8 HOOK] GEMMUL8_BACKEND=FP8: on MI355X the INT8 backend (GEMMUL8_BACKEND=0) is ~2.2x faster at equal or better "
+                                 "accuracy for S/D/C/Z, and the FP8 backend is slower than the native SGEMM / DGEMM; continuing with FP8 as requested\n");
+        });
+    }
 
     auto sp = state_of(handle);
     std::lock_guard<std::mutex> lk(sp->mtx);
@@ -675,8 +702,7 @@ static bool emulate_batch(int dtype, size_t elem, hipblasHandle_t handle, hipbla
         const TypeInfo& ti = kTypes[dtype];
         const unsigned N = (unsigned)env_u64(ti.nmod, 0);
         if (N < 2u || N > ti.max_moduli) return false;
-        const unsigned long long floor_flops = env_u64("GEMMUL8_MIN_FLOPS", 0);
-        if (floor_flops && 2.0 * (double)m * (double)n * (double)k < (double)floor_flops) return false;
+        if (below_floor(dtype, m, n, k, (double)batch)) return false;
         const int backend = env_backend("GEMMUL8_BACKEND", 0, false);
         if (backend == GEMMUL8_INT8 && k <= (1 << 17)) {
             const bool fastmode = env_one(ti.fast);
@@ -918,8 +944,7 @@ bool lt_try(hipblasLtHandle_t handle, hipblasLtMatmulDesc_t desc, const void* al
     // cheap env test before touching D: is emulation selected for this type at all?
     const unsigned N = (unsigned)env_u64(kTypes[dtype].nmod, 0);
     if (N < 2u || N > kTypes[dtype].max_moduli) return false;
-    const unsigned long long floor_flops = env_u64("GEMMUL8_MIN_FLOPS", 0);
-    if (floor_flops && 2.0 * (double)m * (double)n * (double)k < (double)floor_flops) return false;
+    if (below_floor(dtype, (double)m, (double)n, (double)k, (double)nb)) return false;
     if (k > (1u << 17) || (env_backend("GEMMUL8_BACKEND", 0, false) == 1 && k > 65536)) return false;  // outside the emulator's range
     // C is not read when the host scalar beta is 0 (the CRT's "C = +-AB" forms and its general form with beta == 0, oz2_crt.hip): then
     // the out-of-place form needs no copy of C into D.  Device scalars: beta is unknown here, C is copied (the kernel still skips

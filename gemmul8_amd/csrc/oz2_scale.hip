@@ -532,11 +532,18 @@ __global__ void __launch_bounds__(256) stage_kmajor_kernel(const StageArgs a) {
             return;
         }
         U am = 0;
-        for (size_t kk = threadIdx.x; kk < a.k; kk += 256) {
-            const T v = x[kk];
-            const U ar = (U)fabs(E::re(v)), ai = (U)fabs(E::im(v));
-            am = ar > am ? ar : am;
-            am = ai > am ? ai : am;
+        for (size_t k0 = (size_t)threadIdx.x * 4; k0 < a.k; k0 += 2048) {  // two 4-element groups in flight per thread
+            T v0[4], v1[4];
+            load4<T>(x, k0, a.k, v0);
+            load4<T>(x, k0 + 1024 < a.k ? k0 + 1024 : k0, a.k, v1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const U ar = (U)fabs(E::re(v0[e])), ai = (U)fabs(E::im(v0[e])), br = (U)fabs(E::re(v1[e])), bi = (U)fabs(E::im(v1[e]));
+                am = ar > am ? ar : am;
+                am = ai > am ? ai : am;
+                am = br > am ? br : am;
+                am = bi > am ? bi : am;
+            }
         }
         am = wave_max(am);
         if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = am;
@@ -638,7 +645,19 @@ template <typename T> __global__ void __launch_bounds__(256) amax_strided_kernel
     U am = 0;
     if (row < rows) {
         const T* x = X + row;
-        for (size_t kk = kbeg + ky; kk < kend; kk += 4) {
+        size_t kk = kbeg + ky;
+        for (; kk + 12 < kend; kk += 16) {  // four strided loads in flight per thread
+            T v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = x[(kk + 4 * u) * ld];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const U ar = (U)fabs(E::re(v[u])), ai = (U)fabs(E::im(v[u]));
+                am = ar > am ? ar : am;
+                am = ai > am ? ai : am;
+            }
+        }
+        for (; kk < kend; kk += 4) {
             const T v = x[kk * ld];
             const U ar = (U)fabs(E::re(v)), ai = (U)fabs(E::im(v));
             am = ar > am ? ar : am;
@@ -877,7 +896,24 @@ template <typename T> __global__ void __launch_bounds__(256) fast_shift_kmajor_k
     __shared__ U samax[32], ssum[32];
     const T* x = X + (size_t)blockIdx.x * ld;
     U amax = 0, sum = 0;
-    for (size_t i = threadIdx.x; i < k; i += 256) {
+    size_t i = threadIdx.x;
+    for (; i + 3 * 256 < k; i += 4 * 256) {  // four loads ahead of their (sequential) round-up FMAs
+        T v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = x[i + 256 * u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const U ar = (U)fabs(E::re(v[u]));
+            amax = ar > amax ? ar : amax;
+            sum = sqr_add_ru<U>(ar, sum);
+            if constexpr (E::cplx) {
+                const U ai = (U)fabs(E::im(v[u]));
+                amax = ai > amax ? ai : amax;
+                sum = sqr_add_ru<U>(ai, sum);
+            }
+        }
+    }
+    for (; i < k; i += 256) {
         const T v = x[i];
         const U ar = (U)fabs(E::re(v));
         amax = ar > amax ? ar : amax;
@@ -904,19 +940,40 @@ template <typename T> __global__ void __launch_bounds__(256) fast_shift_kmajor_k
     }
 }
 
-// Row-strided: 32 rows x 32 k-lanes per block (scaling_fast_real.hpp:27-49)
-template <typename T> __global__ void __launch_bounds__(1024) fast_shift_strided_kernel(const T* X, size_t ld, size_t rows, size_t k, int16_t* sft, float log2P, size_t bx, size_t bw) {
+// Row-strided: RPB rows x 32 k-lanes per block (scaling_fast_real.hpp:27-49: 32 x 32).  The reduction ORDER is the reference's for every
+// RPB: lane ty of a row adds the squares of columns ty, ty + 32, ... in sequence, then a width-32 tree over the 32 lanes.  RPB = 8
+// gives four times the workgroups when the operand has few rows (1024 rows: 128 instead of 32 workgroups on 256 CUs).  The loads of
+// eight chain steps are issued ahead of their round-up FMAs: the chain itself is sequential, and with one load per step it ran at one
+// memory latency per element (289 us for 1024 x 16384 doubles; 128 MiB).
+template <typename T, int RPB> __global__ void __launch_bounds__(RPB * 32) fast_shift_strided_kernel(const T* X, size_t ld, size_t rows, size_t k, int16_t* sft, float log2P, size_t bx, size_t bw) {
     X = (const T*)((const char*)X + blockIdx.z * bx);  // batched launch: item blockIdx.z
     sft = (int16_t*)((char*)sft + blockIdx.z * bw);
     using E = ET<T>;
     using U = typename E::U;
-    __shared__ U samax[32][33], ssum[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    size_t row = (size_t)blockIdx.x * 32 + tx;
+    __shared__ U samax[32][RPB + 1], ssum[32][RPB + 1];
+    const int tx = threadIdx.x % RPB, ty = threadIdx.x / RPB;
+    size_t row = (size_t)blockIdx.x * RPB + tx;
     U amax = 0, sum = 0;
     if (row < rows) {
         const T* x = X + row;
-        for (size_t col = ty; col < k; col += 32) {
+        size_t col = ty;
+        for (; col + 7 * 32 < k; col += 8 * 32) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = x[(col + 32 * u) * ld];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const U ar = (U)fabs(E::re(v[u]));
+                amax = ar > amax ? ar : amax;
+                sum = sqr_add_ru<U>(ar, sum);
+                if constexpr (E::cplx) {
+                    const U ai = (U)fabs(E::im(v[u]));
+                    amax = ai > amax ? ai : amax;
+                    sum = sqr_add_ru<U>(ai, sum);
+                }
+            }
+        }
+        for (; col < k; col += 32) {
             const T v = x[col * ld];
             const U ar = (U)fabs(E::re(v));
             amax = ar > amax ? ar : amax;
@@ -931,10 +988,12 @@ template <typename T> __global__ void __launch_bounds__(1024) fast_shift_strided
     samax[ty][tx] = amax;
     ssum[ty][tx] = sum;
     __syncthreads();
-    sum = tree32_sum_ru(ssum[tx][ty]);
-    amax = tree32_max(samax[tx][ty]);
-    row = (size_t)blockIdx.x * 32 + ty;
-    if (row < rows && tx == 0) sft[row] = (int16_t)(-fast_sft(amax, sum, log2P));
+    // thread r * 32 + l holds lane l of row r: width-32 trees
+    const int rr = threadIdx.x >> 5, ll = threadIdx.x & 31;
+    sum = tree32_sum_ru(ssum[ll][rr]);
+    amax = tree32_max(samax[ll][rr]);
+    row = (size_t)blockIdx.x * RPB + rr;
+    if (row < rows && ll == 0) sft[row] = (int16_t)(-fast_sft(amax, sum, log2P));
 }
 
 hipError_t launch_fast_shift(hipStream_t stream, int dtype, int backend, unsigned N, bool kmajor, size_t rows, size_t k, const void* X,
@@ -949,13 +1008,21 @@ hipError_t launch_fast_shift(hipStream_t stream, int dtype, int backend, unsigne
         case kC32: hipLaunchKernelGGL(fast_shift_kmajor_kernel<float2>, grid, dim3(256), 0, stream, (const float2*)X, ld, k, sft, log2P, xstride, g_batch.ws); break;
         case kC64: hipLaunchKernelGGL(fast_shift_kmajor_kernel<double2>, grid, dim3(256), 0, stream, (const double2*)X, ld, k, sft, log2P, xstride, g_batch.ws); break;
         }
-    } else {
+    } else if (rows >= 32 * 512) {
         dim3 grid((unsigned)((rows + 31) / 32), 1, g_batch.batch);
         switch (dtype) {
-        case kF32: hipLaunchKernelGGL(fast_shift_strided_kernel<float>, grid, dim3(1024), 0, stream, (const float*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
-        case kF64: hipLaunchKernelGGL(fast_shift_strided_kernel<double>, grid, dim3(1024), 0, stream, (const double*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
-        case kC32: hipLaunchKernelGGL(fast_shift_strided_kernel<float2>, grid, dim3(1024), 0, stream, (const float2*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
-        case kC64: hipLaunchKernelGGL(fast_shift_strided_kernel<double2>, grid, dim3(1024), 0, stream, (const double2*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
+        case kF32: hipLaunchKernelGGL((fast_shift_strided_kernel<float, 32>), grid, dim3(1024), 0, stream, (const float*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
+        case kF64: hipLaunchKernelGGL((fast_shift_strided_kernel<double, 32>), grid, dim3(1024), 0, stream, (const double*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
+        case kC32: hipLaunchKernelGGL((fast_shift_strided_kernel<float2, 32>), grid, dim3(1024), 0, stream, (const float2*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
+        case kC64: hipLaunchKernelGGL((fast_shift_strided_kernel<double2, 32>), grid, dim3(1024), 0, stream, (const double2*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
+        }
+    } else {  // few rows: 8 rows per workgroup (same reduction order, four times the workgroups)
+        dim3 grid((unsigned)((rows + 7) / 8), 1, g_batch.batch);
+        switch (dtype) {
+        case kF32: hipLaunchKernelGGL((fast_shift_strided_kernel<float, 8>), grid, dim3(256), 0, stream, (const float*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
+        case kF64: hipLaunchKernelGGL((fast_shift_strided_kernel<double, 8>), grid, dim3(256), 0, stream, (const double*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
+        case kC32: hipLaunchKernelGGL((fast_shift_strided_kernel<float2, 8>), grid, dim3(256), 0, stream, (const float2*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
+        case kC64: hipLaunchKernelGGL((fast_shift_strided_kernel<double2, 8>), grid, dim3(256), 0, stream, (const double2*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
         }
     }
     return hipGetLastError();

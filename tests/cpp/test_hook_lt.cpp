@@ -155,7 +155,7 @@ template <typename T> int run_type(hipblasLtHandle_t lt, gemm_fn direct, ws_fn w
         }
     std::printf("GEMMUL8_MIN_FLOPS floor -> native: %zu elements differ from the emulation, max abs %e\n", ndiff, e);
     CHECK(e < (sizeof(T) == 4 ? 1e-3 : 1e-11));
-    unsetenv("GEMMUL8_MIN_FLOPS");
+    setenv("GEMMUL8_MIN_FLOPS", "0", 1);  // back to "emulate every call" (unset would be the automatic size floor)
     return 0;
 }
 

@@ -160,7 +160,11 @@ int main() {
     long nat = mock_native_calls();
     CHECK(hipblasDgemm(h, HIPBLAS_OP_N, HIPBLAS_OP_N, 64, 64, 64, &one, A.data(), 64, B.data(), 64, &zero, C.data(), 64) == HIPBLAS_STATUS_SUCCESS);
     CHECK(mock_native_calls() == nat + 1);
-    unsetenv("GEMMUL8_MIN_FLOPS");
+    unsetenv("GEMMUL8_MIN_FLOPS");  // unset = the automatic floor: a 64^3 call is far below the measured crossover -> native again
+    nat = mock_native_calls();
+    CHECK(hipblasDgemm(h, HIPBLAS_OP_N, HIPBLAS_OP_N, 64, 64, 64, &one, A.data(), 64, B.data(), 64, &zero, C.data(), 64) == HIPBLAS_STATUS_SUCCESS);
+    CHECK(mock_native_calls() == nat + 1);
+    setenv("GEMMUL8_MIN_FLOPS", "0", 1);  // 0 = emulate every call (the reference's behaviour)
     setenv("GEMMUL8_DIST", "blocks", 1);  // no RANK / WORLD_SIZE: one warning, then single-GPU emulation
     long emu = mock_emulated_calls();
     CHECK(hipblasDgemm(h, HIPBLAS_OP_N, HIPBLAS_OP_N, 64, 64, 64, &one, A.data(), 64, B.data(), 64, &zero, C.data(), 64) == HIPBLAS_STATUS_SUCCESS);

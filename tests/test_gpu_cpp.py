@@ -13,6 +13,7 @@ LIB = os.path.join(ROOT, "gemmul8_amd", "lib", "libgemmul8.so")
 
 def run(cmd, env_extra):
     env = dict(os.environ)
+    env.setdefault("GEMMUL8_MIN_FLOPS", "0")   # the test matrices are small: emulate every call (the reference's behaviour), not the automatic floor
     env.update(env_extra)
     env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)

@@ -15,6 +15,7 @@ SHIM = os.path.join(ROOT, "gemmul8_amd", "lib", "libgemmul8_preload.so")
 
 def _run(extra_env):
     env = dict(os.environ)
+    env.setdefault("GEMMUL8_MIN_FLOPS", "0")   # small demo matrices: emulate every call (default would be the automatic size floor)
     env.update(extra_env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hook_torch_demo.py")], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -54,3 +55,27 @@ def test_torch_float32_matmul_is_emulated_under_ld_preload():
         _run({"LD_PRELOAD": SHIM, "GEMMUL8_NUM_MOD_S": "13", "TORCH_BLAS_PREFER_HIPBLASLT": prefer})
         assert _run.sgemm_err == emulated, (prefer, _run.sgemm_err, emulated)   # same bits through either library
     assert emulated < 0.25 * native, (native, emulated)
+
+
+def test_default_floor_keeps_small_calls_native():
+    """GEMMUL8_MIN_FLOPS unset: calls below the measured crossover (DGEMM: 2mnk < 1.1e10) go to the native routine, so the drop-in never
+    slows a small GEMM down; the demo's matrices are far below it -> results identical to the un-hooked run."""
+    native, native_b = _run({})
+    env = {"LD_PRELOAD": SHIM, "GEMMUL8_NUM_MOD_D": "18", "GEMMUL8_NUM_MOD_S": "13"}
+    keep = os.environ.pop("GEMMUL8_MIN_FLOPS", None)
+    try:
+        floor_unset = dict(env)
+        out_env = dict(os.environ)
+        out_env.update(floor_unset)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hook_torch_demo.py")], env=out_env, capture_output=True, text=True, timeout=600)
+    finally:
+        if keep is not None:
+            os.environ["GEMMUL8_MIN_FLOPS"] = keep
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"TFLOPS, normwise err ([0-9.e+-]+)", out.stdout)
+    mb = re.search(r"bmm normwise err ([0-9.e+-]+)", out.stdout)
+    big = re.search(r"torch DGEMM (\d+)\^3", out.stdout)
+    n = int(big.group(1))
+    if 2.0 * n ** 3 < 1.1e10:
+        assert float(m.group(1)) == native, (float(m.group(1)), native)      # below the floor: the native routine ran
+    assert float(mb.group(1)) == native_b, (float(mb.group(1)), native_b)    # the small batch stays native as well

@@ -38,5 +38,5 @@ def test_hook_under_asan_ubsan(tmp_path):
     _run(common + FLAGS + [os.path.join(SAN, "hook_driver.cpp"), "-o", os.path.join(d, "hook_driver"), "-L" + d, "-lhook_san", "-lmockgpu",
                            "-Wl,-rpath," + d, "-lpthread"])
     out = _run([os.path.join(d, "hook_driver")], env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1",
-                                                         LD_LIBRARY_PATH=d))
+                                                         LD_LIBRARY_PATH=d, GEMMUL8_MIN_FLOPS="0"))
     assert "ALL OK" in out, out[-3000:]
