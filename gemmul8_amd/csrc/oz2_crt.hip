@@ -95,13 +95,13 @@ template <int ROWS> __device__ __forceinline__ CrtPos crt_pos(size_t gid, size_t
 }
 
 // every plane's ROWS values of one unit (planes are padded to 256 rows: the vector load never leaves the plane)
-template <typename MID, int LB, int COMPS>
-__device__ __forceinline__ void crt_load(const CrtArgs& a, const CrtPos& p, size_t gid, typename CrtVec<MID, LB, COMPS>::Vec (&c)[20]) {
+template <typename MID, int LB, int COMPS, int NMAX>
+__device__ __forceinline__ void crt_load(const CrtArgs& a, const CrtPos& p, size_t gid, typename CrtVec<MID, LB, COMPS>::Vec (&c)[NMAX]) {
     using RawV = typename CrtVec<MID, LB, COMPS>::RawV;
     const size_t zw = blockIdx.z * a.bw;  // batched launch: item blockIdx.z
     const MID* base = (const MID*)((const char*)a.Cmid + zw) + (p.col * a.ld_mid + p.i0) * COMPS;
 #pragma unroll
-    for (unsigned t = 0; t < 20; ++t)
+    for (unsigned t = 0; t < (unsigned)NMAX; ++t)
         if (t < a.N) {
             const RawV* src_ = (const RawV*)(base + (size_t)t * a.plane_stride * COMPS);
 #if defined(OZ2_CRT_ABL) && (OZ2_CRT_ABL & 2)  // timing probe: no residue loads
@@ -119,9 +119,9 @@ __device__ __forceinline__ void crt_load(const CrtArgs& a, const CrtPos& p, size
         }
 }
 
-template <typename U, bool CPLX, typename MID, int LB, bool LDS_STORE>
+template <typename U, bool CPLX, typename MID, int LB, bool LDS_STORE, int NMAX>
 __device__ __forceinline__ void crt_unit(const CrtArgs& a, const CrtPos& p, size_t gid, size_t total, unsigned row_groups,
-                                         const typename CrtVec<MID, LB, (CPLX ? 2 : 1)>::Vec (&c)[20], char* stage) {
+                                         const typename CrtVec<MID, LB, (CPLX ? 2 : 1)>::Vec (&c)[NMAX], char* stage) {
     constexpr int COMPS = CPLX ? 2 : 1;
     constexpr int ROWS = LB / (COMPS * (int)sizeof(MID));
     constexpr int NV = ROWS * COMPS;
@@ -161,7 +161,7 @@ __device__ __forceinline__ void crt_unit(const CrtArgs& a, const CrtPos& p, size
 #pragma unroll
         for (int e = 0; e < PASS; ++e) Sh[e] = 0.0, Sl[e] = 0.0;
 #pragma unroll
-        for (unsigned t = 0; t < 20; ++t) {
+        for (unsigned t = 0; t < (unsigned)NMAX; ++t) {
             if (t < a.N) {
                 if (a.use_dd) {
                     const double qh = a.qh[t], ql = a.ql[t];
@@ -258,8 +258,11 @@ __device__ __forceinline__ void crt_unit(const CrtArgs& a, const CrtPos& p, size
 // UNITS row groups per thread (consecutive 256-thread slabs of one workgroup): the loads of unit u + 1 are issued before unit u is
 // accumulated, so every wave keeps residue vectors in flight while its FP64 pipe is busy (the kernel's FP64 work -- byte extraction,
 // conversion and two FMAs per residue -- is ~2/3 of its HBM time: without the overlap they add up instead of hiding each other)
-template <typename U, bool CPLX, typename MID, int LB, int UNITS>
-__global__ void __launch_bounds__(OZ2_CRT_BLOCK) crt_kernel(const CrtArgs a) {
+#ifndef OZ2_CRT_WAVES
+#define OZ2_CRT_WAVES 4  // waves per SIMD the register allocation aims at (experiment switch)
+#endif
+template <typename U, bool CPLX, typename MID, int LB, int UNITS, int NMAX>
+__global__ void __launch_bounds__(OZ2_CRT_BLOCK) __attribute__((amdgpu_waves_per_eu(OZ2_CRT_WAVES, 8))) crt_kernel(const CrtArgs a) {
     constexpr int COMPS = CPLX ? 2 : 1;
     constexpr int ROWS = LB / (COMPS * (int)sizeof(MID));  // LB = 8: 8 / 4 / 4 / 2 rows; wider vectors cost registers
     constexpr int OUTB = ROWS * COMPS * (int)sizeof(U);     // bytes of C per thread
@@ -272,18 +275,18 @@ __global__ void __launch_bounds__(OZ2_CRT_BLOCK) crt_kernel(const CrtArgs a) {
     const size_t total = (size_t)row_groups * a.n;
     const size_t gid0 = (size_t)blockIdx.x * (OZ2_CRT_BLOCK * UNITS) + threadIdx.x;
     if (!LDS_STORE && UNITS == 1 && gid0 >= total) return;
-    Vec cb[UNITS > 1 ? 2 : 1][20];
+    Vec cb[UNITS > 1 ? 2 : 1][NMAX];  // NMAX = 14 or 20: registers are reserved for every plane the instantiation may load
     CrtPos pos[2];
     pos[0] = crt_pos<ROWS>(gid0, total, row_groups);
-    crt_load<MID, LB, COMPS>(a, pos[0], gid0, cb[0]);
+    crt_load<MID, LB, COMPS, NMAX>(a, pos[0], gid0, cb[0]);
 #pragma unroll
     for (int u = 0; u < UNITS; ++u) {
         const size_t gid = gid0 + (size_t)u * OZ2_CRT_BLOCK;
         if (u + 1 < UNITS) {
             pos[(u + 1) & 1] = crt_pos<ROWS>(gid + OZ2_CRT_BLOCK, total, row_groups);
-            crt_load<MID, LB, COMPS>(a, pos[(u + 1) & 1], gid + OZ2_CRT_BLOCK, cb[(u + 1) & 1]);
+            crt_load<MID, LB, COMPS, NMAX>(a, pos[(u + 1) & 1], gid + OZ2_CRT_BLOCK, cb[(u + 1) & 1]);
         }
-        crt_unit<U, CPLX, MID, LB, LDS_STORE>(a, pos[u & 1], gid, total, row_groups, cb[u & 1], stage);
+        crt_unit<U, CPLX, MID, LB, LDS_STORE, NMAX>(a, pos[u & 1], gid, total, row_groups, cb[u & 1], stage);
     }
 }
 
@@ -528,8 +531,9 @@ hipError_t launch_crt(hipStream_t stream, int dtype, int backend, unsigned N, si
     dim3 grid((unsigned)((threads + per_block - 1) / per_block), 1, g_batch.batch);
 #define OZ2_CRT(U, CP, MID)                                                                                                      \
     do {                                                                                                                         \
-        if (multi) hipLaunchKernelGGL((crt_kernel<U, CP, MID, OZ2_CRT_LB, OZ2_CRT_UNITS>), grid, dim3(OZ2_CRT_BLOCK), 0, stream, a); \
-        else hipLaunchKernelGGL((crt_kernel<U, CP, MID, OZ2_CRT_LB, 1>), grid, dim3(OZ2_CRT_BLOCK), 0, stream, a);                \
+        if (multi) hipLaunchKernelGGL((crt_kernel<U, CP, MID, OZ2_CRT_LB, OZ2_CRT_UNITS, 20>), grid, dim3(OZ2_CRT_BLOCK), 0, stream, a); \
+        else if (N <= 14) hipLaunchKernelGGL((crt_kernel<U, CP, MID, OZ2_CRT_LB, 1, 14>), grid, dim3(OZ2_CRT_BLOCK), 0, stream, a);       \
+        else hipLaunchKernelGGL((crt_kernel<U, CP, MID, OZ2_CRT_LB, 1, 20>), grid, dim3(OZ2_CRT_BLOCK), 0, stream, a);                    \
     } while (0)
     if (i8) {
         switch (dtype) {

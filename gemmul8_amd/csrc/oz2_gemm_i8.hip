@@ -172,27 +172,30 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
                     *(uint4*)(args.out + po + e) = make_uint4(z[0], z[1], z[2], z[3]);
 #endif
                 } else {
-                    const uint4 x4 = *(const uint4*)(args.rx + pr + e);
-                    const uint4 y4 = *(const uint4*)(args.ry + pr + e);
-                    const unsigned xs[4] = {x4.x, x4.y, x4.z, x4.w}, ys[4] = {y4.x, y4.y, y4.z, y4.w};
-                    unsigned o[8];
+                    // eight rows at a time: 8 bytes of X and Y in, 16 bytes of (Cr, Ci) pairs out -- with all 16 rows in flight the epilogue
+                    // needed 16 more registers than the 168-VGPR budget leaves beside the accumulators (51-62 spilled registers)
 #pragma unroll
-                    for (int w4 = 0; w4 < 4; ++w4) {
-                        unsigned lo = 0, hi = 0;
+                    for (int h = 0; h < 2; ++h) {
+                        const uint2 x2 = *(const uint2*)(args.rx + pr + e + 8 * h);
+                        const uint2 y2 = *(const uint2*)(args.ry + pr + e + 8 * h);
+                        const unsigned xs[2] = {x2.x, x2.y}, ys[2] = {y2.x, y2.y};
+                        unsigned o[4];
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            const int X = (int)(int8_t)(xs[w4] >> (8 * b)), Y = (int)(int8_t)(ys[w4] >> (8 * b)), Z = (int)(int8_t)(z[w4] >> (8 * b));
-                            const int cr = red_small(X - Y), ci = red_small(Z - X - Y);
-                            const unsigned pair = ((unsigned)cr & 0xFFu) | (((unsigned)ci & 0xFFu) << 8);
-                            if (b < 2) lo |= pair << (16 * b);
-                            else hi |= pair << (16 * (b - 2));
+                        for (int w2 = 0; w2 < 2; ++w2) {
+                            unsigned lo = 0, hi = 0;
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const int X = (int)(int8_t)(xs[w2] >> (8 * b)), Y = (int)(int8_t)(ys[w2] >> (8 * b)), Z = (int)(int8_t)(z[2 * h + w2] >> (8 * b));
+                                const int cr = red_small(X - Y), ci = red_small(Z - X - Y);
+                                const unsigned pair = ((unsigned)cr & 0xFFu) | (((unsigned)ci & 0xFFu) << 8);
+                                if (b < 2) lo |= pair << (16 * b);
+                                else hi |= pair << (16 * (b - 2));
+                            }
+                            o[2 * w2] = lo;
+                            o[2 * w2 + 1] = hi;
                         }
-                        o[2 * w4] = lo;
-                        o[2 * w4 + 1] = hi;
+                        *((uint4*)(args.out + po + 2 * e) + h) = make_uint4(o[0], o[1], o[2], o[3]);
                     }
-                    uint4* dst = (uint4*)(args.out + po + 2 * e);
-                    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
-                    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
                 }
             }
         }

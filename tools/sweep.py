@@ -31,28 +31,41 @@ def colmajor(x):  # numpy (rows, cols) -> torch tensor (cols, rows) holding the 
 
 
 def accuracy():
-    rows = []
-    rng = np.random.default_rng(2024)
+    """testing/test_accuracy.hpp:67-208: S / D / C / Z x both backends, 128 x k x 128, phi sweep; one CSV per type and backend.  The moduli
+    counts follow testing/common.hpp:38-43 (D / Z: up to 20, S / C: up to 12)."""
     m = n = 128
-    for k in [1024, 4096, 16384, 65536]:
-        for phi in [0.0, 0.5, 1.0, 2.0, 4.0]:
-            A = (rng.random((m, k)) - 0.5) * np.exp(phi * rng.standard_normal((m, k)))
-            B = (rng.random((k, n)) - 0.5) * np.exp(phi * rng.standard_normal((k, n)))
-            truth = A.astype(np.longdouble) @ B.astype(np.longdouble)
-            At, Bt = colmajor(A), colmajor(B)
-            nat = torch.matmul(Bt, At).cpu().numpy().T  # (A B)^T in tensor terms
-            rec = {"k": k, "phi": phi, "native_dgemm": float(np.max(np.abs((nat - truth) / truth)))}
-            for N in [8, 10, 12, 14, 16, 18, 20]:
-                for fast in [False, True]:
-                    Cm, _, _ = g.gemm(At, Bt, N, fastmode=fast)
-                    got = Cm.cpu().numpy().T
-                    rec[f"N{N}_{'fast' if fast else 'accu'}"] = float(np.max(np.abs((got - truth) / truth)))
-            rows.append(rec)
-            print(rec, flush=True)
-    with open(os.path.join(out_dir, "accuracy_dgemm_int8.csv"), "w", newline="") as f:
-        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
-        w.writeheader()
-        w.writerows(rows)
+    types = [("dgemm", np.float64, False), ("sgemm", np.float32, False), ("zgemm", np.float64, True), ("cgemm", np.float32, True)]
+    for name, rdt, cplx in types:
+        for bname, be in (("int8", g.INT8), ("fp8", g.FP8)):
+            rows = []
+            rng = np.random.default_rng(2024)
+            ks = [1024, 4096, 16384] if cplx else [1024, 4096, 16384, 65536]   # (the 80-bit complex reference product at k = 65536 takes minutes on the host)
+            mods = ([8, 10, 12, 14, 16, 18, 20] if rdt == np.float64 else [3, 4, 6, 8, 10, 12])
+            for k in ks:
+                for phi in [0.0, 0.5, 1.0, 2.0, 4.0]:
+                    def rnd(shape):
+                        x = ((rng.random(shape) - 0.5) * np.exp(phi * rng.standard_normal(shape))).astype(rdt)
+                        if cplx:
+                            x = x + 1j * ((rng.random(shape) - 0.5) * np.exp(phi * rng.standard_normal(shape))).astype(rdt)
+                        return x
+                    A, B = rnd((m, k)), rnd((k, n))
+                    hp = np.clongdouble if cplx else np.longdouble
+                    truth = A.astype(hp) @ B.astype(hp)
+                    At, Bt = colmajor(A), colmajor(B)
+                    nat = torch.matmul(Bt, At).cpu().numpy().T  # (A B)^T in tensor terms
+                    den = np.abs(truth)
+                    rec = {"k": k, "phi": phi, "native": float(np.max(np.abs(nat - truth) / den))}
+                    for N in mods:
+                        for fast in [False, True]:
+                            Cm, _, _ = g.gemm(At, Bt, N, fastmode=fast, backend=be)
+                            got = Cm.cpu().numpy().T
+                            rec[f"N{N}_{'fast' if fast else 'accu'}"] = float(np.max(np.abs(got - truth) / den))
+                    rows.append(rec)
+                    print(name, bname, rec, flush=True)
+            with open(os.path.join(out_dir, f"accuracy_{name}_{bname}.csv"), "w", newline="") as f:
+                w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+                w.writeheader()
+                w.writerows(rows)
 
 
 def timed(fn, reps=10, warm=2):
