@@ -131,14 +131,16 @@ __device__ __forceinline__ void quad_transpose4(unsigned (&w)[4], unsigned q) {
 }
 
 // v[0..3] = x[k0 .. k0+3], zero beyond k: 16-byte loads when the four elements exist and start on a 16-byte boundary
-template <typename T> __device__ __forceinline__ void load4(const T* x, size_t k0, size_t k, T (&v)[4]) {
+// NT: non-temporal (the data is read once); false where the same workgroup re-reads the row right away (two-pass bound extract: with nt
+// loads in the maxima pass the second pass went back to HBM -- ZGEMM 8192^3 bounds phase 2.58 -> 2.81 ms)
+template <typename T, bool NT = true> __device__ __forceinline__ void load4(const T* x, size_t k0, size_t k, T (&v)[4]) {
     const T* p = x + k0;
     if (OZ2_STAGE_VLOAD && k0 + 4 <= k && (reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
         typedef unsigned V4 __attribute__((ext_vector_type(4)));
         constexpr int NQ = (int)(4 * sizeof(T) / 16);
         V4 r[NQ];
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) r[i] = __builtin_nontemporal_load((const V4*)p + i);  // the operand is streamed: read once per kernel
+        for (int i = 0; i < NQ; ++i) r[i] = NT ? __builtin_nontemporal_load((const V4*)p + i) : ((const V4*)p)[i];
         __builtin_memcpy(v, r, sizeof(r));
     } else {
 #pragma unroll
@@ -170,6 +172,9 @@ struct StageArgs {
 #define OZ2_ZW ((size_t)blockIdx.z * a.bw)
 #define OZ2_ZX ((size_t)blockIdx.z * a.bx)
 
+#ifndef OZ2_AMAX_PREFETCH
+#define OZ2_AMAX_PREFETCH 1  // row-maximum loops keep several loads in flight per thread (experiment switch)
+#endif
 #ifndef OZ2_STAGE_KCHUNK
 #define OZ2_STAGE_KCHUNK 1  // K-major quantise: grid over (row, 1024-wide k chunk) instead of one workgroup looping over a whole row
 #endif
@@ -480,7 +485,7 @@ template <typename T, int MODE>
 __global__ void __launch_bounds__(256) stage_kmajor_kernel(const StageArgs a) {
     using E = ET<T>;
     using U = typename E::U;
-    if constexpr (MODE == MODE_MOD && OZ2_STAGE_KCHUNK) {
+    if constexpr (MODE == MODE_MOD && OZ2_STAGE_KCHUNK && sizeof(T) <= 8) {  // (16-byte elements measured 4 % better with the row loop)
         // quantise: one workgroup per 1024-wide k chunk of a row, the chunk index fastest: the workgroups in flight walk through
         // memory together (one row after the other) instead of streaming ~2000 rows at once
         const unsigned nch = (unsigned)(a.kp / 1024 + (a.kp % 1024 != 0));
@@ -532,10 +537,16 @@ __global__ void __launch_bounds__(256) stage_kmajor_kernel(const StageArgs a) {
             return;
         }
         U am = 0;
-        for (size_t k0 = (size_t)threadIdx.x * 4; k0 < a.k; k0 += 2048) {  // two 4-element groups in flight per thread
+        for (size_t kk = threadIdx.x; !OZ2_AMAX_PREFETCH && kk < a.k; kk += 256) {
+            const T v = x[kk];
+            const U ar = (U)fabs(E::re(v)), ai = (U)fabs(E::im(v));
+            am = ar > am ? ar : am;
+            am = ai > am ? ai : am;
+        }
+        for (size_t k0 = (size_t)threadIdx.x * 4; OZ2_AMAX_PREFETCH && k0 < a.k; k0 += 2048) {  // two 4-element groups in flight per thread
             T v0[4], v1[4];
-            load4<T>(x, k0, a.k, v0);
-            load4<T>(x, k0 + 1024 < a.k ? k0 + 1024 : k0, a.k, v1);
+            load4<T, false>(x, k0, a.k, v0);
+            load4<T, false>(x, k0 + 1024 < a.k ? k0 + 1024 : k0, a.k, v1);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const U ar = (U)fabs(E::re(v0[e])), ai = (U)fabs(E::im(v0[e])), br = (U)fabs(E::re(v1[e])), bi = (U)fabs(E::im(v1[e]));
@@ -646,7 +657,7 @@ template <typename T> __global__ void __launch_bounds__(256) amax_strided_kernel
     if (row < rows) {
         const T* x = X + row;
         size_t kk = kbeg + ky;
-        for (; kk + 12 < kend; kk += 16) {  // four strided loads in flight per thread
+        for (; OZ2_AMAX_PREFETCH && kk + 12 < kend; kk += 16) {  // four strided loads in flight per thread
             T v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) v[u] = x[(kk + 4 * u) * ld];
@@ -679,7 +690,7 @@ template <typename T> __global__ void __launch_bounds__(256) amax_strided_kernel
 template <typename T, int MODE> static hipError_t launch_stage(hipStream_t stream, bool kmajor, const StageArgs& a) {
     if (kmajor) {
         size_t blocks = a.rows;
-        if (MODE == MODE_MOD && OZ2_STAGE_KCHUNK) blocks *= (a.kp + 1023) / 1024;
+        if (MODE == MODE_MOD && OZ2_STAGE_KCHUNK && sizeof(T) <= 8) blocks *= (a.kp + 1023) / 1024;
         if (blocks > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
         dim3 grid((unsigned)blocks, 1, g_batch.batch);
         hipLaunchKernelGGL((stage_kmajor_kernel<T, MODE>), grid, dim3(256), 0, stream, a);

@@ -4,7 +4,7 @@
 #   2. MFMA-busy / shader-cycle / LDS / L2 counters of the INT8 GEMM kernel  -> <tag>_pmc_mfma_summary.txt
 #   3. FETCH_SIZE and WRITE_SIZE (separate passes) of every kernel of a step -> <tag>_pmc_fetch / <tag>_pmc_write (tools/pmc_traffic.py)
 # Counter passes run with --kernel-trace only (never combined with sys/hip/hsa tracing on this pool).
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
