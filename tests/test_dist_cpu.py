@@ -68,6 +68,19 @@ def _worker(rank, world, port, plan, N, fast, m, n, k, typ, opA, opB, grid_rows,
         assert np.array_equal(Cbuf[c0:c1, r0:r1].view(np.uint8), untouched[c0:c1, r0:r1].view(np.uint8)), "allgather changed the own block"
         assert np.all(Cbuf[:, m:] == 7.25), "padding between the columns of C was written"
         calls = eng.calls
+        # accounting of gemmul8_dist_exchange_bytes: what the ranks send in total is what they receive in total; the block plan moves
+        # nothing but the bounds vector; exchange events are accepted (and ignored) with a non-HIP engine
+        ar, tx, rx = pl.exchange_bytes()
+        pl.set_exchange_events(None)
+        import torch
+        tot = torch.tensor([tx, rx], dtype=torch.int64)
+        dist.all_reduce(tot)
+        assert int(tot[0]) == int(tot[1]), (plan, tot)
+        if plan == "blocks":
+            assert tx == 0 and rx == 0 and ar == (0 if fast or world == 1 else 4 * (m + n))
+        else:
+            assert (ar > 0) == (not fast and world > 1)
+        assert comm.rccl_ranks() == -1
         pl.close()
         if rank == 0:
             full = np.ascontiguousarray(Cbuf[:, :m].T)
