@@ -172,6 +172,9 @@ struct StageArgs {
 #define OZ2_ZW ((size_t)blockIdx.z * a.bw)
 #define OZ2_ZX ((size_t)blockIdx.z * a.bx)
 
+#ifndef OZ2_STAGE_PAIRLOAD
+#define OZ2_STAGE_PAIRLOAD 1  // row-strided kernels, 8-byte elements: two rows per lane and 16-byte load
+#endif
 #ifndef OZ2_AMAX_PREFETCH
 #define OZ2_AMAX_PREFETCH 1  // row-maximum loops keep several loads in flight per thread (experiment switch)
 #endif
@@ -604,7 +607,39 @@ __global__ void __launch_bounds__(256) stage_strided_kernel(const StageArgs a) {
 #endif
     const size_t r0 = (size_t)rt * TR;
     const size_t kb = (size_t)kt * TK;
-    {
+    if constexpr (OZ2_STAGE_PAIRLOAD && sizeof(T) == 8) {
+        // 8-byte elements: a lane fetches TWO consecutive rows with one 16-byte load (half the load instructions, 1 KiB per wave
+        // instruction instead of 512 B) when both rows exist and the pair is 16-byte aligned; all loads of the tile are in flight at once
+        constexpr int RP = TR / 2;       // row pairs per column
+        constexpr int KY = 256 / RP;     // k values fetched per pass
+        const int rp = threadIdx.x % RP, ky = threadIdx.x / RP;
+        const size_t row = r0 + 2 * rp;
+        const T* x = (const T*)((const char*)a.X + OZ2_ZX) + row;
+        const bool pair_ok = row + 1 < a.rows && ((reinterpret_cast<uintptr_t>(x) | (a.ld * sizeof(T))) & 15u) == 0;
+        typedef unsigned V4 __attribute__((ext_vector_type(4)));
+        V4 buf[TK / KY];
+#pragma unroll
+        for (int it = 0; it < TK / KY; ++it) {
+            const size_t kg = kb + ky + KY * it;
+            V4 v = {0u, 0u, 0u, 0u};
+            if (kg < a.k) {
+                if (pair_ok) {
+                    v = __builtin_nontemporal_load((const V4*)(x + kg * a.ld));
+                } else {
+                    T t0 = (row < a.rows) ? x[kg * a.ld] : E::zero(), t1 = (row + 1 < a.rows) ? x[kg * a.ld + 1] : E::zero();
+                    __builtin_memcpy(&v, &t0, 8);
+                    __builtin_memcpy((char*)&v + 8, &t1, 8);
+                }
+            }
+            buf[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < TK / KY; ++it) {
+            const int kk = ky + KY * it;
+            __builtin_memcpy(&tile[2 * rp][kk], &buf[it], 8);
+            __builtin_memcpy(&tile[2 * rp + 1][kk], (const char*)&buf[it] + 8, 8);
+        }
+    } else {
         constexpr int KY = 256 / TR;  // k values fetched per pass
         const int rx = threadIdx.x % TR, ky = threadIdx.x / TR;
         const size_t row = r0 + rx;
@@ -648,41 +683,66 @@ template <typename T> __global__ void __launch_bounds__(256) amax_strided_kernel
     using E = ET<T>;
     using U = typename E::U;
     using UB = typename std::conditional<sizeof(U) == 8, unsigned long long, unsigned>::type;
-    __shared__ U sm[4][64];
-    const int rx = threadIdx.x & 63, ky = threadIdx.x >> 6;
-    const size_t row = (size_t)blockIdx.x * 64 + rx;
+    // a lane owns RPL consecutive rows = 16 bytes of a column (one 16-byte load when they exist and are aligned); 64 rows per workgroup,
+    // the remaining lanes spread over KL k-lanes
+    constexpr int RPL = OZ2_STAGE_PAIRLOAD ? 16 / (int)sizeof(T) : 1;
+    constexpr int LPC = 64 / RPL, KL = 256 / LPC;
+    __shared__ U sm[KL][64];
+    const int rl = threadIdx.x % LPC, ky = threadIdx.x / LPC;
+    const size_t row0 = (size_t)blockIdx.x * 64 + (size_t)rl * RPL;
     const size_t kper = (k + gridDim.y - 1) / gridDim.y;
     const size_t kbeg = (size_t)blockIdx.y * kper, kend = (kbeg + kper < k) ? kbeg + kper : k;
-    U am = 0;
-    if (row < rows) {
-        const T* x = X + row;
+    U am[RPL];
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) am[j] = 0;
+    auto take = [&](const T& v, int j) {
+        const U ar = (U)fabs(E::re(v)), ai = (U)fabs(E::im(v));
+        am[j] = ar > am[j] ? ar : am[j];
+        am[j] = ai > am[j] ? ai : am[j];
+    };
+    if (row0 < rows) {
+        const T* x = X + row0;
+        const bool vec = RPL > 1 && row0 + RPL <= rows && ((reinterpret_cast<uintptr_t>(x) | (ld * sizeof(T))) & 15u) == 0;
         size_t kk = kbeg + ky;
-        for (; OZ2_AMAX_PREFETCH && kk + 12 < kend; kk += 16) {  // four strided loads in flight per thread
-            T v[4];
+        if (vec) {
+            typedef unsigned V4 __attribute__((ext_vector_type(4)));
+            for (; OZ2_AMAX_PREFETCH && kk + 3 * KL < kend; kk += 4 * KL) {  // four strided 16-byte loads in flight per thread
+                V4 raw[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = x[(kk + 4 * u) * ld];
+                for (int u = 0; u < 4; ++u) raw[u] = *(const V4*)(x + (kk + (size_t)KL * u) * ld);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const U ar = (U)fabs(E::re(v[u])), ai = (U)fabs(E::im(v[u]));
-                am = ar > am ? ar : am;
-                am = ai > am ? ai : am;
+                for (int u = 0; u < 4; ++u) {
+                    T v[RPL];
+                    __builtin_memcpy(v, &raw[u], 16);
+#pragma unroll
+                    for (int j = 0; j < RPL; ++j) take(v[j], j);
+                }
+            }
+            for (; kk < kend; kk += KL) {
+                T v[RPL];
+                const V4 raw = *(const V4*)(x + kk * ld);
+                __builtin_memcpy(v, &raw, 16);
+#pragma unroll
+                for (int j = 0; j < RPL; ++j) take(v[j], j);
+            }
+        } else {
+            for (; kk < kend; kk += KL) {
+#pragma unroll
+                for (int j = 0; j < RPL; ++j)
+                    if (row0 + j < rows) take(x[kk * ld + j], j);
             }
         }
-        for (; kk < kend; kk += 4) {
-            const T v = x[kk * ld];
-            const U ar = (U)fabs(E::re(v)), ai = (U)fabs(E::im(v));
-            am = ar > am ? ar : am;
-            am = ai > am ? ai : am;
-        }
     }
-    sm[ky][rx] = am;
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) sm[ky][rl * RPL + j] = am[j];
     __syncthreads();
-    if (ky == 0 && row < rows) {
-        am = sm[1][rx] > am ? sm[1][rx] : am;
-        am = sm[2][rx] > am ? sm[2][rx] : am;
-        am = sm[3][rx] > am ? sm[3][rx] : am;
+    const size_t row = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x < 64 && row < rows) {
+        U m = sm[0][threadIdx.x];
+#pragma unroll
+        for (int y = 1; y < KL; ++y) m = sm[y][threadIdx.x] > m ? sm[y][threadIdx.x] : m;
         UB bits;
-        __builtin_memcpy(&bits, &am, sizeof(U));
+        __builtin_memcpy(&bits, &m, sizeof(U));
         if (bits) atomicMax((UB*)amax + row, bits);  // non-negative IEEE values order like unsigned integers
     }
 }
@@ -951,60 +1011,81 @@ template <typename T> __global__ void __launch_bounds__(256) fast_shift_kmajor_k
     }
 }
 
-// Row-strided: RPB rows x 32 k-lanes per block (scaling_fast_real.hpp:27-49: 32 x 32).  The reduction ORDER is the reference's for every
-// RPB: lane ty of a row adds the squares of columns ty, ty + 32, ... in sequence, then a width-32 tree over the 32 lanes.  RPB = 8
-// gives four times the workgroups when the operand has few rows (1024 rows: 128 instead of 32 workgroups on 256 CUs).  The loads of
+// Row-strided (scaling_fast_real.hpp:27-49: 32 rows x 32 k-lanes per block).  The reduction ORDER is the reference's: lane ty of a row adds
+// the squares of columns ty, ty + 32, ... in sequence, then a width-32 tree over the 32 lanes.  Geometry here: 256 threads = 8 lanes per
+// column x 32 k-lanes; a lane owns RPL = 16 / sizeof(T) consecutive rows (one 16-byte load per column when aligned), a workgroup 8 RPL rows
+// = one 128-byte line per column -- 512 workgroups for 8192 rows of doubles where the 32 x 32 form had 256 and 8-byte loads.  The loads of
 // eight chain steps are issued ahead of their round-up FMAs: the chain itself is sequential, and with one load per step it ran at one
 // memory latency per element (289 us for 1024 x 16384 doubles; 128 MiB).
-template <typename T, int RPB> __global__ void __launch_bounds__(RPB * 32) fast_shift_strided_kernel(const T* X, size_t ld, size_t rows, size_t k, int16_t* sft, float log2P, size_t bx, size_t bw) {
+template <typename T> __global__ void __launch_bounds__(256) fast_shift_strided_kernel(const T* X, size_t ld, size_t rows, size_t k, int16_t* sft, float log2P, size_t bx, size_t bw) {
     X = (const T*)((const char*)X + blockIdx.z * bx);  // batched launch: item blockIdx.z
     sft = (int16_t*)((char*)sft + blockIdx.z * bw);
     using E = ET<T>;
     using U = typename E::U;
+    constexpr int RPL = 16 / (int)sizeof(T), RPB = 8 * RPL;
     __shared__ U samax[32][RPB + 1], ssum[32][RPB + 1];
-    const int tx = threadIdx.x % RPB, ty = threadIdx.x / RPB;
-    size_t row = (size_t)blockIdx.x * RPB + tx;
-    U amax = 0, sum = 0;
-    if (row < rows) {
-        const T* x = X + row;
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    const size_t row0 = (size_t)blockIdx.x * RPB + (size_t)tx * RPL;
+    U amax[RPL], sum[RPL];
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) amax[j] = 0, sum[j] = 0;
+    auto take = [&](const T& v, int j) {
+        const U ar = (U)fabs(E::re(v));
+        amax[j] = ar > amax[j] ? ar : amax[j];
+        sum[j] = sqr_add_ru<U>(ar, sum[j]);
+        if constexpr (E::cplx) {
+            const U ai = (U)fabs(E::im(v));
+            amax[j] = ai > amax[j] ? ai : amax[j];
+            sum[j] = sqr_add_ru<U>(ai, sum[j]);
+        }
+    };
+    if (row0 < rows) {
+        const T* x = X + row0;
+        const bool vec = row0 + RPL <= rows && ((reinterpret_cast<uintptr_t>(x) | (ld * sizeof(T))) & 15u) == 0;
         size_t col = ty;
-        for (; col + 7 * 32 < k; col += 8 * 32) {
-            T v[8];
+        if (vec) {
+            typedef unsigned V4 __attribute__((ext_vector_type(4)));
+            for (; col + 7 * 32 < k; col += 8 * 32) {
+                V4 raw[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = x[(col + 32 * u) * ld];
+                for (int u = 0; u < 8; ++u) raw[u] = *(const V4*)(x + (col + 32 * u) * ld);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const U ar = (U)fabs(E::re(v[u]));
-                amax = ar > amax ? ar : amax;
-                sum = sqr_add_ru<U>(ar, sum);
-                if constexpr (E::cplx) {
-                    const U ai = (U)fabs(E::im(v[u]));
-                    amax = ai > amax ? ai : amax;
-                    sum = sqr_add_ru<U>(ai, sum);
+                for (int u = 0; u < 8; ++u) {
+                    T v[RPL];
+                    __builtin_memcpy(v, &raw[u], 16);
+#pragma unroll
+                    for (int j = 0; j < RPL; ++j) take(v[j], j);
                 }
             }
-        }
-        for (; col < k; col += 32) {
-            const T v = x[col * ld];
-            const U ar = (U)fabs(E::re(v));
-            amax = ar > amax ? ar : amax;
-            sum = sqr_add_ru<U>(ar, sum);
-            if constexpr (E::cplx) {
-                const U ai = (U)fabs(E::im(v));
-                amax = ai > amax ? ai : amax;
-                sum = sqr_add_ru<U>(ai, sum);
+            for (; col < k; col += 32) {
+                T v[RPL];
+                const V4 raw = *(const V4*)(x + col * ld);
+                __builtin_memcpy(v, &raw, 16);
+#pragma unroll
+                for (int j = 0; j < RPL; ++j) take(v[j], j);
+            }
+        } else {
+            for (; col < k; col += 32) {
+#pragma unroll
+                for (int j = 0; j < RPL; ++j)
+                    if (row0 + j < rows) take(x[col * ld + j], j);
             }
         }
     }
-    samax[ty][tx] = amax;
-    ssum[ty][tx] = sum;
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) {
+        samax[ty][tx * RPL + j] = amax[j];
+        ssum[ty][tx * RPL + j] = sum[j];
+    }
     __syncthreads();
-    // thread r * 32 + l holds lane l of row r: width-32 trees
-    const int rr = threadIdx.x >> 5, ll = threadIdx.x & 31;
-    sum = tree32_sum_ru(ssum[ll][rr]);
-    amax = tree32_max(samax[ll][rr]);
-    row = (size_t)blockIdx.x * RPB + rr;
-    if (row < rows && ll == 0) sft[row] = (int16_t)(-fast_sft(amax, sum, log2P));
+    // thread r * 32 + l holds lane l of row r: width-32 trees, 8 rows per sweep
+    const int ll = threadIdx.x & 31;
+    for (int rr = threadIdx.x >> 5; rr < RPB; rr += 8) {
+        const U s = tree32_sum_ru(ssum[ll][rr]);
+        const U m = tree32_max(samax[ll][rr]);
+        const size_t row = (size_t)blockIdx.x * RPB + rr;
+        if (row < rows && ll == 0) sft[row] = (int16_t)(-fast_sft(m, s, log2P));
+    }
 }
 
 hipError_t launch_fast_shift(hipStream_t stream, int dtype, int backend, unsigned N, bool kmajor, size_t rows, size_t k, const void* X,
@@ -1019,21 +1100,14 @@ hipError_t launch_fast_shift(hipStream_t stream, int dtype, int backend, unsigne
         case kC32: hipLaunchKernelGGL(fast_shift_kmajor_kernel<float2>, grid, dim3(256), 0, stream, (const float2*)X, ld, k, sft, log2P, xstride, g_batch.ws); break;
         case kC64: hipLaunchKernelGGL(fast_shift_kmajor_kernel<double2>, grid, dim3(256), 0, stream, (const double2*)X, ld, k, sft, log2P, xstride, g_batch.ws); break;
         }
-    } else if (rows >= 32 * 512) {
-        dim3 grid((unsigned)((rows + 31) / 32), 1, g_batch.batch);
+    } else {
+        const size_t rpb = 8 * (16 / (is_f32(dtype) ? 4 : 8) / (is_complex(dtype) ? 2 : 1));
+        dim3 grid((unsigned)((rows + rpb - 1) / rpb), 1, g_batch.batch);
         switch (dtype) {
-        case kF32: hipLaunchKernelGGL((fast_shift_strided_kernel<float, 32>), grid, dim3(1024), 0, stream, (const float*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
-        case kF64: hipLaunchKernelGGL((fast_shift_strided_kernel<double, 32>), grid, dim3(1024), 0, stream, (const double*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
-        case kC32: hipLaunchKernelGGL((fast_shift_strided_kernel<float2, 32>), grid, dim3(1024), 0, stream, (const float2*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
-        case kC64: hipLaunchKernelGGL((fast_shift_strided_kernel<double2, 32>), grid, dim3(1024), 0, stream, (const double2*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
-        }
-    } else {  // few rows: 8 rows per workgroup (same reduction order, four times the workgroups)
-        dim3 grid((unsigned)((rows + 7) / 8), 1, g_batch.batch);
-        switch (dtype) {
-        case kF32: hipLaunchKernelGGL((fast_shift_strided_kernel<float, 8>), grid, dim3(256), 0, stream, (const float*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
-        case kF64: hipLaunchKernelGGL((fast_shift_strided_kernel<double, 8>), grid, dim3(256), 0, stream, (const double*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
-        case kC32: hipLaunchKernelGGL((fast_shift_strided_kernel<float2, 8>), grid, dim3(256), 0, stream, (const float2*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
-        case kC64: hipLaunchKernelGGL((fast_shift_strided_kernel<double2, 8>), grid, dim3(256), 0, stream, (const double2*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
+        case kF32: hipLaunchKernelGGL(fast_shift_strided_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
+        case kF64: hipLaunchKernelGGL(fast_shift_strided_kernel<double>, grid, dim3(256), 0, stream, (const double*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
+        case kC32: hipLaunchKernelGGL(fast_shift_strided_kernel<float2>, grid, dim3(256), 0, stream, (const float2*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
+        case kC64: hipLaunchKernelGGL(fast_shift_strided_kernel<double2>, grid, dim3(256), 0, stream, (const double2*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
         }
     }
     return hipGetLastError();
