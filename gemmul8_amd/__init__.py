@@ -166,8 +166,8 @@ def gemm(A, B, num_moduli, fastmode=False, backend=INT8, opA="N", opB="N", alpha
     return C_out, (list(tm) if timers else None), work
 
 
-def gemm_batched(A, B, num_moduli, fastmode=False, opA="N", opB="N", alpha=1.0, beta=0.0, C_out=None, work=None, stream=None):
-    """A strided batch as ONE set of launches (gemmul8_gemm_batched; INT8 backend).  A, B (and C_out): contiguous tensors of shape
+def gemm_batched(A, B, num_moduli, fastmode=False, opA="N", opB="N", alpha=1.0, beta=0.0, C_out=None, work=None, stream=None, backend=INT8):
+    """A strided batch as ONE set of launches (gemmul8_gemm_batched).  A, B (and C_out): contiguous tensors of shape
     (batch, cols, rows) -- each item a column-major matrix as in `gemm`; a batch dimension of 1 on A or B broadcasts (stride 0).
     Returns (C, work).  Bit-identical to calling `gemm` per item."""
     import numpy as np
@@ -184,13 +184,13 @@ def gemm_batched(A, B, num_moduli, fastmode=False, opA="N", opB="N", alpha=1.0, 
         C_out = torch.zeros((batch, n, m), dtype=dt, device=A.device)
     assert C_out.is_contiguous() and C_out.dtype == dt and C_out.shape[0] == batch
     if work is None:
-        work = torch.empty(lib().gemmul8_work_size_batched(int(dt.is_complex), INT8, m, n, k, num_moduli, batch), dtype=torch.uint8, device=A.device)
+        work = torch.empty(lib().gemmul8_work_size_batched(int(dt.is_complex), backend, m, n, k, num_moduli, batch), dtype=torch.uint8, device=A.device)
     np_dt = {torch.float32: np.float32, torch.float64: np.float64, torch.complex64: np.complex64, torch.complex128: np.complex128}[dt]
     al, be = np.array([alpha], dtype=np_dt), np.array([beta], dtype=np_dt)
     st = stream if stream is not None else torch.cuda.current_stream(A.device).cuda_stream
     sa = 0 if A.shape[0] == 1 else A.shape[1] * A.shape[2]
     sb = 0 if B.shape[0] == 1 else B.shape[1] * B.shape[2]
-    rc = lib().gemmul8_gemm_batched(st, _dtype_code(dt), INT8, OPS[opA], OPS[opB], m, n, k, al.ctypes.data, A.data_ptr(), lda, sa, B.data_ptr(), ldb, sb,
+    rc = lib().gemmul8_gemm_batched(st, _dtype_code(dt), backend, OPS[opA], OPS[opB], m, n, k, al.ctypes.data, A.data_ptr(), lda, sa, B.data_ptr(), ldb, sb,
                                     be.ctypes.data, C_out.data_ptr(), C_out.shape[2], C_out.shape[1] * C_out.shape[2], batch, num_moduli,
                                     int(fastmode), work.data_ptr())
     check(rc, "gemmul8_gemm_batched")

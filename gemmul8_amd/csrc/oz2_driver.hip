@@ -472,7 +472,7 @@ int gemmul8_gemm_batched(void* stream_, int dtype, int backend, int op_A, int op
     if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
     if (!alpha || !beta || !A || !B || !C || !work) return GEMMUL8_E_ARG;
     if (k > (size_t(1) << 17)) return GEMMUL8_E_ARG;
-    if (backend != kINT8) return GEMMUL8_E_UNSUPPORTED;  // the FP8 kernels take one item at a time
+    if (backend == kFP8 && k > 65536) return GEMMUL8_E_ARG;  // exact FP32 accumulation needs k*16*16 <= 2^24
     if (m == 0 || n == 0 || k == 0 || batch == 0) return GEMMUL8_OK;
     const size_t esz = (is_f32(dtype) ? 4 : 8) * (is_complex(dtype) ? 2 : 1);
     const size_t W = gemmul8_batched_item_bytes(is_complex(dtype), backend, m, n, k, N);

@@ -64,9 +64,22 @@ struct F8Args {
     int* colmax;
     float ku;             // bound inflation, see bound_ku (reference: (k+1) * 2^-24)
     int total_tiles;      // planes * tiles_m * tiles_n
+    int ppi;              // planes per batch item (plane p = item p / ppi, item-relative plane p % ppi); = all planes for one GEMM
+    size_t bstride;       // bytes between the workspaces of consecutive batch items (every pointer above lives in the workspace)
     int moduli[20];
     int sqrtp[6];
 };
+
+// plane p of a (batched) launch: byte offset of its item's workspace and its plane index inside the item (as in oz2_gemm_i8.hip)
+struct F8Plane {
+    size_t boff;
+    int tt;
+};
+__device__ __forceinline__ F8Plane f8_plane(const F8Args& args, int plane) {
+    const int p = __builtin_amdgcn_readfirstlane(plane);
+    const int b = p / args.ppi;
+    return {(size_t)b * args.bstride, p - b * args.ppi};
+}
 
 __device__ __forceinline__ unsigned pack16(int a, int b) { return ((unsigned)a & 0xFFFFu) | ((unsigned)b << 16); }
 
@@ -82,10 +95,17 @@ constexpr int F8_THREADS = 512;
 // exact integers (|c| <= 2^24): one exact FP64 quotient step (five full-rate instructions); the combined value (|v| < 2^18)
 // needs one fp32 step.  p = 1024 (the only even FP8 modulus; the tie +-512 keeps the reference's representative +512): ((a + 511) & 1023) - 511.
 template <int EPI, bool ODD>
-__device__ __forceinline__ void f8_epilogue_mod(const v4f (&acc)[8][4], const F8Args& args, int plane, int i0, int j0, int lane) {
+__device__ __forceinline__ void f8_epilogue_mod(const v4f (&acc)[8][4], const F8Args& args, F8Plane pl, int i0, int j0, int lane) {
     const int c16 = lane & 15;
     const int q = lane >> 4;
+    const int plane = pl.tt;
     const int t = args.t_begin + plane;
+    // batch item: every plane pointer moves by the item's workspace offset (bytes)
+    int16_t* const out_ = (int16_t*)((char*)args.out + pl.boff);
+    const int16_t* const r0_ = (const int16_t*)((const char*)args.r0 + pl.boff);
+    const int16_t* const r1_ = (const int16_t*)((const char*)args.r1 + pl.boff);
+    const int16_t* const rx_ = (const int16_t*)((const char*)args.rx + pl.boff);
+    const int16_t* const ry_ = (const int16_t*)((const char*)args.ry + pl.boff);
     const int p = args.moduli[t];
     // value = k0*R0 + k1*R1 + k2*R2:  square moduli s*(R0+R1) + R2;  Karatsuba 256*R0 + 16*(R2-R0-R1) + R1
     const int k0 = t < 6 ? args.sqrtp[t < 6 ? t : 0] : 240;
@@ -139,10 +159,10 @@ __device__ __forceinline__ void f8_epilogue_mod(const v4f (&acc)[8][4], const F8
             }
             if (col < args.n) {
                 const size_t e = (size_t)col * args.ldo + i0 + tg * 64 + q * 16;
-                int16_t* dst = args.out + (size_t)plane * args.strideO + e;
+                int16_t* dst = out_ + (size_t)plane * args.strideO + e;
                 if constexpr (EPI == EPI_FINAL || EPI == EPI_FINAL_CPLX) {
-                    const uint4* p0 = (const uint4*)(args.r0 + (size_t)plane * args.strideR + e);
-                    const uint4* p1 = (const uint4*)(args.r1 + (size_t)plane * args.strideR + e);
+                    const uint4* p0 = (const uint4*)(r0_ + (size_t)plane * args.strideR + e);
+                    const uint4* p1 = (const uint4*)(r1_ + (size_t)plane * args.strideR + e);
                     const uint4 x0 = p0[0], x1 = p0[1], y0 = p1[0], y1 = p1[1];
                     const unsigned xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                     const unsigned ys[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
@@ -159,8 +179,8 @@ __device__ __forceinline__ void f8_epilogue_mod(const v4f (&acc)[8][4], const F8
                     }
                 }
                 if constexpr (EPI == EPI_FINAL_CPLX) {
-                    const uint4* px = (const uint4*)(args.rx + (size_t)plane * args.strideR + e);
-                    const uint4* py = (const uint4*)(args.ry + (size_t)plane * args.strideR + e);
+                    const uint4* px = (const uint4*)(rx_ + (size_t)plane * args.strideR + e);
+                    const uint4* py = (const uint4*)(ry_ + (size_t)plane * args.strideR + e);
                     const uint4 x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1];
                     const unsigned xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                     const unsigned ys[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
@@ -173,7 +193,7 @@ __device__ __forceinline__ void f8_epilogue_mod(const v4f (&acc)[8][4], const F8
                                       Z = (int)(int16_t)(z[w] >> (16 * hlf));
                             o[2 * w + hlf] = pack16(red_small(X - Y), red_small(Z - X - Y));
                         }
-                    uint4* dc = (uint4*)(args.out + (size_t)plane * args.strideO + 2 * e);
+                    uint4* dc = (uint4*)(out_ + (size_t)plane * args.strideO + 2 * e);
 #pragma unroll
                     for (int w = 0; w < 4; ++w) dc[w] = make_uint4(o[4 * w], o[4 * w + 1], o[4 * w + 2], o[4 * w + 3]);
                 } else {
@@ -189,10 +209,13 @@ __device__ __forceinline__ void f8_epilogue_mod(const v4f (&acc)[8][4], const F8
 // error of the inexact bound products); FMAX and FB3 then reduce row / column maxima (atomicMax on the bit patterns of
 // non-negative floats).
 template <int EPI>
-__device__ __forceinline__ void f8_epilogue_bound(v4f (&acc)[8][4], const F8Args& args, int i0, int j0, int lane) {
+__device__ __forceinline__ void f8_epilogue_bound(v4f (&acc)[8][4], const F8Args& args, F8Plane pl, int i0, int j0, int lane) {
     const int c16 = lane & 15;
     const int q = lane >> 4;
     const float ku = args.ku;
+    float* const fbuf_ = (float*)((char*)args.fbuf + pl.boff);
+    int* const rowmax_ = (int*)((char*)args.rowmax + pl.boff);
+    int* const colmax_ = (int*)((char*)args.colmax + pl.boff);
 #pragma unroll
     for (int tj = 0; tj < 4; ++tj) {
         const int col = j0 + tj * 16 + c16;
@@ -202,7 +225,7 @@ __device__ __forceinline__ void f8_epilogue_bound(v4f (&acc)[8][4], const F8Args
 #pragma unroll
             for (int b = 0; b < 4; ++b) u[b] = __fmaf_ru(ku, acc[ti][tj][b], acc[ti][tj][b]);
             if constexpr (EPI != EPI_FMAX) {
-                float4* fp = (float4*)(args.fbuf + (size_t)col * args.ldo + i0 + ti * 16 + 4 * q);  // this lane's 4 consecutive rows
+                float4* fp = (float4*)(fbuf_ + (size_t)col * args.ldo + i0 + ti * 16 + 4 * q);  // this lane's 4 consecutive rows
                 if (col < args.n) {
                     if constexpr (EPI == EPI_FB1) {
                         *fp = make_float4(u[0], u[1], u[2], u[3]);
@@ -239,7 +262,7 @@ __device__ __forceinline__ void f8_epilogue_bound(v4f (&acc)[8][4], const F8Args
             cm = fmaxf(cm, __shfl_xor(cm, 16));
             cm = fmaxf(cm, __shfl_xor(cm, 32));
             const int col = j0 + tj * 16 + c16;
-            if (q == 0 && col < args.n && cm > 0.0f) atomicMax(args.colmax + col, __float_as_int(cm));
+            if (q == 0 && col < args.n && cm > 0.0f) atomicMax(colmax_ + col, __float_as_int(cm));
         }
 #pragma unroll
         for (int ti = 0; ti < 8; ++ti) {
@@ -254,7 +277,7 @@ __device__ __forceinline__ void f8_epilogue_bound(v4f (&acc)[8][4], const F8Args
                 }
                 w[r] = __float_as_int(v);
             }
-            tile_rowmax_atomic16(w, args.rowmax, i0 + ti * 16, args.m, lane);
+            tile_rowmax_atomic16(w, rowmax_, i0 + ti * 16, args.m, lane);
         }
     }
 }
@@ -289,8 +312,9 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
 #define F8_SET_TILE(vb_)                                                                                                     \
     do {                                                                                                                     \
         const TileMap tmap_ = map_tile((vb_), total, args.tiles_m, args.tiles_n);                                            \
-        gsrc = uniform(isB ? args.B + (size_t)args.planeB[tmap_.plane] * args.strideB + (size_t)tmap_.tn * BN * args.kp      \
-                           : args.A + (size_t)args.planeA[tmap_.plane] * args.strideA + (size_t)tmap_.tm * BM * args.kp);    \
+        const F8Plane pl_ = f8_plane(args, tmap_.plane);                                                                     \
+        gsrc = uniform(isB ? args.B + pl_.boff + (size_t)args.planeB[pl_.tt] * args.strideB + (size_t)tmap_.tn * BN * args.kp \
+                           : args.A + pl_.boff + (size_t)args.planeA[pl_.tt] * args.strideA + (size_t)tmap_.tm * BM * args.kp); \
         const int nvalid_ = isB ? ((args.n - tmap_.tn * BN) < BN ? (args.n - tmap_.tn * BN) : BN) : BM;                       \
         _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                                      \
             const int pp_ = (((wave & 3) * 8 + q) * 64 + lane);                                                              \
@@ -436,11 +460,12 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
             }
             const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n);
             const int i0 = tmap.tm * BM + wm * 128, j0 = tmap.tn * BN + wn * 64;
+            const F8Plane pl = f8_plane(args, tmap.plane);
             if constexpr (EPI == EPI_PART || EPI == EPI_FINAL || EPI == EPI_FINAL_CPLX) {
-                if (args.moduli[args.t_begin + tmap.plane] & 1) f8_epilogue_mod<EPI, true>(acc, args, tmap.plane, i0, j0, lane);
-                else f8_epilogue_mod<EPI, false>(acc, args, tmap.plane, i0, j0, lane);
+                if (args.moduli[args.t_begin + pl.tt] & 1) f8_epilogue_mod<EPI, true>(acc, args, pl, i0, j0, lane);
+                else f8_epilogue_mod<EPI, false>(acc, args, pl, i0, j0, lane);
             } else {
-                f8_epilogue_bound<EPI>(acc, args, i0, j0, lane);
+                f8_epilogue_bound<EPI>(acc, args, pl, i0, j0, lane);
             }
         }
     };
@@ -489,6 +514,10 @@ template <int EPI> static hipError_t launch(hipStream_t stream, F8Args& a, int p
         if (e != hipSuccess) return e;
         attr_set_dev[dev_].store(true, std::memory_order_release);
     }
+    // the items of a batched call fold into the plane sequence: plane p = item p / ppi (oz2_gemm_i8.hip does the same)
+    a.ppi = planes;
+    a.bstride = g_batch.ws;
+    planes *= (int)g_batch.batch;
     a.total_tiles = planes * a.tiles_m * a.tiles_n;
     if (a.total_tiles <= 0) return hipSuccess;
     int grid = num_cus() & ~7;  // persistent: one workgroup per CU (see oz2_gemm_i8.hip)

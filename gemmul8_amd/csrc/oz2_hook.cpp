@@ -687,8 +687,8 @@ hipblasStatus_t hipblasGemmExWithFlags_64(hipblasHandle_t handle, hipblasOperati
 
 // Strided-batched entry points (not hooked by the reference; PyTorch's bmm uses them).  alpha/beta are shared by the batch; element
 // strides are in units of the matrix type.  The items of a batch are independent, and below ~2048^3 one emulated GEMM is ten
-// latency-bound launches that leave most of the chip idle.  INT8 backend: one set of launches for the whole batch (below).  Otherwise
-// (FP8 backend, GEMMUL8_BATCH_FUSED=0, GEMMUL8_DIST) the batch is spread over GEMMUL8_BATCH_STREAMS lanes (default 4, 1 =
+// latency-bound launches that leave most of the chip idle.  Default: one set of launches for the whole batch (below).  Otherwise
+// (GEMMUL8_BATCH_FUSED=0, GEMMUL8_DIST) the batch is spread over GEMMUL8_BATCH_STREAMS lanes (default 4, 1 =
 // serial loop on the handle's stream): lane 0 is the handle's stream with the handle's buffers, every other lane has its own
 // non-blocking stream and workspace; the lanes fork from the handle's stream with an event and join it again before the call
 // returns, so the call stays stream-ordered for the application (and capturable in a HIP graph after one warm-up call).
@@ -704,7 +704,7 @@ static bool emulate_batch(int dtype, size_t elem, hipblasHandle_t handle, hipbla
         if (N < 2u || N > ti.max_moduli) return false;
         if (below_floor(dtype, m, n, k, (double)batch)) return false;
         const int backend = env_backend("GEMMUL8_BACKEND", 0, false);
-        if (backend == GEMMUL8_INT8 && k <= (1 << 17)) {
+        if (k <= (backend == GEMMUL8_FP8 ? 65536 : (1 << 17))) {
             const bool fastmode = env_one(ti.fast);
             auto sp = state_of(handle);
             std::lock_guard<std::mutex> lk(sp->mtx);

@@ -128,8 +128,8 @@ GEMMUL8_API int gemmul8_fused_crt_selected(int dtype, int backend, size_t m, siz
 /* A strided batch of GEMMs (same shape, alpha / beta shared; strides in ELEMENTS of the matrix type, as in
  * hipblas{S,D,C,Z}gemmStridedBatched) as ONE set of launches: every kernel of the pipeline takes the item from gridDim.z, the
  * persistent GEMM kernels run over the items' residue planes in one launch.  `work` holds gemmul8_work_size_batched bytes (the items'
- * workspaces are consecutive blocks of gemmul8_batched_item_bytes).  INT8 backend; GEMMUL8_E_UNSUPPORTED for FP8 (call gemmul8_gemm per
- * item).  Bit-identical to per-item gemmul8_gemm calls.  No counterpart in the reference (it hooks no batched entry point). */
+ * workspaces are consecutive blocks of gemmul8_batched_item_bytes).  Both backends (FP8: k <= 65536 as in gemmul8_gemm).
+ * Bit-identical to per-item gemmul8_gemm calls.  No counterpart in the reference (it hooks no batched entry point). */
 GEMMUL8_API size_t gemmul8_batched_item_bytes(int is_complex, int backend, size_t m, size_t n, size_t k, unsigned num_moduli);
 GEMMUL8_API size_t gemmul8_work_size_batched(int is_complex, int backend, size_t m, size_t n, size_t k, unsigned num_moduli, size_t batch);
 GEMMUL8_API int gemmul8_gemm_batched(void *stream, int dtype, int backend, int op_A, int op_B, size_t m, size_t n, size_t k,

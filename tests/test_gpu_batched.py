@@ -18,9 +18,10 @@ def rand(shape, dtype, rng):
     return x.astype(dtype)
 
 
-def run_batched(A, B, C0, N, fast, opA, opB, alpha, beta, strideB_zero=False):
+def run_batched(A, B, C0, N, fast, opA, opB, alpha, beta, strideB_zero=False, backend=None):
     """A: (batch, colsA, rowsA) torch (column-major items), likewise B, C0.  Returns (batched C, per-item C)."""
     import gemmul8_amd as g
+    be_ = g.INT8 if backend is None else backend
     batch = A.shape[0]
     lda, ldb, ldc = A.shape[2], B.shape[2], C0.shape[2]
     m, k = (lda, A.shape[1]) if opA == "N" else (A.shape[1], lda)
@@ -31,14 +32,14 @@ def run_batched(A, B, C0, N, fast, opA, opB, alpha, beta, strideB_zero=False):
     al, be = np.array([alpha], np_dt), np.array([beta], np_dt)
     st = torch.cuda.current_stream().cuda_stream
     Cb = C0.clone()
-    work = torch.empty(g.lib().gemmul8_work_size_batched(int(dt.is_complex), g.INT8, m, n, k, N, batch), dtype=torch.uint8, device="cuda")
+    work = torch.empty(g.lib().gemmul8_work_size_batched(int(dt.is_complex), be_, m, n, k, N, batch), dtype=torch.uint8, device="cuda")
     sB = 0 if strideB_zero else B.shape[1] * B.shape[2]
-    g.check(g.lib().gemmul8_gemm_batched(st, code, g.INT8, g.OPS[opA], g.OPS[opB], m, n, k, al.ctypes.data, A.data_ptr(), lda,
+    g.check(g.lib().gemmul8_gemm_batched(st, code, be_, g.OPS[opA], g.OPS[opB], m, n, k, al.ctypes.data, A.data_ptr(), lda,
                                          A.shape[1] * A.shape[2], B.data_ptr(), ldb, sB, be.ctypes.data, Cb.data_ptr(), ldc,
                                          C0.shape[1] * C0.shape[2], batch, N, int(fast), work.data_ptr()))
     Ci = C0.clone()
     for b in range(batch):
-        g.gemm(A[b], B[0 if strideB_zero else b], N, fastmode=fast, opA=opA, opB=opB, alpha=alpha, beta=beta, C_out=Ci[b])
+        g.gemm(A[b], B[0 if strideB_zero else b], N, fastmode=fast, backend=be_, opA=opA, opB=opB, alpha=alpha, beta=beta, C_out=Ci[b])
     torch.cuda.synchronize()
     return Cb, Ci
 
@@ -87,13 +88,30 @@ def test_batched_shared_operand_and_oracle():
     assert np.max(np.abs(got - ref)) <= 1e-13 * np.max(np.abs(ref))
 
 
-def test_batched_rejects_fp8_and_is_stream_ordered():
+@pytest.mark.parametrize("dtype,N", [(np.float64, 12), (np.float32, 6), (np.complex128, 9), (np.complex64, 7)])
+@pytest.mark.parametrize("fast", [False, True])
+def test_batched_fp8_backend_equals_per_item(dtype, N, fast):
+    """The FP8 backend in the batched entry point (round 3: the items fold into the FP8 kernels' plane sequence like the INT8 ones):
+    three / nine GEMMs per modulus with int16 scratch planes per item, float bound maxima, complex bound stages -- bitwise equal to
+    per-item gemmul8_gemm calls."""
+    import gemmul8_amd as g
+    rng = np.random.default_rng(100 + N + fast)
+    batch, m, n, k = 4, 150, 70, 210
+    A = torch.from_numpy(rand((batch, k, m), dtype, rng)).cuda()
+    B = torch.from_numpy(rand((batch, n, k), dtype, rng)).cuda()
+    C0 = torch.from_numpy(rand((batch, n, m), dtype, rng)).cuda()
+    alpha, beta = (-1.5, 0.5) if np.dtype(dtype).kind != "c" else (-1.5 + 0.5j, 0.5 - 0.25j)
+    Cb, Ci = run_batched(A, B, C0, N, fast, "N", "N", alpha, beta, backend=g.FP8)
+    assert torch.equal(Cb.view(torch.uint8), Ci.view(torch.uint8)), int((Cb != Ci).sum())
+
+
+def test_batched_work_size_and_fp8_k_limit():
     import gemmul8_amd as g
     one = np.array([1.0])
     x = torch.zeros(64, dtype=torch.float64, device="cuda")
-    rc = g.lib().gemmul8_gemm_batched(None, g.D, g.FP8, 0, 0, 8, 8, 8, one.ctypes.data, x.data_ptr(), 8, 64, x.data_ptr(), 8, 64,
+    rc = g.lib().gemmul8_gemm_batched(None, g.D, g.FP8, 0, 0, 8, 8, 65537, one.ctypes.data, x.data_ptr(), 8, 64, x.data_ptr(), 8, 64,
                                       one.ctypes.data, x.data_ptr(), 8, 64, 1, 8, 0, x.data_ptr())
-    assert rc == -3
+    assert rc == -2   # FP8: k <= 65536 (exact FP32 accumulation), as in gemmul8_gemm
     assert g.lib().gemmul8_work_size_batched(0, g.INT8, 100, 100, 100, 14, 7) == 7 * g.lib().gemmul8_batched_item_bytes(0, g.INT8, 100, 100, 100, 14) + 256
 
 
