@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstddef>
+#include <cstdlib>
 #include <type_traits>
 
 #include "oz2_crt_common.hpp"
@@ -292,6 +294,134 @@ __global__ void __launch_bounds__(OZ2_CRT_BLOCK) __attribute__((amdgpu_waves_per
 
 
 // ---------------------------------------------------------------------------------------------------------------------
+// LDS-DMA form of the CRT kernel for INT8 residues (round 3).  One wave per workgroup; a unit = 1024 consecutive bytes of one column
+// of every residue plane (1024 rows, or 512 complex elements).  The N slices go global -> LDS with `global_load_lds_dwordx4` (1 KiB per
+// instruction, no VGPRs), the lanes then read single bytes with `ds_read_i8` -- the SIGN-EXTENDING byte load replaces the v_bfe_i32 of
+// the register form (one of four VALU operations per residue), the residue vectors no longer occupy 2 x N registers, and up to eleven
+// workgroups per CU (N KiB of LDS each) keep HBM requests in flight while others accumulate.  Lane l reads bytes 128 j + 2 l + h
+// (j = 0..7, h = 0, 1): two consecutive rows (or Re / Im of one complex element), so its results for one j are 16 contiguous bytes of C
+// (8 for float) and a store instruction writes 1 KiB of contiguous memory without any transposition.  Accumulation order, reduction and
+// axpby forms are those of crt_unit: the results are bit-identical (tests/test_gpu_parity.py runs both kernels).
+// Eligibility (launch_crt): int8 residues, (m * COMPS) % 1024 == 0, 16-byte aligned plane slices and C columns.
+#ifndef OZ2_CRT_DMA
+#define OZ2_CRT_DMA 1
+#endif
+
+template <typename U, bool CPLX>
+__global__ void __launch_bounds__(64) crt_dma_kernel(const CrtArgs a, unsigned units_per_col) {
+    extern __shared__ __attribute__((aligned(16))) char dma_lds[];
+    constexpr int COMPS = CPLX ? 2 : 1;
+    const unsigned lane = threadIdx.x;
+    const size_t unit = blockIdx.x;
+    const size_t col = unit / units_per_col;
+    const size_t ub = (unit - col * units_per_col) * 1024;  // first byte of the unit inside the column of a plane
+    const size_t zw = blockIdx.z * a.bw;                  // batched launch: item blockIdx.z
+    const char* src = (const char*)a.Cmid + zw + col * a.ld_mid * COMPS + ub + lane * 16;
+    const unsigned N = a.N;
+    for (unsigned t = 0; t < N; ++t)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)t * a.plane_stride * COMPS),
+                                         (__attribute__((address_space(3))) void*)(dma_lds + t * 1024), 16, 0, 0);
+
+    U al[2] = {(U)a.alpha[0], (U)a.alpha[1]}, be[2] = {(U)a.beta[0], (U)a.beta[1]};
+    int mode = a.mode;
+    if (mode == 5) {
+        al[0] = ((const U*)a.alpha_dev)[0];
+        be[0] = ((const U*)a.beta_dev)[0];
+        if (CPLX) {
+            al[1] = ((const U*)a.alpha_dev)[1];
+            be[1] = ((const U*)a.beta_dev)[1];
+        }
+        mode = 0;
+    }
+    const bool beta0 = be[0] == (U)0 && (!CPLX || be[1] == (U)0);
+    const bool reads_c = (mode == 0 && !beta0) || mode == 2 || mode == 4;
+    const int16_t* sftA_z = (const int16_t*)((const char*)a.sftA + zw);
+    const int sB = (int)((const int16_t*)((const char*)a.sftB + zw))[col];
+    const size_t e0 = ub / COMPS;  // first element (row) of the unit
+    U* Cc = (U*)((char*)a.C + blockIdx.z * a.bc) + (col * a.ldc + e0) * COMPS;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the N slices have landed
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // volatile: single sign-extending byte reads (ds_read_i8); merged into wider reads the compiler would need a v_bfe_i32 per byte again
+    typedef const volatile __attribute__((address_space(3))) signed char* LdsBytes;
+    LdsBytes lb = (LdsBytes)dma_lds + 2 * lane;
+#pragma unroll 1
+    for (int jp = 0; jp < 8; jp += 4) {  // four j (8 values) at a time: 16 FP64 accumulators
+        double Sh[8], Sl[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Sh[e] = 0.0, Sl[e] = 0.0;
+        // Rolled loop over the planes, weights from scalar loads.  Measured and not adopted (tools/hbm_ab.py, 14 real / 20 complex planes): fully
+        // unrolled with the next plane's byte reads issued ahead (SGPR weights spill to VGPR lanes; weights staged in LDS: 319 / 902 us),
+        // rolled with LDS weights (305 / 805 us), with or without the read-ahead -- this plain form: 295 / 765 us.
+        if (a.use_dd) {
+            for (unsigned t = 0; t < N; ++t) {
+                const double qh = a.qh[t], ql = a.ql[t];
+                LdsBytes p = lb + t * 1024 + jp * 128;
+                int cb[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cb[e] = (int)p[(e >> 1) * 128 + (e & 1)];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const double cd = (double)cb[e];
+                    Sh[e] = fma(qh, cd, Sh[e]);
+                    Sl[e] = fma(ql, cd, Sl[e]);
+                }
+            }
+        } else {
+            for (unsigned t = 0; t < N; ++t) {
+                const double q1 = a.q1[t];
+                LdsBytes p = lb + t * 1024 + jp * 128;
+                int cb[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cb[e] = (int)p[(e >> 1) * 128 + (e & 1)];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) Sh[e] = fma(q1, (double)cb[e], Sh[e]);
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = jp + jj;
+            U* dst = Cc + (size_t)(CPLX ? 64 * j + lane : 128 * j + 2 * lane) * COMPS;  // two values: 2 rows, or (Re, Im)
+            U oldc[2] = {(U)0, (U)0};
+            if (reads_c) __builtin_memcpy(oldc, dst, 2 * sizeof(U));
+            int s0, s1;  // this lane's shifts: real -> rows 128 j + 2 l, + 1; complex -> row 64 j + l
+            if constexpr (CPLX) {
+                s0 = s1 = (int)sftA_z[e0 + 64 * j + lane];
+            } else {
+                const unsigned w = *(const unsigned*)(sftA_z + e0 + 128 * j + 2 * lane);
+                s0 = (int)(int16_t)(w & 0xFFFFu), s1 = (int)(int16_t)(w >> 16);
+            }
+            const U x = scalb<U>((U)crt_reduce(a, Sh[2 * jj], Sl[2 * jj]), s0 + sB);
+            const U y = scalb<U>((U)crt_reduce(a, Sh[2 * jj + 1], Sl[2 * jj + 1]), s1 + sB);
+            U o[2];
+            if constexpr (!CPLX) {
+                switch (mode) {
+                case 1: o[0] = x, o[1] = y; break;
+                case 2: o[0] = oldc[0] + x, o[1] = oldc[1] + y; break;
+                case 3: o[0] = -x, o[1] = -y; break;
+                case 4: o[0] = oldc[0] - x, o[1] = oldc[1] - y; break;
+                default: o[0] = fmaU<U>(be[0], oldc[0], al[0] * x), o[1] = fmaU<U>(be[0], oldc[1], al[0] * y); break;
+                }
+            } else {
+                const U cx = oldc[0], cy = oldc[1];
+                switch (mode) {
+                case 1: o[0] = x, o[1] = y; break;
+                case 2: o[0] = cx + x, o[1] = cy + y; break;
+                case 3: o[0] = -x, o[1] = -y; break;
+                case 4: o[0] = cx - x, o[1] = cy - y; break;
+                default:
+                    o[0] = fmaU<U>(-be[1], cy, fmaU<U>(be[0], cx, fmaU<U>(-al[1], y, al[0] * x)));
+                    o[1] = fmaU<U>(be[1], cx, fmaU<U>(be[0], cy, fmaU<U>(al[1], x, al[0] * y)));
+                    break;
+                }
+            }
+            typedef U V2 __attribute__((ext_vector_type(2)));
+            __builtin_nontemporal_store(V2{o[0], o[1]}, (V2*)dst);  // streaming: C is written once and not re-read by this kernel
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Multi-GPU exchange variant (A) of BASELINE.json's north_star / SURVEY.md 8(e): each rank accumulates the CRT sum over ITS
 // moduli only and the ranks add the FP64 partials (RCCL reduce-scatter, sum) before the mod-P reduction.
 //   crt_partial: (Sh, Sl)[j][i] = sum over t in [t_begin, t_end) of fma(q_t, double(C_mid[t][j][i]), .) in ascending t, the same
@@ -523,6 +653,30 @@ hipError_t launch_crt(hipStream_t stream, int dtype, int backend, unsigned N, si
     a.bw = g_batch.ws;
     a.bc = g_batch.sc;
     const bool cplx = is_complex(dtype), i8 = backend == kINT8;
+    {
+        // LDS-DMA form: int8 residues, whole 1024-byte units per column, 16-byte aligned slices and C columns
+        const size_t comps = cplx ? 2 : 1, usz = is_f32(dtype) ? 4 : 8;
+        const char* force = getenv("GEMMUL8_CRT_KERNEL");  // "dma" | "reg": testing switch (default: dma when eligible and large enough)
+        const bool eligible = OZ2_CRT_DMA && i8 && (m * comps) % 1024 == 0 && (ld_mid * comps) % 16 == 0 && (plane_stride * comps) % 16 == 0 &&
+                              ((uintptr_t)Cmid & 15u) == 0 && ((uintptr_t)C & 15u) == 0 && (ldc * comps * usz) % 16 == 0 && (g_batch.ws & 15u) == 0 &&
+                              (g_batch.sc & 15u) == 0;
+        const size_t units = m * comps / 1024 * n;
+        const bool want = force && force[0] == 'd' ? true : force && force[0] == 'r' ? false : units >= 4096;
+        if (eligible && want && units <= 0x7FFFFFFFull) {
+            const unsigned upc = (unsigned)(m * comps / 1024);
+            const size_t lds = (size_t)N * 1024;
+            dim3 grid((unsigned)units, 1, g_batch.batch);
+#define OZ2_CRT_DMA_LAUNCH(U, CP) hipLaunchKernelGGL((crt_dma_kernel<U, CP>), grid, dim3(64), lds, stream, a, upc)
+            switch (dtype) {
+            case kF32: OZ2_CRT_DMA_LAUNCH(float, false); break;
+            case kF64: OZ2_CRT_DMA_LAUNCH(double, false); break;
+            case kC32: OZ2_CRT_DMA_LAUNCH(float, true); break;
+            case kC64: OZ2_CRT_DMA_LAUNCH(double, true); break;
+            }
+#undef OZ2_CRT_DMA_LAUNCH
+            return hipGetLastError();
+        }
+    }
     const size_t rows_per_thread = OZ2_CRT_LB / ((cplx ? 2 : 1) * (i8 ? 1 : 2));
     const size_t threads = ((m + rows_per_thread - 1) / rows_per_thread) * n;
     // small problems keep one unit per thread (more workgroups); large ones take the prefetching form

@@ -340,6 +340,28 @@ def test_bound_gemm_both_tile_sizes(dtype, tile, monkeypatch):
         gu.parity_case(A, B, 14, False, opA=opA, opB=opB)
 
 
+@pytest.mark.parametrize("kernel", ["dma", "reg"])
+@pytest.mark.parametrize("dtype,m", [(np.float64, 1024), (np.float32, 2048), (np.complex128, 512), (np.complex64, 1024)])
+def test_crt_kernels_both_forms(dtype, m, kernel, monkeypatch):
+    """The CRT has two kernels for INT8 residues: the register form (oz2_crt.hip: crt_kernel) and the LDS-DMA form (crt_dma_kernel: slices
+    through global_load_lds, sign-extending byte reads) that large products with whole 1024-byte units per column take.
+    GEMMUL8_CRT_KERNEL forces either; both must reproduce the oracle bit for bit, for every axpby form."""
+    import gpu_util as gu
+    monkeypatch.setenv("GEMMUL8_CRT_KERNEL", kernel)
+    rng = np.random.default_rng(5)
+    n, k = 37, 160
+    cplx = np.dtype(dtype).kind == "c"
+    N = 14 if np.dtype(dtype).itemsize >= 8 and not cplx or np.dtype(dtype) == np.complex128 else 7
+    A = rand((m, k), dtype, rng, phi=1.0)
+    B = rand((k, n), dtype, rng, phi=1.0)
+    C0 = rand((m, n), dtype, rng, phi=0.0)
+    for alpha, beta in [(1.0, 0.0), (1.0, 1.0), (-1.0, 1.0), (-1.5, 0.5), (0.75, 0.0)]:
+        if cplx and alpha == -1.5:
+            alpha, beta = -1.5 + 0.5j, 0.5 - 0.25j
+        gu.parity_case(A, B, N, True, alpha=alpha, beta=beta, C0=C0)
+    gu.parity_case(A, B, N, False, C0=C0)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.complex128])
 def test_bounds_fp8_exact_when_fp32_sums_are_exact(dtype):
     """Operands of one binade: every e4m3 bound value is a multiple of 8 in [64, 256], so the FP32 accumulation of the
