@@ -345,11 +345,15 @@ __global__ void __launch_bounds__(64) crt_dma_kernel(const CrtArgs a, unsigned u
     // volatile: single sign-extending byte reads (ds_read_i8); merged into wider reads the compiler would need a v_bfe_i32 per byte again
     typedef const volatile __attribute__((address_space(3))) signed char* LdsBytes;
     LdsBytes lb = (LdsBytes)dma_lds + 2 * lane;
+#ifndef OZ2_CRT_DMA_J
+#define OZ2_CRT_DMA_J 8  // j per pass (2 values each): 8 -> 32 FP64 accumulators, one pass over the weights (2 / 4 / 8: 330 / 304 / 289 us; LDS, not registers, bounds the occupancy)
+#endif
+    constexpr int PJ = OZ2_CRT_DMA_J, PV = 2 * PJ;
 #pragma unroll 1
-    for (int jp = 0; jp < 8; jp += 4) {  // four j (8 values) at a time: 16 FP64 accumulators
-        double Sh[8], Sl[8];
+    for (int jp = 0; jp < 8; jp += PJ) {
+        double Sh[PV], Sl[PV];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) Sh[e] = 0.0, Sl[e] = 0.0;
+        for (int e = 0; e < PV; ++e) Sh[e] = 0.0, Sl[e] = 0.0;
         // Rolled loop over the planes, weights from scalar loads.  Measured and not adopted (tools/hbm_ab.py, 14 real / 20 complex planes): fully
         // unrolled with the next plane's byte reads issued ahead (SGPR weights spill to VGPR lanes; weights staged in LDS: 319 / 902 us),
         // rolled with LDS weights (305 / 805 us), with or without the read-ahead -- this plain form: 295 / 765 us.
@@ -357,11 +361,11 @@ __global__ void __launch_bounds__(64) crt_dma_kernel(const CrtArgs a, unsigned u
             for (unsigned t = 0; t < N; ++t) {
                 const double qh = a.qh[t], ql = a.ql[t];
                 LdsBytes p = lb + t * 1024 + jp * 128;
-                int cb[8];
+                int cb[PV];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) cb[e] = (int)p[(e >> 1) * 128 + (e & 1)];
+                for (int e = 0; e < PV; ++e) cb[e] = (int)p[(e >> 1) * 128 + (e & 1)];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
+                for (int e = 0; e < PV; ++e) {
                     const double cd = (double)cb[e];
                     Sh[e] = fma(qh, cd, Sh[e]);
                     Sl[e] = fma(ql, cd, Sl[e]);
@@ -371,15 +375,15 @@ __global__ void __launch_bounds__(64) crt_dma_kernel(const CrtArgs a, unsigned u
             for (unsigned t = 0; t < N; ++t) {
                 const double q1 = a.q1[t];
                 LdsBytes p = lb + t * 1024 + jp * 128;
-                int cb[8];
+                int cb[PV];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) cb[e] = (int)p[(e >> 1) * 128 + (e & 1)];
+                for (int e = 0; e < PV; ++e) cb[e] = (int)p[(e >> 1) * 128 + (e & 1)];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) Sh[e] = fma(q1, (double)cb[e], Sh[e]);
+                for (int e = 0; e < PV; ++e) Sh[e] = fma(q1, (double)cb[e], Sh[e]);
             }
         }
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < PJ; ++jj) {
             const int j = jp + jj;
             U* dst = Cc + (size_t)(CPLX ? 64 * j + lane : 128 * j + 2 * lane) * COMPS;  // two values: 2 rows, or (Re, Im)
             U oldc[2] = {(U)0, (U)0};
