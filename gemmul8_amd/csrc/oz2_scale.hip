@@ -253,6 +253,65 @@ template <typename T> __device__ __forceinline__ void emit4_mod_float(const Stag
         }
     }
     auto run = [&]<bool WIDE, bool BIG>() {
+        if constexpr (!WIDE && OZ2_STAGE_V16) {
+            // experiment (see OZ2_STAGE_V16): four planes per trip, quad-transposed so that lane q stores the 16 bytes of plane t + q
+            typedef unsigned V4 __attribute__((ext_vector_type(4)));
+            const unsigned q = threadIdx.x & 3u;
+            int8_t* oq = out - 4 * q;
+            auto pack = [](const int (&r)[4]) {
+                return ((unsigned)r[0] & 0xFFu) | (((unsigned)r[1] & 0xFFu) << 8) | (((unsigned)r[2] & 0xFFu) << 16) | ((unsigned)r[3] << 24);
+            };
+            for (int t = a.t_begin; t < a.t_end; t += 4) {
+                unsigned wr[4] = {0u, 0u, 0u, 0u}, wi[4] = {0u, 0u, 0u, 0u}, ws[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int tp = t + 2 * h;
+                    if (tp >= a.t_end) break;
+                    const double P = a.pairP[(tp - a.t_begin) >> 1], invP = a.pairInvP[(tp - a.t_begin) >> 1];
+                    int Rr[4], Ri[4];
+                    float Fr[4], Fi[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        double R = fma(-rint(xr[e] * invP), P, xr[e]);
+                        if constexpr (BIG) R = fma(-rint(R * invP), P, R);
+                        Rr[e] = (int)R, Fr[e] = (float)R;
+                        if constexpr (E::cplx) {
+                            double I = fma(-rint(xi[e] * invP), P, xi[e]);
+                            if constexpr (BIG) I = fma(-rint(I * invP), P, I);
+                            Ri[e] = (int)I, Fi[e] = (float)I;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int tt = tp + u;
+                        if (tt >= a.t_end) break;
+                        const ModConst mc = a.mt.mc[tt];
+                        int rr[4], ri[4], rs[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            rr[e] = residue_from_small<false>(Rr[e], Fr[e], mc);
+                            if constexpr (E::cplx) {
+                                ri[e] = residue_from_small<false>(Ri[e], Fi[e], mc);
+                                rs[e] = wrapping((int)(int8_t)rr[e] + (int)(int8_t)ri[e], mc.p);
+                            }
+                        }
+                        wr[2 * h + u] = pack(rr);
+                        if constexpr (E::cplx) wi[2 * h + u] = pack(ri), ws[2 * h + u] = pack(rs);
+                    }
+                }
+                quad_transpose4(wr, q);
+                if constexpr (E::cplx) quad_transpose4(wi, q), quad_transpose4(ws, q);
+                if (t + (int)q < a.t_end) {
+                    int8_t* o = oq + (size_t)(t + (int)q) * a.plane_stride;
+                    *(V4*)o = V4{wr[0], wr[1], wr[2], wr[3]};
+                    if constexpr (E::cplx) {
+                        *(V4*)(o + a.part_stride) = V4{wi[0], wi[1], wi[2], wi[3]};
+                        *(V4*)(o + 2 * a.part_stride) = V4{ws[0], ws[1], ws[2], ws[3]};
+                    }
+                }
+            }
+            return;
+        }
         for (int t = a.t_begin; t < a.t_end; t += 2) {
             const double P = a.pairP[(t - a.t_begin) >> 1], invP = a.pairInvP[(t - a.t_begin) >> 1];
             int Rr[4], Ri[4];

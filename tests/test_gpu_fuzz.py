@@ -22,7 +22,7 @@ def _rand(shape, dtype, rng, phi):
 
 
 @pytest.mark.parametrize("seed", range(N_SEEDS))
-def test_random_case_bit_exact(seed):
+def test_random_case_bit_exact(seed, monkeypatch):
     import gemmul8_amd as g
     import gpu_util as gu
     rng = np.random.default_rng(9000 + seed)
@@ -35,6 +35,16 @@ def test_random_case_bit_exact(seed):
     k = int(rng.choice(DIMS_K))
     if backend == g.FP8 or np.dtype(dtype).kind == "c":   # 3-9x the oracle work
         m, n = min(m, 257), min(n, 256)
+    # kernel-selection switches (round 3): the CRT's register / LDS-DMA forms (the latter needs whole 1024-byte units per column:
+    # m = 1024 real, 512 complex) and the bound GEMM's 128 / 256 tiles, drawn per seed; "" = the library's own choice
+    crt_force = str(rng.choice(["", "dma", "reg"]))
+    tile_force = str(rng.choice(["", "128", "256"]))
+    if crt_force == "dma" and backend == g.INT8:
+        m, n = (512 if np.dtype(dtype).kind == "c" else 1024), min(n, 64)
+    if crt_force:
+        monkeypatch.setenv("GEMMUL8_CRT_KERNEL", crt_force)
+    if tile_force:
+        monkeypatch.setenv("GEMMUL8_BOUND_TILE", tile_force)
     cplx = np.dtype(dtype).kind == "c"
     opA = str(rng.choice(["N", "T", "C"] if cplx else ["N", "T"]))
     opB = str(rng.choice(["N", "T", "C"] if cplx else ["N", "T"]))

@@ -189,3 +189,79 @@ def test_wide_byte_dot_residue_fp8_moduli(p):
             s_list.append(lo + 32 * hi)
         assert np.array_equal(finish(s_list), np.array([sym(-(M << E) if neg else (M << E)) for M, E in zip(Ms, Es)]))
 
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 3: the quantise kernels' two-level FLOATING-POINT reduction (oz2_scale.hip: emit4_mod_float, residue_from_small).
+#   level 1 (FP64, per pair P = p_a * p_b):  q = rint(xs * RN(1/P)),  R = fma(-q, P, xs)   -- exact: R = xs - q P, |R| small
+#   level 2 (FP32, per modulus):            qf = fma(float(R), RN_f32(1/p), 1.5 * 2^23)   -- rounds to 1.5 * 2^23 + rint(R/p)
+#                                           r  = R - q p                                   -- v_mad_i32_i24 on the low 24 bits of qf
+# Modelled with exact integer / rational arithmetic and numpy's IEEE operations, compared with the exact symmetric residue.
+FP8_MODULI = [1089, 1024, 961, 841, 625, 529, 511, 509, 503, 499, 491, 487, 481, 479, 467, 463, 461, 457, 449, 443]
+
+
+def _level1(xs_int, P):
+    """xs_int: python ints (|xs| < 2^53 -> one step; larger -> two steps as the kernel's BIG path).  Returns exact R (python ints)."""
+    invP = np.float64(1.0) / np.float64(P)
+    out = []
+    for x in xs_int:
+        xf = np.float64(x)
+        assert int(xf) == x                      # the kernel's xs is an exactly representable double
+        q = int(np.rint(xf * invP))
+        R = x - q * P                            # = fma(-q, P, xs) exactly when representable: checked next
+        assert abs(R) < 2 ** 53
+        if abs(x) >= 2 ** 53:
+            assert abs(R) <= P // 2 + abs(x) * 2.0 ** -51 + 2
+            q2 = int(np.rint(np.float64(R) * invP))
+            R = R - q2 * P
+        assert abs(R) <= P // 2 + 2, (x, P, R)
+        out.append(R)
+    return out
+
+
+def _level2(R, p):
+    """Single-fma quotient on a signed |R| < 2^21 and the i24 multiply-add; returns the int the kernel derives (full value)."""
+    from fractions import Fraction
+    invp = np.float32(1.0) / np.float32(p)
+    exact = Fraction(int(R)) * Fraction(float(invp)) + Fraction(12582912)      # R * RN(1/p) + 1.5 * 2^23, exactly
+    fl = exact.numerator // exact.denominator
+    rem = exact - fl
+    qf = fl + (1 if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and fl % 2 == 1) else 0)   # RN-even at unit spacing
+    assert 2 ** 23 <= qf < 2 ** 24
+    low24 = qf - 2 ** 23                          # low 24 bits of the float's BIT PATTERN: the mantissa field (bit 23 = exponent LSB = 0) = 2^22 + q
+    assert 0 <= low24 < 2 ** 23
+    raw = (low24 * (-p) + int(R))                 # v_mad_i32_i24
+    return raw + (p << 22)                        # the kernel adds p << 22 (mod 2^32) where it needs the value; low byte unchanged
+
+
+def _values(rng, P, big):
+    lim = 2 ** 53 - 1
+    vals = [int(v) for v in rng.integers(-lim, lim, size=300)]
+    vals += [int(q) * P + d for q in rng.integers(-(lim // P), lim // P, size=60) for d in (-(P // 2) - 1, -(P // 2), -1, 0, 1, P // 2, P // 2 + 1)]
+    vals += [0, 1, -1, lim, -lim, P, -P, P // 2, -(P // 2)]
+    vals = [v for v in vals if abs(v) <= lim]
+    if big:   # |xs| >= 2^53: 53-bit mantissa times a power of two (what trunc(ldexp(x, s)) produces for num_moduli > 15)
+        for _ in range(200):
+            m = int(rng.integers(2 ** 52, 2 ** 53)) * (1 if rng.integers(0, 2) else -1)
+            vals.append(m * 2 ** int(rng.integers(1, 38)))
+    return vals
+
+
+@pytest.mark.parametrize("moduli,big", [(INT8_MODULI, True), (FP8_MODULI, True)])
+def test_float_domain_two_level_residue(moduli, big):
+    rng = np.random.default_rng(len(moduli) + moduli[0])
+    pairs = [(moduli[t], moduli[t + 1]) for t in range(0, 19)] + [(p, 1) for p in moduli]   # every consecutive pair (any t_begin) and the odd tail
+    for pa, pb in pairs:
+        P = pa * pb
+        xs = _values(rng, P, big)
+        Rs = _level1(xs, P)
+        for p in (pa, pb):
+            if p == 1:
+                continue
+            for x, R in zip(xs, Rs):
+                r = _level2(R, p)
+                assert (r - x) % p == 0, (x, p, r)
+                if p & 1:
+                    assert abs(r) <= (p - 1) // 2, (x, p, r)          # the canonical symmetric representative
+                else:
+                    assert abs(r) <= p // 2, (x, p, r)                # p = 256: +-128 is the same int8 byte; p = 1024: -512 is mapped to +512
