@@ -1137,7 +1137,7 @@ hipError_t launch_gemm_i8_cplx(hipStream_t stream, const int8_t* A, const int8_t
 }
 
 #ifndef OZ2_MAX_SMALL_TILES
-#define OZ2_MAX_SMALL_TILES 100  // the bound GEMM takes the 128 x 128-tile kernel when (batch x) its 256 x 256 tiles number at most this (of 256 CUs): bounds phase 33 -> 28 / 41 -> 32 / 66 -> 55 us at 512^3 / 1024^3 / 2048^3, but 98 -> 111 us at 3072^3 (144 tiles), profiles/r03_bound_ab.txt
+#define OZ2_MAX_SMALL_TILES 128  // the bound GEMM takes the 128 x 128-tile kernel when (batch x) its 256 x 256 tiles number at most this (of 256 CUs): bounds phase 33 -> 28 / 41 -> 32 / 66 -> 55 us at 512^3 / 1024^3 / 2048^3, but 98 -> 111 us at 3072^3 (144 tiles), profiles/r03_bound_ab.txt
 #endif
 hipError_t launch_gemm_i8_max(hipStream_t stream, int nseg, const int8_t* const* A, const int8_t* const* B, size_t kp, size_t m, size_t n,
                               int* rowmax, int* colmax) {
