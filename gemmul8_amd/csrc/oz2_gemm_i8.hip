@@ -92,6 +92,10 @@ struct GemmArgs {
 #define OZ2_EPI_NT 0  // 1: non-temporal residue stores (experiment: GEMM + CRT at 8192^2 x k, 14 planes: +3 % at k = 256 and 1024, +1 % at 512 and 1536,
                      // -2.5 % at 2048, -1 % at 4096 / 8192 -- the CRT pass loses what the GEMM gains; not adopted)
 #endif
+#ifndef OZ2_CPLX_PK16
+#define OZ2_CPLX_PK16 0  // 1: complex combine epilogue with packed 16-bit arithmetic (two elements per instruction, half the VALU work; bit-identical).
+                         // Measured NOT faster (ZGEMM 8192^3 x 20 moduli low-precision phase 25.85 vs 25.58 ms): the epilogue waits on its X / Y loads, not on VALU
+#endif
 #ifndef OZ2_ABL_EPI
 #define OZ2_ABL_EPI 0  // 1: no stores, 2: every plane takes the p = 256 path (timing ablations only)
 #endif
@@ -183,6 +187,38 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
 #pragma unroll
                         for (int w2 = 0; w2 < 2; ++w2) {
                             unsigned lo = 0, hi = 0;
+                            if constexpr (RED == RED_ODD && OZ2_CPLX_PK16) {
+                                // packed 16-bit form: |X|, |Y|, |Z| <= (p-1)/2, so X - Y lies in (-p, p) and Z - X - Y in (-1.5 p, 1.5 p):
+                                // ONE wrap r = d + p ([d < -h] - [d > h]) gives the canonical residue, and v_pk_*_i16 does two elements per
+                                // instruction (comparisons as arithmetic shifts of h -+ d).  Half the VALU work of the per-element fp32 steps.
+                                typedef short v2s __attribute__((ext_vector_type(2)));
+                                const v2s hv = {(short)((p - 1) >> 1), (short)((p - 1) >> 1)}, pv = {(short)p, (short)p};
+                                auto ev = [](unsigned w) {  // bytes 0, 2 sign-extended into the 16-bit halves
+                                    v2s t;
+                                    __builtin_memcpy(&t, &w, 4);
+                                    return (v2s)((t << 8) >> 8);
+                                };
+                                auto od = [](unsigned w) {  // bytes 1, 3
+                                    v2s t;
+                                    __builtin_memcpy(&t, &w, 4);
+                                    return (v2s)(t >> 8);
+                                };
+                                auto wrap = [&](v2s d) { return (v2s)(d + (((hv - d) >> 15) - ((d + hv) >> 15)) * pv); };
+                                auto bits = [](v2s v) {
+                                    unsigned u;
+                                    __builtin_memcpy(&u, &v, 4);
+                                    return u;
+                                };
+                                const unsigned xw = xs[w2], yw = ys[w2], zw_ = z[2 * h + w2];
+                                const v2s xe = ev(xw), ye = ev(yw), ze = ev(zw_), xo = od(xw), yo = od(yw), zo = od(zw_);
+                                const v2s cre = wrap(xe - ye), cro = wrap(xo - yo);
+                                const v2s cie = wrap(ze - xe - ye), cio = wrap(zo - xo - yo);
+                                // t0 = (Cr, Ci) pairs of bytes 0 and 2, t1 = of bytes 1 and 3; lo = elements 0, 1, hi = elements 2, 3
+                                const unsigned t0 = __builtin_amdgcn_perm(bits(cie), bits(cre), 0x06020400u);
+                                const unsigned t1 = __builtin_amdgcn_perm(bits(cio), bits(cro), 0x06020400u);
+                                lo = __builtin_amdgcn_perm(t1, t0, 0x05040100u);
+                                hi = __builtin_amdgcn_perm(t1, t0, 0x07060302u);
+                            } else
 #pragma unroll
                             for (int b = 0; b < 4; ++b) {
                                 const int X = (int)(int8_t)(xs[w2] >> (8 * b)), Y = (int)(int8_t)(ys[w2] >> (8 * b)), Z = (int)(int8_t)(z[2 * h + w2] >> (8 * b));
