@@ -143,3 +143,18 @@ def test_batched_fuzz(seed):
     alpha, beta = [(1.0, 0.0), (-1.0, 1.0), (0.75, -0.5)][seed % 3]
     Cb, Ci = run_batched(A, B, C0, N, fast, str(opA), str(opB), alpha, beta)
     assert torch.equal(Cb.view(torch.uint8), Ci.view(torch.uint8)), (dtype, N, m, n, k, batch, opA, opB, fast)
+
+
+@pytest.mark.parametrize("dtype,m", [(np.float64, 1024), (np.complex128, 512)])
+def test_batched_with_dma_crt_kernel(dtype, m, monkeypatch):
+    """The LDS-DMA form of the CRT kernel inside a batched launch (item in gridDim.z: workspace and C offsets per item), forced with
+    GEMMUL8_CRT_KERNEL=dma on a shape with whole 1024-byte units per column; beta != 0 so that the old C is read per item."""
+    monkeypatch.setenv("GEMMUL8_CRT_KERNEL", "dma")
+    rng = np.random.default_rng(77)
+    batch, n, k = 3, 40, 96
+    A = torch.from_numpy(rand((batch, k, m), dtype, rng)).cuda()
+    B = torch.from_numpy(rand((batch, n, k), dtype, rng)).cuda()
+    C0 = torch.from_numpy(rand((batch, n, m), dtype, rng)).cuda()
+    alpha, beta = (-1.5, 0.5) if np.dtype(dtype).kind != "c" else (-1.5 + 0.5j, 0.5 - 0.25j)
+    Cb, Ci = run_batched(A, B, C0, 14, False, "N", "N", alpha, beta)
+    assert torch.equal(Cb.view(torch.uint8), Ci.view(torch.uint8)), int((Cb != Ci).sum())
