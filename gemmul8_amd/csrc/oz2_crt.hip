@@ -307,18 +307,23 @@ __global__ void __launch_bounds__(OZ2_CRT_BLOCK) __attribute__((amdgpu_waves_per
 #define OZ2_CRT_DMA 1
 #endif
 
+#ifndef OZ2_CRT_DMA_WAVES
+#define OZ2_CRT_DMA_WAVES 2  // waves per workgroup sharing one unit (1 / 2 / 4: 289 / 266 / 262 us real x 14, 728 / 668 / 697 us complex x 20): each wave fetches half the planes and accumulates half the j (twice
+                             // the waves per CU for the same LDS)
+#endif
 template <typename U, bool CPLX>
-__global__ void __launch_bounds__(64) crt_dma_kernel(const CrtArgs a, unsigned units_per_col) {
+__global__ void __launch_bounds__(64 * OZ2_CRT_DMA_WAVES) crt_dma_kernel(const CrtArgs a, unsigned units_per_col) {
     extern __shared__ __attribute__((aligned(16))) char dma_lds[];
     constexpr int COMPS = CPLX ? 2 : 1;
-    const unsigned lane = threadIdx.x;
+    constexpr int WPB = OZ2_CRT_DMA_WAVES;
+    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const size_t unit = blockIdx.x;
     const size_t col = unit / units_per_col;
     const size_t ub = (unit - col * units_per_col) * 1024;  // first byte of the unit inside the column of a plane
     const size_t zw = blockIdx.z * a.bw;                  // batched launch: item blockIdx.z
     const char* src = (const char*)a.Cmid + zw + col * a.ld_mid * COMPS + ub + lane * 16;
     const unsigned N = a.N;
-    for (unsigned t = 0; t < N; ++t)
+    for (unsigned t = wv; t < N; t += WPB)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)t * a.plane_stride * COMPS),
                                          (__attribute__((address_space(3))) void*)(dma_lds + t * 1024), 16, 0, 0);
 
@@ -339,7 +344,8 @@ __global__ void __launch_bounds__(64) crt_dma_kernel(const CrtArgs a, unsigned u
     const int sB = (int)((const int16_t*)((const char*)a.sftB + zw))[col];
     const size_t e0 = ub / COMPS;  // first element (row) of the unit
     U* Cc = (U*)((char*)a.C + blockIdx.z * a.bc) + (col * a.ldc + e0) * COMPS;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the N slices have landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slices this wave fetched have landed
+    if constexpr (WPB > 1) __syncthreads();           // ... and the other waves' too
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // volatile: single sign-extending byte reads (ds_read_i8); merged into wider reads the compiler would need a v_bfe_i32 per byte again
@@ -348,9 +354,10 @@ __global__ void __launch_bounds__(64) crt_dma_kernel(const CrtArgs a, unsigned u
 #ifndef OZ2_CRT_DMA_J
 #define OZ2_CRT_DMA_J 8  // j per pass (2 values each): 8 -> 32 FP64 accumulators, one pass over the weights (2 / 4 / 8: 330 / 304 / 289 us; LDS, not registers, bounds the occupancy)
 #endif
-    constexpr int PJ = OZ2_CRT_DMA_J, PV = 2 * PJ;
+    constexpr int PJ = (OZ2_CRT_DMA_J * WPB > 8) ? 8 / WPB : OZ2_CRT_DMA_J, PV = 2 * PJ;
+    const int j_begin = (int)wv * (8 / WPB), j_end = j_begin + 8 / WPB;
 #pragma unroll 1
-    for (int jp = 0; jp < 8; jp += PJ) {
+    for (int jp = j_begin; jp < j_end; jp += PJ) {
         double Sh[PV], Sl[PV];
 #pragma unroll
         for (int e = 0; e < PV; ++e) Sh[e] = 0.0, Sl[e] = 0.0;
@@ -670,7 +677,7 @@ hipError_t launch_crt(hipStream_t stream, int dtype, int backend, unsigned N, si
             const unsigned upc = (unsigned)(m * comps / 1024);
             const size_t lds = (size_t)N * 1024;
             dim3 grid((unsigned)units, 1, g_batch.batch);
-#define OZ2_CRT_DMA_LAUNCH(U, CP) hipLaunchKernelGGL((crt_dma_kernel<U, CP>), grid, dim3(64), lds, stream, a, upc)
+#define OZ2_CRT_DMA_LAUNCH(U, CP) hipLaunchKernelGGL((crt_dma_kernel<U, CP>), grid, dim3(64 * OZ2_CRT_DMA_WAVES), lds, stream, a, upc)
             switch (dtype) {
             case kF32: OZ2_CRT_DMA_LAUNCH(float, false); break;
             case kF64: OZ2_CRT_DMA_LAUNCH(double, false); break;
