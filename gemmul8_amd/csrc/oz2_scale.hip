@@ -172,6 +172,9 @@ struct StageArgs {
 #define OZ2_ZW ((size_t)blockIdx.z * a.bw)
 #define OZ2_ZX ((size_t)blockIdx.z * a.bx)
 
+#ifndef OZ2_BOUND_FLOAT
+#define OZ2_BOUND_FLOAT 1
+#endif
 #ifndef OZ2_STAGE_PAIRLOAD
 #define OZ2_STAGE_PAIRLOAD 1  // row-strided kernels, 8-byte elements: two rows per lane and 16-byte load
 #endif
@@ -408,10 +411,13 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
         unsigned wr = 0, wi = 0, wd = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int br = upper_bound_i8(E::re(v[e]), s);
+            // ceil(|x| * 2^s) in FP64 (v_ldexp_f64, v_ceil_f64, v_cvt_i32_f64: exact, the value is below 2^7 by construction of s) instead of
+            // the ~25 integer operations of upper_bound_i8 (kept in oz2_device.hpp; -DOZ2_BOUND_FLOAT=0)
+            auto ub = [&](double x) { return OZ2_BOUND_FLOAT ? (int)ceil(ldexp(fabs(x), s)) : upper_bound_i8(x, s); };
+            const int br = ub(E::re(v[e]));
             wr |= ((unsigned)br & 0xFFu) << (8 * e);
             if constexpr (E::cplx) {
-                const int bi = upper_bound_i8(E::im(v[e]), s);
+                const int bi = ub(E::im(v[e]));
                 wi |= ((unsigned)bi & 0xFFu) << (8 * e);
                 wd |= ((unsigned)(br - bi) & 0xFFu) << (8 * e);
             }
