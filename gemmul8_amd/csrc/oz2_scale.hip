@@ -651,8 +651,11 @@ template <typename T> struct StageTile {
 #ifndef OZ2_STAGE_TR8
 #define OZ2_STAGE_TR8 16  // rows per tile of the 8- and 16-byte element types
 #endif
-    static constexpr int TR = sizeof(T) == 4 ? 32 : OZ2_STAGE_TR8;
-    static constexpr int TK = sizeof(T) == 16 ? 64 : 128;
+#ifndef OZ2_STAGE_Z_WIDE
+#define OZ2_STAGE_Z_WIDE 1  // 16-byte elements: 8 rows x 128 k (128-byte runs per row and plane on the way out) instead of 16 rows x 64 k (64-byte runs)
+#endif
+    static constexpr int TR = sizeof(T) == 4 ? 32 : (sizeof(T) == 16 && OZ2_STAGE_Z_WIDE) ? 8 : OZ2_STAGE_TR8;
+    static constexpr int TK = (sizeof(T) == 16 && !OZ2_STAGE_Z_WIDE) ? 64 : 128;
 };
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) stage_strided_kernel(const StageArgs a) {
