@@ -321,6 +321,10 @@ int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t
     const size_t per_mod = 2 * L->sizeC;
     size_t chunk = L->scratch_bytes / per_mod;
     if (chunk == 0) return GEMMUL8_E_ARG;
+    if (const char* cs = getenv("GEMMUL8_CPLX_CHUNK")) {  // experiment switch: moduli per X / Y / Z launch group
+        const size_t want = (size_t)atoi(cs);
+        if (want >= 1 && want < chunk) chunk = want;
+    }
     int8_t* rx = (int8_t*)L->scratch;
     for (unsigned t0 = t_begin; t0 < t_end; t0 += (unsigned)chunk) {
         const unsigned t1 = std::min<unsigned>(t_end, t0 + (unsigned)chunk);
