@@ -92,6 +92,12 @@ struct GemmArgs {
 #define OZ2_EPI_NT 0  // 1: non-temporal residue stores (experiment: GEMM + CRT at 8192^2 x k, 14 planes: +3 % at k = 256 and 1024, +1 % at 512 and 1536,
                      // -2.5 % at 2048, -1 % at 4096 / 8192 -- the CRT pass loses what the GEMM gains; not adopted)
 #endif
+#ifndef OZ2_CPLX_ABL
+#define OZ2_CPLX_ABL 0  // timing ablations of the complex combine epilogue (wrong results): 1 no X / Y loads, 2 no stores, 4 half the stores.
+                        // ZGEMM 8192^3, 20 moduli, low-precision phase: 25.24 ms shipped, 24.38 (1), 24.47 (2), 23.89 (3) against 23.3 ms
+                        // for 60 plain residue planes -- the whole combine costs 8 %, its compute 2.5 %, loads and stores 2.5-3.5 % each; a
+                        // producer-side touch of the X / Y lines ahead of the epilogue changed nothing (profiles/r03_cplx_abl.txt)
+#endif
 #ifndef OZ2_CPLX_PK16
 #define OZ2_CPLX_PK16 0  // 1: complex combine epilogue with packed 16-bit arithmetic (two elements per instruction, half the VALU work; bit-identical).
                          // Measured NOT faster (ZGEMM 8192^3 x 20 moduli low-precision phase 25.85 vs 25.58 ms): the epilogue waits on its X / Y loads, not on VALU
@@ -180,8 +186,12 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
                     // needed 16 more registers than the 168-VGPR budget leaves beside the accumulators (51-62 spilled registers)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
+#if OZ2_CPLX_ABL & 1  // timing ablations of the complex epilogue (wrong results; -DOZ2_CPLX_ABL=bits): 1 = no X / Y loads
+                        const uint2 x2 = make_uint2(z[2 * h] * 3, z[2 * h + 1] * 5), y2 = make_uint2(z[2 * h] ^ 0x55u, z[2 * h + 1] + 7u);
+#else
                         const uint2 x2 = *(const uint2*)(args.rx + pr + e + 8 * h);
                         const uint2 y2 = *(const uint2*)(args.ry + pr + e + 8 * h);
+#endif
                         const unsigned xs[2] = {x2.x, x2.y}, ys[2] = {y2.x, y2.y};
                         unsigned o[4];
 #pragma unroll
@@ -230,7 +240,13 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
                             o[2 * w2] = lo;
                             o[2 * w2 + 1] = hi;
                         }
+#if OZ2_CPLX_ABL & 2  // timing ablation (wrong results): no stores
+                        asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
+#elif OZ2_CPLX_ABL & 4  // timing ablation (wrong results): half the stores
+                        if (h == 0) *((uint4*)(args.out + po + 2 * e) + h) = make_uint4(o[0] ^ o[2], o[1] ^ o[3], o[2], o[3]);
+#else
                         *((uint4*)(args.out + po + 2 * e) + h) = make_uint4(o[0], o[1], o[2], o[3]);
+#endif
                     }
                 }
             }
