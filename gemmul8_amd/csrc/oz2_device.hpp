@@ -157,6 +157,15 @@ __device__ __forceinline__ int mod_i32_sym_odd_f64(int a, double p, double invp)
     const double q = rint(x * invp);
     return (int)fma(-q, p, x);
 }
+// 0 <= s < 2^22, odd p: s * |RN(1/p) - 1/p| <= 2^22 2^-24 / p < 1/(2p), so fma(s, RN(1/p), 2^23) rounds (RN-even at unit spacing) to
+// 2^23 + q with q = rint(s / p) exactly; the low 24 bits of its bit pattern are q, which v_mad_i32_i24(bits, -p, s) = s - q p turns
+// into the canonical residue in [-(p-1)/2, (p-1)/2] (same step as finish_residue).
+__device__ __forceinline__ int mod_small_sym_u(unsigned s, int p, float invp) {
+    const float qf = fmaf((float)s, invp, 8388608.0f);
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(__float_as_int(qf)), "s"(-p), "v"(s));
+    return r;
+}
 // |a| < 2^16: one exact step
 __device__ __forceinline__ int mod_small_sym_odd(int a, int p, float invp) {
     return a - __mul24((int)rintf((float)a * invp), p);

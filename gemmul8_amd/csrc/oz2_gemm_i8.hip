@@ -77,6 +77,8 @@ struct GemmArgs {
     size_t bstride;        // bytes between the workspaces of consecutive batch items (every pointer above lives in the workspace)
     int moduli[20];
     int pinv32[20];
+    unsigned dotw[20];     // RED_ODD: bytes (256^j mod p), j = 0..3 (byte 0 = 1)
+    unsigned dotc[20];     //          (-2^31) mod p
 };
 
 // Epilogues on a wave's 128 x 64 accumulator block (first row i0, first column j0) = 8 x 4 tiles of v_mfma_i32_16x16x64_i8, whose
@@ -92,6 +94,10 @@ struct GemmArgs {
 #define OZ2_EPI_NT 0  // 1: non-temporal residue stores (experiment: GEMM + CRT at 8192^2 x k, 14 planes: +3 % at k = 256 and 1024, +1 % at 512 and 1536,
                      // -2.5 % at 2048, -1 % at 4096 / 8192 -- the CRT pass loses what the GEMM gains; not adopted)
 #endif
+#ifndef OZ2_RED_DOT4
+#define OZ2_RED_DOT4 1  // odd moduli: residue of an accumulator by byte dot product (4 full-rate 32-bit instructions) instead of the FP64 quotient (5):
+                        // 14 planes 8192 x 8192, k = 1024 / 4096 / 8192: 1.011 -> 0.990 / 2.911 -> 2.891 / 5.356 -> 5.348 ms (profiles/r03_red_dot4_ab.txt)
+#endif
 #ifndef OZ2_CPLX_ABL
 #define OZ2_CPLX_ABL 0  // timing ablations of the complex combine epilogue (wrong results): 1 no X / Y loads, 2 no stores, 4 half the stores.
                         // ZGEMM 8192^3, 20 moduli, low-precision phase: 25.24 ms shipped, 24.38 (1), 24.47 (2), 23.89 (3) against 23.3 ms
@@ -103,7 +109,14 @@ struct GemmArgs {
                          // Measured NOT faster (ZGEMM 8192^3 x 20 moduli low-precision phase 25.85 vs 25.58 ms): the epilogue waits on its X / Y loads, not on VALU
 #endif
 #ifndef OZ2_ABL_EPI
-#define OZ2_ABL_EPI 0  // 1: no stores, 2: every plane takes the p = 256 path (timing ablations only)
+#define OZ2_ABL_EPI 0  // timing ablations only: 1 no stores, 2 every plane takes the p = 256 path, 3 all stores of a plane land in one 1 MiB window.
+                       // Epilogue of a 256 x 256 tile = 5.6 us (k = 1024: 17.5 us per tile, 11.9 without epilogue): residue arithmetic 1.8,
+                       // stores 2.6-3.0, packing / transposes 1.2.  The store cost is NOT the instructions: into an L2-resident window (3) they
+                       // cost 0.3 us.  It is the 64 KiB of fresh lines per tile on the memory side, which delays the LDS-DMA reads of the
+                       // next tile.  Measured and not kept: lane order with 64 contiguous bytes per lane quad (+3 %), complete 128-byte
+                       // lines per store instruction via v_mov_dpp row_ror:8 + ds_bpermute (+6 % at k = 1024, +0.5 % at 8192), workgroups
+                       // started up to one tile apart (k = 1024: -1 % at a quarter tile, 0 beyond; k = 8192: +1.4 ... +4 %), non-temporal
+                       // stores (round 2).  profiles/r03_epi_probe.txt, r03_epi_store_probe.txt, r03_epi_laneperm_ab.txt, r03_epi_fullline_ab.txt
 #endif
 // plane p of a (batched) launch: byte offset of its item's workspace and its plane index inside the item
 struct PlaneRef {
@@ -131,10 +144,19 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
     const int pinv = args.pinv32[t];
     const float invp = 1.0f / (float)p;
     [[maybe_unused]] const double pd = (double)p, invpd = 1.0 / (double)p;
+    [[maybe_unused]] const unsigned dotw = args.dotw[t], dotc = args.dotc[t];
     auto red = [&](int x) {
-        if constexpr (RED == RED_256) return x;
-        else if constexpr (RED == RED_ODD) return mod_i32_sym_odd_f64(x, pd, invpd);
-        else return mod_i32_sym(x, p, pinv);
+        if constexpr (RED == RED_256) return x;  // the bias 2^31 of OZ2_RED_DOT4 does not touch the low byte
+        else if constexpr (RED == RED_ODD) {
+#if OZ2_RED_DOT4
+            // the accumulators start at -2^31 (acc init in the kernel): read as unsigned the register holds u = x + 2^31 for ANY int32 sum
+            // x, and s = sum_j byte_j(u) (256^j mod p) + ((-2^31) mod p) == x (mod p), 0 <= s < 2^18: v_dot4_u32_u8.  One fp32 quotient
+            // and the 24-bit multiply-add give the canonical residue (mod_small_sym_u, oz2_device.hpp).
+            return mod_small_sym_u(__builtin_amdgcn_udot4((unsigned)x, dotw, dotc, false), p, invp);
+#else
+            return mod_i32_sym_odd_f64(x, pd, invpd);
+#endif
+        } else return mod_i32_sym((int)((unsigned)x ^ (OZ2_RED_DOT4 ? 0x80000000u : 0u)), p, pinv);
     };
     auto red_small = [&](int x) {
         if constexpr (RED == RED_256) return x;
@@ -171,7 +193,7 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
             const auto w23 = __builtin_amdgcn_permlane16_swap(s0[1], s1[1], false, false);  //         rows 8-11, rows 12-15
             const unsigned z[4] = {w01[0], w01[1], w23[0], w23[1]};
             if (col < args.n && !(OZ2_ABL_EPI == 1 && args.kp > 0)) {
-                const size_t e = e00 + tj * ejs + tg * 64;  // first of 16 consecutive rows
+                const size_t e = (e00 + tj * ejs + tg * 64) & (OZ2_ABL_EPI == 3 ? (size_t)0xFFFF0 : ~(size_t)0);  // first of 16 consecutive rows
                 if constexpr (EPI == EPI_MOD) {
 #if OZ2_EPI_NT
                     {
@@ -902,7 +924,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][j][r] = 0;
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = (EPI == EPI_MAX || !OZ2_RED_DOT4) ? 0 : (int)0x80000000u;
 #define OZ2_LOAD_SEG(seg_)                                                                                                   \
     do {                                                                                                                     \
         const int coff_ = (((((seg_) >> 1) << 2) | q) ^ sw) << 4;                                                            \
@@ -979,7 +1001,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0;
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = (EPI == EPI_MAX || !OZ2_RED_DOT4) ? 0 : (int)0x80000000u;
 
         for (int kt = 0; kt < KT; ++kt) {
             const char* curA = smem + sA * TILE_BYTES + a_base;
@@ -1050,6 +1072,8 @@ static void fill_common(GemmArgs& a, size_t kp, size_t m, size_t n) {
         const int p = GEMMUL8_MODULI_INT8[t];
         a.moduli[t] = p;
         a.pinv32[t] = (int)(4294967296ull / (unsigned long long)p);
+        a.dotw[t] = 1u | ((256u % p) << 8) | ((65536u % p) << 16) | ((16777216u % p) << 24);
+        a.dotc[t] = (unsigned)((p - (int)(2147483648u % (unsigned)p)) % p);
     }
 }
 

@@ -48,6 +48,35 @@ def test_one_step_fp64_reduction_is_exact(p):
 
 
 @pytest.mark.parametrize("p", [m for m in INT8_MODULI if m & 1])
+def test_biased_accumulator_byte_dot_reduction_is_exact(p):
+    """INT8 GEMM epilogue, odd moduli (oz2_gemm_i8.hip red() with OZ2_RED_DOT4, oz2_device.hpp mod_small_sym_u): the accumulator
+    starts at -2^31, so its register read as unsigned is u = x + 2^31 for any int32 sum x; s = sum_j byte_j(u) (256^j mod p) +
+    ((-2^31) mod p) (v_dot4_u32_u8), q from the low 24 bits of fma(float(s), RN(1/p), 2^23), r = s - q p (v_mad_i32_i24)."""
+    rng = np.random.default_rng(1000 + p)
+    lim = 2 ** 31 - 1
+    parts = [rng.integers(-lim - 1, lim + 1, size=2_000_000, dtype=np.int64),
+             np.arange(-lim - 1, -lim + 70_000, dtype=np.int64), np.arange(lim - 70_000, lim + 1, dtype=np.int64),
+             np.arange(-70_000, 70_000, dtype=np.int64)]
+    qs = np.concatenate([rng.integers(-(lim // p), lim // p, size=4000), [-(lim // p), lim // p - 1, 0, 1, -1]])
+    rs = np.arange(-(p // 2) - 1, p // 2 + 2)
+    parts.append(np.clip((qs[:, None] * p + rs[None, :]).ravel(), -lim - 1, lim))
+    x = np.concatenate(parts)
+    u = (x + 2 ** 31).astype(np.uint64)                       # the register contents
+    w = [pow(256, j, p) for j in range(4)]                    # GemmArgs.dotw bytes (fill_common)
+    c = (p - (2 ** 31) % p) % p                               # GemmArgs.dotc
+    assert all(0 <= v < 256 for v in w)
+    s = sum(((u >> np.uint64(8 * j)) & np.uint64(0xFF)).astype(np.int64) * w[j] for j in range(4)) + c
+    assert s.max() < 2 ** 18
+    invp = np.float32(1.0) / np.float32(p)
+    prod = s.astype(np.float32).astype(np.float64) * np.float64(invp)        # exact in float64 (24 x 24 bits)
+    qf = (prod + np.float64(8388608.0)).astype(np.float32)                   # the rounding of the fp32 fma (the float64 sum is off by < 2^-29, far inside the 1/(2p) margin to a tie)
+    bits = qf.view(np.uint32).astype(np.int64) & 0xFFFFFF                    # v_mad_i32_i24 reads the low 24 bits (positive here)
+    assert np.array_equal(bits, qf.astype(np.int64) - 8388608)
+    r = s - bits * p
+    assert np.array_equal(r, sym_exact(x, p))
+
+
+@pytest.mark.parametrize("p", [m for m in INT8_MODULI if m & 1])
 def test_one_step_small(p):
     a = np.arange(-65535, 65536, dtype=np.int64)
     invp = np.float32(1.0) / np.float32(p)
