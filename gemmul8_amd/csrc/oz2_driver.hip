@@ -312,7 +312,7 @@ int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t
     }
     if (!is_complex(dtype)) {
         OZ2_HIP(launch_gemm_i8_mod(stream, A_lo + (size_t)t_begin * L->sizeA, B_lo + (size_t)t_begin * L->sizeB, L->sizeA, L->sizeB, L->kp, m, n,
-                                   (int)t_begin, (int)t_end, (int8_t*)L->C_mid + (size_t)t_begin * L->sizeC, L->mp, L->sizeC));
+                                   (int)t_begin, (int)t_end, (int8_t*)L->C_mid + (size_t)t_begin * L->sizeC, L->mp, L->sizeC, true));
         return GEMMUL8_OK;
     }
     // complex (gemmul8_complex.hpp:154-206, conv_hi2mid_complex.hpp:9-127): per modulus X = ArBr, Y = AiBi,
@@ -330,9 +330,9 @@ int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t
         const unsigned t1 = std::min<unsigned>(t_end, t0 + (unsigned)chunk);
         int8_t* ry = rx + (size_t)(t1 - t0) * L->sizeC;
         OZ2_HIP(launch_gemm_i8_mod(stream, A_lo + (size_t)t0 * L->sizeA, B_lo + (size_t)t0 * L->sizeB, L->sizeA, L->sizeB, L->kp, m, n,
-                                   (int)t0, (int)t1, rx, L->mp, L->sizeC));
+                                   (int)t0, (int)t1, rx, L->mp, L->sizeC, false));  // X, Y: re-read by the Z launch right away
         OZ2_HIP(launch_gemm_i8_mod(stream, A_lo + L->part_strideA + (size_t)t0 * L->sizeA, B_lo + L->part_strideB + (size_t)t0 * L->sizeB,
-                                   L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1, ry, L->mp, L->sizeC));
+                                   L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1, ry, L->mp, L->sizeC, false));
         OZ2_HIP(launch_gemm_i8_cplx(stream, A_lo + 2 * L->part_strideA + (size_t)t0 * L->sizeA,
                                     B_lo + 2 * L->part_strideB + (size_t)t0 * L->sizeB, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1, rx,
                                     ry, L->sizeC, (int8_t*)L->C_mid + (size_t)t0 * 2 * L->sizeC, L->mp, 2 * L->sizeC));

@@ -77,6 +77,7 @@ struct GemmArgs {
     size_t bstride;        // bytes between the workspaces of consecutive batch items (every pointer above lives in the workspace)
     int moduli[20];
     int pinv32[20];
+    int nt_planes;         // EPI_MOD: planes tt < nt_planes (of each batch item) leave with non-temporal stores (launch_gemm_i8_mod decides)
     unsigned dotw[20];     // RED_ODD: bytes (256^j mod p), j = 0..3 (byte 0 = 1)
     unsigned dotc[20];     //          (-2^31) mod p
 };
@@ -91,8 +92,14 @@ struct GemmArgs {
                         // first tile only, bit 3 no epilogue, bit 4 operands from the first 8 K-steps only (L2 hits); 0 in every shipped build
 #endif
 #ifndef OZ2_EPI_NT
-#define OZ2_EPI_NT 0  // 1: non-temporal residue stores (experiment: GEMM + CRT at 8192^2 x k, 14 planes: +3 % at k = 256 and 1024, +1 % at 512 and 1536,
-                     // -2.5 % at 2048, -1 % at 4096 / 8192 -- the CRT pass loses what the GEMM gains; not adopted)
+#define OZ2_EPI_NT 0  // compile-time residue-store policy for A/B builds: 1 non-temporal always, 2 sc0, 3 sc1, 4 sc0 sc1 (sc bits: 2-6 % slower
+                     // everywhere, profiles/r03_epi_store_policy.txt).  The shipped build chooses non-temporal stores per launch and plane: args.nt_planes
+#endif
+#ifndef OZ2_NT_KEEP_MIB
+#define OZ2_NT_KEEP_MIB 0  // the LAST planes of a launch, up to this many MiB of residues, keep the default store policy (the CRT pass finds them in the Infinity Cache)
+#endif
+#ifndef OZ2_NT_LARGE
+#define OZ2_NT_LARGE 0     // 1: non-temporal residue stores also when the operand planes do not fit the Infinity Cache
 #endif
 #ifndef OZ2_RED_DOT4
 #define OZ2_RED_DOT4 1  // odd moduli: residue of an accumulator by byte dot product (4 full-rate 32-bit instructions) instead of the FP64 quotient (5):
@@ -195,13 +202,27 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
             if (col < args.n && !(OZ2_ABL_EPI == 1 && args.kp > 0)) {
                 const size_t e = (e00 + tj * ejs + tg * 64) & (OZ2_ABL_EPI == 3 ? (size_t)0xFFFF0 : ~(size_t)0);  // first of 16 consecutive rows
                 if constexpr (EPI == EPI_MOD) {
-#if OZ2_EPI_NT
+#if OZ2_EPI_NT == 1
                     {
                         typedef unsigned v4u __attribute__((ext_vector_type(4)));
                         __builtin_nontemporal_store(v4u{z[0], z[1], z[2], z[3]}, (v4u*)(args.out + po + e));
                     }
+#elif OZ2_EPI_NT >= 2  // cache-policy bits of the residue stores: 2 = sc0, 3 = sc1, 4 = sc0 sc1
+                    {
+                        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                        const v4u zv = {z[0], z[1], z[2], z[3]};
+                        const int8_t* ptr = args.out + po + e;
+                        if (OZ2_EPI_NT == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(ptr), "v"(zv) : "memory");
+                        else if (OZ2_EPI_NT == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(zv) : "memory");
+                        else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(zv) : "memory");
+                    }
 #else
-                    *(uint4*)(args.out + po + e) = make_uint4(z[0], z[1], z[2], z[3]);
+                    if (pl.tt < args.nt_planes) {  // wave-uniform
+                        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(v4u{z[0], z[1], z[2], z[3]}, (v4u*)(args.out + po + e));
+                    } else {
+                        *(uint4*)(args.out + po + e) = make_uint4(z[0], z[1], z[2], z[3]);
+                    }
 #endif
                 } else {
                     // eight rows at a time: 8 bytes of X and Y in, 16 bytes of (Cr, Ci) pairs out -- with all 16 rows in flight the epilogue
@@ -1129,8 +1150,29 @@ template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int
     return launch_sched<EPI, false>(stream, a);
 }
 
+// Non-temporal residue stores.  The residue planes are written once and read once, by the CRT pass, N planes later; written with the
+// default policy they are allocated in the 256 MiB Infinity Cache on their way to HBM and push out the operand planes A_lo / B_lo,
+// which the quantise kernels have just left there and which every plane's 32 x 32 tiles re-read through eight L2s.  When ALL operand
+// planes of the launch fit the Infinity Cache, keeping them there is worth 8-14 % of the WHOLE call (8192^2: k = 256 / 512 / 1024
+// 0.917 -> 0.815 / 1.059 -> 0.940 / 1.470 -> 1.285 ms; 16384^2: k = 256 / 512 3.22 -> 2.88 / 3.88 -> 3.59 ms); when they do not fit
+// there is nothing to protect and the CRT pass loses the tail of C_mid it would have found in the cache (-0.5 ... -2 % from k = 1536
+// at 8192^2, k = 1024 at 16384^2); with small outputs (4096^2 and below) it is a wash.  profiles/r03_epi_nt_grid.txt
+static int nt_residue_planes(const GemmArgs& a, int planes, bool stream_out) {
+    const char* e = getenv("GEMMUL8_EPI_NT");  // testing switch, read per launch: 0 / 1 forces the policy for all planes (results are identical)
+    if (e && (e[0] == '0' || e[0] == '1') && !e[1]) return e[0] == '1' ? planes : 0;
+    if (!stream_out) return 0;
+    const size_t all = (size_t)planes * g_batch.batch;
+    const size_t operands = all * (a.strideA + a.strideB), residues = all * a.strideO;
+    if (residues < ((size_t)256 << 20)) return 0;
+    int keep = OZ2_NT_KEEP_MIB < 0 ? 0 : (int)(((size_t)OZ2_NT_KEEP_MIB << 20) / (a.strideO * g_batch.batch));
+    if (const char* k = getenv("GEMMUL8_EPI_NT_KEEP")) keep = atoi(k);  // experiment switch
+    keep = keep < 0 ? 0 : keep > planes ? planes : keep;
+    if (operands <= ((size_t)240 << 20)) return planes - keep;
+    return OZ2_NT_LARGE ? planes - keep : 0;
+}
+
 hipError_t launch_gemm_i8_mod(hipStream_t stream, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp, size_t m,
-                              size_t n, int t_begin, int t_end, int8_t* out, size_t ldo, size_t strideO) {
+                              size_t n, int t_begin, int t_end, int8_t* out, size_t ldo, size_t strideO, bool stream_out) {
     GemmArgs a{};
     a.A[0] = A;
     a.B[0] = B;
@@ -1142,6 +1184,7 @@ hipError_t launch_gemm_i8_mod(hipStream_t stream, const int8_t* A, const int8_t*
     a.ldo = ldo;
     a.strideO = strideO;
     fill_common(a, kp, m, n);
+    a.nt_planes = nt_residue_planes(a, t_end - t_begin, stream_out);
     return launch<EPI_MOD>(stream, a, t_end - t_begin);
 }
 

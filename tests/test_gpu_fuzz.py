@@ -39,12 +39,15 @@ def test_random_case_bit_exact(seed, monkeypatch):
     # m = 1024 real, 512 complex) and the bound GEMM's 128 / 256 tiles, drawn per seed; "" = the library's own choice
     crt_force = str(rng.choice(["", "dma", "reg"]))
     tile_force = str(rng.choice(["", "128", "256"]))
+    nt_force = str(rng.choice(["", "0", "1"]))       # residue-store policy of the INT8 GEMM (oz2_gemm_i8.hip nt_residue_stores)
     if crt_force == "dma" and backend == g.INT8:
         m, n = (512 if np.dtype(dtype).kind == "c" else 1024), min(n, 64)
     if crt_force:
         monkeypatch.setenv("GEMMUL8_CRT_KERNEL", crt_force)
     if tile_force:
         monkeypatch.setenv("GEMMUL8_BOUND_TILE", tile_force)
+    if nt_force:
+        monkeypatch.setenv("GEMMUL8_EPI_NT", nt_force)
     cplx = np.dtype(dtype).kind == "c"
     opA = str(rng.choice(["N", "T", "C"] if cplx else ["N", "T"]))
     opB = str(rng.choice(["N", "T", "C"] if cplx else ["N", "T"]))

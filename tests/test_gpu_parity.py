@@ -362,6 +362,40 @@ def test_crt_kernels_both_forms(dtype, m, kernel, monkeypatch):
     gu.parity_case(A, B, N, False, C0=C0)
 
 
+@pytest.mark.parametrize("policy", ["0", "1"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, np.complex128])
+def test_residue_store_policy_both(dtype, policy, monkeypatch):
+    """The INT8 GEMM writes its residue planes with non-temporal stores when the operand planes of the launch fit the Infinity Cache
+    and the output is large (oz2_gemm_i8.hip nt_residue_stores); GEMMUL8_EPI_NT forces either policy.  Same bits either way."""
+    import gpu_util as gu
+    monkeypatch.setenv("GEMMUL8_EPI_NT", policy)
+    rng = np.random.default_rng(77)
+    m, n, k = 300, 290, 200
+    A = rand((m, k), dtype, rng, phi=1.0)
+    B = rand((k, n), dtype, rng, phi=1.0)
+    gu.parity_case(A, B, 12 if dtype != np.float32 else 7, False)
+    gu.parity_case(A, B, 12 if dtype != np.float32 else 7, True, alpha=-1.0, beta=1.0, C0=rand((m, n), dtype, rng, phi=0.0))
+
+
+def test_residue_store_policy_auto_at_size(monkeypatch):
+    """8192 x 8192 x 512, 14 moduli: 112 MiB of operand planes and 896 MiB of residues -- the shape class where the library picks
+    non-temporal residue stores by itself.  The result must equal the forced default-policy run bit for bit."""
+    import torch
+    import gemmul8_amd as g
+    torch.manual_seed(3)
+    n, k = 8192, 512
+    A = torch.randn((k, n), dtype=torch.float64, device="cuda")
+    B = torch.randn((n, k), dtype=torch.float64, device="cuda")
+    monkeypatch.delenv("GEMMUL8_EPI_NT", raising=False)
+    C_auto, _, work = g.gemm(A, B, 14)
+    monkeypatch.setenv("GEMMUL8_EPI_NT", "0")
+    C_plain, _, _ = g.gemm(A, B, 14, work=work)
+    torch.cuda.synchronize()
+    assert torch.equal(C_auto, C_plain)
+    ref = (B.double() @ A.double())  # tensors are transposed views of the column-major matrices: C^T = B^T-view @ A^T-view
+    assert float((C_auto - ref).abs().max() / ref.abs().max()) < 1e-13
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.complex128])
 def test_bounds_fp8_exact_when_fp32_sums_are_exact(dtype):
     """Operands of one binade: every e4m3 bound value is a multiple of 8 in [64, 256], so the FP32 accumulation of the
