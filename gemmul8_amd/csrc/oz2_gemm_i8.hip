@@ -95,12 +95,6 @@ struct GemmArgs {
 #define OZ2_EPI_NT 0  // compile-time residue-store policy for A/B builds: 1 non-temporal always, 2 sc0, 3 sc1, 4 sc0 sc1 (sc bits: 2-6 % slower
                      // everywhere, profiles/r03_epi_store_policy.txt).  The shipped build chooses non-temporal stores per launch and plane: args.nt_planes
 #endif
-#ifndef OZ2_NT_KEEP_MIB
-#define OZ2_NT_KEEP_MIB 0  // the LAST planes of a launch, up to this many MiB of residues, keep the default store policy (the CRT pass finds them in the Infinity Cache)
-#endif
-#ifndef OZ2_NT_LARGE
-#define OZ2_NT_LARGE 0     // 1: non-temporal residue stores also when the operand planes do not fit the Infinity Cache
-#endif
 #ifndef OZ2_RED_DOT4
 #define OZ2_RED_DOT4 1  // odd moduli: residue of an accumulator by byte dot product (4 full-rate 32-bit instructions) instead of the FP64 quotient (5):
                         // 14 planes 8192 x 8192, k = 1024 / 4096 / 8192: 1.011 -> 0.990 / 2.911 -> 2.891 / 5.356 -> 5.348 ms (profiles/r03_red_dot4_ab.txt)
@@ -1163,12 +1157,9 @@ static int nt_residue_planes(const GemmArgs& a, int planes, bool stream_out) {
     if (!stream_out) return 0;
     const size_t all = (size_t)planes * g_batch.batch;
     const size_t operands = all * (a.strideA + a.strideB), residues = all * a.strideO;
-    if (residues < ((size_t)256 << 20)) return 0;
-    int keep = OZ2_NT_KEEP_MIB < 0 ? 0 : (int)(((size_t)OZ2_NT_KEEP_MIB << 20) / (a.strideO * g_batch.batch));
-    if (const char* k = getenv("GEMMUL8_EPI_NT_KEEP")) keep = atoi(k);  // experiment switch
-    keep = keep < 0 ? 0 : keep > planes ? planes : keep;
-    if (operands <= ((size_t)240 << 20)) return planes - keep;
-    return OZ2_NT_LARGE ? planes - keep : 0;
+    // (keeping the default policy for the last 2-6 planes, so that the CRT finds them in the cache, and non-temporal stores for the
+    // leading planes of launches whose operands do NOT fit were both measured: no gain, profiles/r03_epi_nt_keep.txt)
+    return residues >= ((size_t)256 << 20) && operands <= ((size_t)240 << 20) ? planes : 0;
 }
 
 hipError_t launch_gemm_i8_mod(hipStream_t stream, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp, size_t m,
