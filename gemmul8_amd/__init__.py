@@ -33,7 +33,8 @@ class Layout(C.Structure):
 _lib = None
 
 EXPORTS = ["gemmul8_version", "gemmul8_work_size", "gemmul8_gemm", "gemmul8_get_layout", "gemmul8_scale",
-           "gemmul8_scale_bounds", "gemmul8_scale_finish", "gemmul8_lowprec_gemm", "gemmul8_crt", "gemmul8_set_fp8_bound_mode"]
+           "gemmul8_scale_bounds", "gemmul8_scale_finish", "gemmul8_lowprec_gemm", "gemmul8_crt", "gemmul8_set_fp8_bound_mode",
+           "gemmul8_hook_would_emulate"]
 
 
 def _bind_hip_runtime():
@@ -110,6 +111,8 @@ def lib():
                                        C.c_void_p, C.c_size_t, C.c_longlong, C.c_size_t, C.c_uint, C.c_int, C.c_void_p]
     L.gemmul8_set_fp8_bound_mode.restype = C.c_int
     L.gemmul8_set_fp8_bound_mode.argtypes = [C.c_int]
+    L.gemmul8_hook_would_emulate.restype = C.c_int
+    L.gemmul8_hook_would_emulate.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.c_int, C.c_size_t]
     L.gemmul8_add_row_bias.restype = C.c_int
     L.gemmul8_add_row_bias.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     _lib = L

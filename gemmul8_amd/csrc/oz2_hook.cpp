@@ -14,7 +14,7 @@
 //   early outs: m|n|k <= 0 -> SUCCESS, null A/B/C -> INVALID_VALUE            hook.cu:616-617
 //   GEMMUL8_DIST (this build only)  blocks | moduli | fp64sum: shard every emulated GEMM over the ranks of an SPMD job (see try_dist)
 //   GEMMUL8_MIN_FLOPS (this build only) calls with 2*m*n*k below it use the native routine; 0 = emulate every call (the reference's
-//                     behaviour); UNSET = automatic floor from the measured crossover sizes (below_floor)
+//                     behaviour); UNSET = automatic: a fitted cost model decides per call whether the emulation wins (below_floor)
 //   per-handle state under a mutex: three grow-only stream-ordered buffers (hipMallocAsync /
 //   hipFreeAsync), event hand-off when the handle's stream changes, skip-scaling cache
 //   (hook.cu:70-162,331-374,684-727); hipblasDestroy frees the state first (hook.cu:846-856).
@@ -401,25 +401,55 @@ bool try_dist(int kind, int dtype, int backend, hipblasOperation_t ta, hipblasOp
     return true;
 }
 
-// GEMMUL8_MIN_FLOPS (not in the reference).  Below ~2048^3 one emulated GEMM is ten latency-bound launches and the native routine is
-// faster (profiles/sweeps/r03_flops_dgemm_int8.csv: 1024^3 17 vs 48 TFLOPS, 2048^2 x 1024 44 vs 66; from 1024^2 x 8192 and 2048^2 x 4096
-// on the emulation wins).  A drop-in must not make an application slower by default, so with the variable UNSET calls below the
-// measured crossover go to the native routine: emulated time ~ 90 us + W / 160 TFLOPS against W / 70 TFLOPS native for D / Z
-// (W = real flops) gives W > 1.1e10; S / C (native 154, emulated ~250 TFLOPS): 3.6e10.  A strided batch runs as ONE set of launches
-// (no per-item launch cost) and is judged on its total work with a 4x higher bar (16 x 1024^3: 45 vs 49 native; 8 x 2048^3: 80 vs 65).
-// GEMMUL8_MIN_FLOPS=0 restores the reference's behaviour (emulate every call); any other value is a floor on 2*m*n*k per call.
-bool below_floor(int dtype, double m, double n, double k, double batch = 1.0) {
+// GEMMUL8_MIN_FLOPS (not in the reference).  A drop-in must not make an application slower by default: small products are ten
+// latency-bound launches (1024^3: 21 vs 48 TFLOPS native), and what a hooked solver issues most -- trailing updates with large m = n
+// and small k, panel products with one small dimension -- pays the per-output cost of the scheme (N bytes of residues written, read
+// and recombined per element) without the k to amortise it (DGEMM 8192^2 x 256: 45 vs 65 TFLOPS native; x 512: 71 vs 69; x 1024:
+// 107 vs 70).  With the variable UNSET the hook therefore evaluates a fitted cost model per call and emulates only where the
+// emulation is predicted to win:
+//     emulated  t_e = c0 + (a1 + b1 N)(m + n) k + (a2 + b2 N) m n + b3 N m n k      per (type, accurate / fast), N = number of moduli
+//     native    t_n = d0 + d2 m n + d3 m n k                                        per type (the library at its normal rate)
+//     emulate   iff t_e <= 0.95 t_n        (a strided batch: one set of launches, so c0 / d0 once and the rest times the batch)
+// Constants: tools/fit_floor.py on profiles/sweeps/r03_floor_scan_{s,d,c,z}.csv (tools/floor_scan.py: 60-68 shapes x 3 N x 2 modes
+// per type against the native routine on the same box; median model error 5-7 %).  On the scanned shapes the rule emulates 31-53 of
+// 180-204 cases per type and mode, lets 0-2 marginal losses through (worst 1.05x the native time, one 1.19x), and the summed time is
+// within 0.3-10 % of always picking the faster of the two (always-native: +25-45 %).  The FP8 backend costs ~2.2x the INT8 one.
+// GEMMUL8_MIN_FLOPS=0 restores the reference's behaviour (emulate every call); any other value is a plain floor on 2*m*n*k per call.
+struct FloorModel {
+    double e[6];  // ms: 1, (m+n)k, N(m+n)k, mn, N mn, N mnk
+    double n[3];  // ms: 1, mn, mnk
+};
+// generated by tools/fit_floor.py
+static const FloorModel kFloor[4][2] = {  // [S, D, C, Z][accurate, fast]
+    {{{0.0645, 2.285e-09, 4.147e-10, 1.694e-09, 4.08e-10, 5.589e-13}, {0.02053, 4.996e-10, 1.333e-11}}, {{0.04985, 1.623e-09, 4.27e-10, 9.139e-10, 4.164e-10, 5.381e-13}, {0.02053, 4.996e-10, 1.333e-11}}},
+    {{{0.0594, 3.454e-09, 4.262e-10, 1.137e-09, 5.264e-10, 5.443e-13}, {0.01041, 5.723e-10, 2.757e-11}}, {{0.04537, 2.218e-09, 4.341e-10, 4.592e-10, 5.204e-10, 5.395e-13}, {0.01041, 5.723e-10, 2.757e-11}}},
+    {{{0.09541, 7.142e-09, 1.221e-09, 2.907e-09, 2.514e-09, 1.793e-12}, {0.01247, 3.124e-10, 5.502e-11}}, {{0.06607, 3.724e-09, 1.237e-09, 1.175e-09, 2.57e-09, 1.612e-12}, {0.01247, 3.124e-10, 5.502e-11}}},
+    {{{0.1111, 1.222e-08, 1.376e-09, 7.487e-10, 2.956e-09, 1.689e-12}, {0.00809, 2.584e-10, 1.076e-10}}, {{0.07812, 7.692e-09, 1.346e-09, 4.235e-11, 3.05e-09, 1.503e-12}, {0.00809, 2.584e-10, 1.076e-10}}},
+};
+bool below_floor(int dtype, double m, double n, double k, unsigned N, bool fast, int backend, double batch = 1.0) {
     const char* s = std::getenv("GEMMUL8_MIN_FLOPS");
-    const double w = 2.0 * m * n * k;
     if (s && *s) {
         const unsigned long long f = env_u64("GEMMUL8_MIN_FLOPS", 0);
-        return f && w < (double)f;
+        return f && 2.0 * m * n * k < (double)f;
     }
-    static const double kAuto[4] = {3.6e10, 1.1e10, 3.6e10, 1.1e10};  // S, D, C, Z in real flops
-    const double real = w * (kTypes[dtype].cplx ? 4.0 : 1.0) * batch;
-    return real < kAuto[dtype] * (batch > 1.0 ? 4.0 : 1.0);
+    const FloorModel& fm = kFloor[dtype][fast ? 1 : 0];
+    const double mk = (m + n) * k, mn = m * n, mnk = mn * k, Nd = (double)N;
+    double te = fm.e[0] + batch * ((fm.e[1] + fm.e[2] * Nd) * mk + (fm.e[3] + fm.e[4] * Nd) * mn + fm.e[5] * Nd * mnk);
+    if (backend == GEMMUL8_FP8) te *= 2.2;
+    const double tn = fm.n[0] + batch * (fm.n[1] * mn + fm.n[2] * mnk);
+    return te > 0.95 * tn;
 }
 
+}  // namespace
+extern "C" GEMMUL8_API int gemmul8_hook_would_emulate(int dtype, int backend, size_t m, size_t n, size_t k, unsigned num_moduli, int fastmode,
+                                                      size_t batch) {
+    if (dtype < 0 || dtype > 3 || (backend != GEMMUL8_INT8 && backend != GEMMUL8_FP8) || batch == 0 || num_moduli < 2 ||
+        num_moduli > kTypes[dtype].max_moduli)
+        return GEMMUL8_E_ARG;
+    if (m == 0 || n == 0 || k == 0) return 0;
+    return below_floor(dtype, (double)m, (double)n, (double)k, num_moduli, fastmode != 0, backend, (double)batch) ? 0 : 1;
+}
+namespace {
 // explicit_stream: hipblasLtMatmul carries its stream as an argument (a hipblasLt handle has none)
 bool try_emulate(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, hipblasOperation_t tb, int m, int n, int k, const void* alpha,
                  const void* A, int lda, const void* B, int ldb, const void* beta, void* C, int ldc, hipblasStatus_t* status,
@@ -427,10 +457,10 @@ bool try_emulate(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, hipbl
     const TypeInfo& ti = kTypes[dtype];
     const unsigned N = (unsigned)env_u64(ti.nmod, 0);
     if (N < 2u || N > ti.max_moduli) return false;
-    if (below_floor(dtype, m, n, k)) return false;
     const bool fastmode = env_one(ti.fast);
     const bool enA = env_one("GEMMUL8_SKIP_SCALE_A"), enB = env_one("GEMMUL8_SKIP_SCALE_B");
     const int backend = env_backend("GEMMUL8_BACKEND", 0, false);
+    if (below_floor(dtype, m, n, k, N, fastmode, backend)) return false;
     if (backend == GEMMUL8_FP8) {
         // the FP8 backend exists for parity with the reference; on this chip it is dominated: three FP8 GEMMs per modulus at about the
         // INT8 MFMA rate against one INT8 GEMM (profiles/sweeps/*_types_backends.csv: SGEMM 8192^3 126 vs 276 TFLOPS, native 153;
@@ -702,8 +732,8 @@ static bool emulate_batch(int dtype, size_t elem, hipblasHandle_t handle, hipbla
         const TypeInfo& ti = kTypes[dtype];
         const unsigned N = (unsigned)env_u64(ti.nmod, 0);
         if (N < 2u || N > ti.max_moduli) return false;
-        if (below_floor(dtype, m, n, k, (double)batch)) return false;
         const int backend = env_backend("GEMMUL8_BACKEND", 0, false);
+        if (below_floor(dtype, m, n, k, N, env_one(ti.fast), backend, (double)batch)) return false;
         if (k <= (backend == GEMMUL8_FP8 ? 65536 : (1 << 17))) {
             const bool fastmode = env_one(ti.fast);
             auto sp = state_of(handle);
@@ -944,7 +974,7 @@ bool lt_try(hipblasLtHandle_t handle, hipblasLtMatmulDesc_t desc, const void* al
     // cheap env test before touching D: is emulation selected for this type at all?
     const unsigned N = (unsigned)env_u64(kTypes[dtype].nmod, 0);
     if (N < 2u || N > kTypes[dtype].max_moduli) return false;
-    if (below_floor(dtype, (double)m, (double)n, (double)k, (double)nb)) return false;
+    if (below_floor(dtype, (double)m, (double)n, (double)k, N, env_one(kTypes[dtype].fast), env_backend("GEMMUL8_BACKEND", 0, false), (double)nb)) return false;
     if (k > (1u << 17) || (env_backend("GEMMUL8_BACKEND", 0, false) == 1 && k > 65536)) return false;  // outside the emulator's range
     // C is not read when the host scalar beta is 0 (the CRT's "C = +-AB" forms and its general form with beta == 0, oz2_crt.hip): then
     // the out-of-place form needs no copy of C into D.  Device scalars: beta is unknown here, C is copied (the kernel still skips

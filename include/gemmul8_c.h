@@ -162,6 +162,14 @@ GEMMUL8_API int gemmul8_crt_finish(void *stream, int dtype, int backend, unsigne
  * Process-wide; returns the previous mode (>= 0) or GEMMUL8_E_ARG.  The hook sets mode 1 when GEMMUL8_FP8_BOUND=reference. */
 GEMMUL8_API int gemmul8_set_fp8_bound_mode(int mode);
 
+/* The hook's automatic floor (GEMMUL8_MIN_FLOPS unset; oz2_hook.cpp below_floor): 1 if a hooked GEMM of this shape is emulated,
+ * 0 if the hook hands it to the native routine because the fitted cost model (tools/fit_floor.py, profiles/sweeps/r03_floor_scan_*.csv)
+ * predicts the emulation to lose; GEMMUL8_E_ARG on bad arguments.  With GEMMUL8_MIN_FLOPS set, that floor is applied instead
+ * (0 = emulate everything, the reference's behaviour).  batch = items of a strided batch (1 for a plain call).  No counterpart in
+ * the reference, whose hook emulates every call. */
+GEMMUL8_API int gemmul8_hook_would_emulate(int dtype, int backend, size_t m, size_t n, size_t k, unsigned num_moduli, int fastmode,
+                                           size_t batch);
+
 /* Library identification (build arch, version) */
 GEMMUL8_API const char *gemmul8_version(void);
 

@@ -54,6 +54,9 @@ static void one_thread(int id) {
         CHECK(hipblasDgemmStridedBatched(h, HIPBLAS_OP_N, HIPBLAS_OP_N, 50, 40, 30, &one, A.data(), 50, 1500, B.data(), 30, 1200, &zero, C.data(), 50, 2000, 7) ==
               HIPBLAS_STATUS_SUCCESS);
         CHECK(mock_emulated_calls() >= emu_a + 7);
+        // the environment is process state and setenv is not thread-safe against getenv: only the first, sequential pass (id 0)
+        // switches the batch paths; the concurrent passes run the default one
+        if (id != 0) goto batch_done;
         setenv("GEMMUL8_BATCH_WORKSPACE_MB", "1", 1);  // smaller than one item: chunks of a single item, the buffer is re-grown
         const long emu_c = mock_emulated_calls();
         CHECK(hipblasDgemmStridedBatched(h, HIPBLAS_OP_N, HIPBLAS_OP_N, 50, 40, 30, &one, A.data(), 50, 1500, B.data(), 30, 1200, &zero, C.data(), 50, 2000, 5) ==
@@ -71,6 +74,7 @@ static void one_thread(int id) {
         unsetenv("GEMMUL8_BATCH_STREAMS");
         unsetenv("GEMMUL8_BATCH_FUSED");
     }
+batch_done:
     // outside the emulator's range (k > 2^17): native, not an error
     std::vector<double> Ak((size_t)4 * ((1 << 17) + 8)), Bk((size_t)((1 << 17) + 8) * 3);
     const long nat0 = mock_native_calls();

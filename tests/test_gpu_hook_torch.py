@@ -58,8 +58,9 @@ def test_torch_float32_matmul_is_emulated_under_ld_preload():
 
 
 def test_default_floor_keeps_small_calls_native():
-    """GEMMUL8_MIN_FLOPS unset: calls below the measured crossover (DGEMM: 2mnk < 1.1e10) go to the native routine, so the drop-in never
-    slows a small GEMM down; the demo's matrices are far below it -> results identical to the un-hooked run."""
+    """GEMMUL8_MIN_FLOPS unset: calls the fitted cost model predicts to lose (oz2_hook.cpp below_floor; tests/test_hook_floor.py) go to the
+    native routine, so the drop-in never slows a small GEMM down; the demo's matrices are far below any crossover -> results identical
+    to the un-hooked run."""
     native, native_b = _run({})
     env = {"LD_PRELOAD": SHIM, "GEMMUL8_NUM_MOD_D": "18", "GEMMUL8_NUM_MOD_S": "13"}
     keep = os.environ.pop("GEMMUL8_MIN_FLOPS", None)

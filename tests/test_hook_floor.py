@@ -1,0 +1,91 @@
+"""The hook's automatic floor (oz2_hook.cpp below_floor, exported as gemmul8_hook_would_emulate): with GEMMUL8_MIN_FLOPS unset a
+hooked call is emulated only where the fitted cost model predicts a win over the native routine.  Checked here, without a GPU,
+against the measurements the model was fitted to (profiles/sweeps/r03_floor_scan_*.csv, tools/floor_scan.py on one MI355X)."""
+import csv
+import os
+
+import pytest
+
+import gemmul8_amd as g
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CODE = {"s": 0, "d": 1, "c": 2, "z": 3}
+
+
+def would(dtype, m, n, k, N, fast=0, backend=None, batch=1):
+    return g.lib().gemmul8_hook_would_emulate(CODE[dtype], g.INT8 if backend is None else backend, m, n, k, N, fast, batch)
+
+
+@pytest.fixture(autouse=True)
+def _floor_unset(monkeypatch):
+    monkeypatch.delenv("GEMMUL8_MIN_FLOPS", raising=False)
+
+
+def test_known_crossovers():
+    # DGEMM, 14 moduli, accurate: the trailing update wins from k ~ 600 at 8192^2 (45 / 71 / 107 TFLOPS at k = 256 / 512 / 1024 vs 65-70 native)
+    assert would("d", 8192, 8192, 256, 14) == 0
+    assert would("d", 8192, 8192, 1024, 14) == 1
+    assert would("d", 8192, 8192, 8192, 14) == 1
+    assert would("d", 1024, 1024, 1024, 14) == 0          # ten latency-bound launches: 21 vs 48 TFLOPS native
+    assert would("d", 16384, 256, 1024, 14) == 0          # panel product: the per-output cost is not amortised
+    assert would("d", 64, 64, 64, 14) == 0
+    assert would("s", 8192, 8192, 8192, 7) == 1
+    assert would("s", 2048, 2048, 1024, 7) == 0
+    assert would("z", 8192, 8192, 2048, 14) == 1
+    assert would("c", 2048, 2048, 256, 7) == 0
+    # more moduli cost more: a shape that wins with 10 may lose with 18
+    assert would("d", 8192, 8192, 512, 10, fast=1) >= would("d", 8192, 8192, 512, 18, fast=1)
+    # the FP8 backend costs ~2.2x: DGEMM never wins with it on this chip below very large k
+    assert would("d", 8192, 8192, 1024, 14, backend=g.FP8) == 0
+
+
+def test_monotone_in_k_for_large_squares():
+    for dt, N in (("d", 14), ("s", 7), ("z", 14), ("c", 7)):
+        for mn in (4096, 8192, 16384):
+            seen = [would(dt, mn, mn, k, N) for k in (64, 128, 256, 512, 1024, 2048, 4096, 8192)]
+            assert seen == sorted(seen), (dt, mn, seen)
+            assert seen[0] == 0 and seen[-1] == 1, (dt, mn, seen)
+
+
+def test_batch_counts_as_one_launch_set():
+    assert would("d", 1024, 1024, 1024, 14, batch=1) == 0
+    assert would("d", 2048, 2048, 2048, 14, batch=8) == 1   # measured 80 vs 65 TFLOPS native
+    assert would("d", 64, 64, 64, 14, batch=4) == 0
+
+
+def test_explicit_floor_overrides(monkeypatch):
+    monkeypatch.setenv("GEMMUL8_MIN_FLOPS", "0")
+    assert would("d", 64, 64, 64, 14) == 1                   # the reference's behaviour: emulate every call
+    monkeypatch.setenv("GEMMUL8_MIN_FLOPS", "1000000000000")
+    assert would("d", 4096, 4096, 4096, 14) == 0
+    assert would("d", 8192, 8192, 8192, 14) == 1
+
+
+def test_bad_arguments():
+    L = g.lib()
+    assert L.gemmul8_hook_would_emulate(7, g.INT8, 10, 10, 10, 14, 0, 1) < 0
+    assert L.gemmul8_hook_would_emulate(1, g.INT8, 10, 10, 10, 30, 0, 1) < 0
+    assert L.gemmul8_hook_would_emulate(1, g.INT8, 10, 10, 10, 14, 0, 0) < 0
+
+
+@pytest.mark.parametrize("dt", ["d", "s", "z", "c"])
+def test_rule_against_the_measurements(dt):
+    """On every measured shape the rule emulates, the emulation must not have lost by more than a few per cent (one known outlier:
+    SGEMM 1024^2 x 16384 with 5 moduli, 1.19x); and the rule must keep most of the time the better choice would have saved."""
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "sweeps", f"r03_floor_scan_{dt}.csv"))))
+    assert len(rows) >= 150
+    t_rule = t_best = t_native = 0.0
+    worst = 0.0
+    for r in rows:
+        m, n, k, N, fast = int(r["m"]), int(r["n"]), int(r["k"]), int(r["N"]), int(r["fast"])
+        te, tn = float(r["emulated_ms"]), float(r["native_ms"])
+        em = would(dt, m, n, k, N, fast)
+        assert em in (0, 1)
+        t_rule += te if em else tn
+        t_best += min(te, tn)
+        t_native += tn
+        if em:
+            worst = max(worst, te / tn)
+    assert worst <= 1.20, worst
+    assert t_rule <= 1.12 * t_best, (t_rule, t_best)
+    assert t_rule <= 0.90 * t_native, (t_rule, t_native)
