@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace oz2 {
 
@@ -24,9 +25,29 @@ struct TileMap {
 #ifndef OZ2_MAP_CHUNKED
 #define OZ2_MAP_CHUNKED 1
 #endif
+#ifndef OZ2_MAP_COLBLOCK
+#define OZ2_MAP_COLBLOCK 1  // 0: always walk the full width of a plane
+#endif
+// Tile-columns per column block for operand panels of kbytes bytes per row (0 = full width).  Walking the full width, every group of
+// 8 tile-rows touches ALL B panels of the plane; they stay in the 256 MiB Infinity Cache between row groups as long as they are not
+// much more than half of it (n = 16384, k = 8192: 128 MiB -- blocking costs 3 % there, A is re-streamed once per block).  Beyond
+// that (16384^2 x 16384: 256 MiB of B per plane) every row group re-read B from HBM: blocks of ~128 MiB of B panels recover it
+// (6 planes 16384^2 x 16384: 19.19 -> 18.32 ms, 12288^2 x 16384: 10.47 -> 10.24; profiles/r03_map_colblock_ab.txt).
+inline int map_colblock(size_t tiles_n, size_t kbytes) {
+    if (!OZ2_MAP_COLBLOCK) return 0;
+    if (const char* e = getenv("GEMMUL8_MAP_COLBLOCK")) {  // experiment / testing switch: tile-columns per block, 0 = full width
+        const int w = atoi(e);
+        return w > 0 && (size_t)w < tiles_n ? w : 0;
+    }
+    const size_t panel = (size_t)BN * kbytes;
+    if (tiles_n * panel <= ((size_t)160 << 20)) return 0;
+    size_t w = (((size_t)128 << 20) / panel) & ~(size_t)3;
+    if (w < 8) w = 8;
+    return w >= tiles_n ? 0 : (int)w;
+}
 // bid: (virtual) workgroup id -- blockIdx.x + round * gridDim.x in the persistent kernels, gridDim.x a multiple of 8
 // whenever there is more than one round -- nwg: total number of tiles.
-__device__ __forceinline__ TileMap map_tile(int bid, int nwg, int tiles_m, int tiles_n) {
+__device__ __forceinline__ TileMap map_tile(int bid, int nwg, int tiles_m, int tiles_n, int colblock) {
     const int tiles_per_plane = tiles_m * tiles_n;
     {
         const int xcd = bid & 7, idx = bid >> 3;
@@ -41,14 +62,25 @@ __device__ __forceinline__ TileMap map_tile(int bid, int nwg, int tiles_m, int t
     TileMap t;
     t.plane = bid / tiles_per_plane;
     int rem = bid - t.plane * tiles_per_plane;
+    // Column blocks (colblock > 0, chosen by map_colblock on the host): the plane is walked one block of colblock tile-columns at a
+    // time, ALL row groups of a block before the next block, so that the block's B panels stay in the Infinity Cache while the row
+    // groups stream past.
+    int tn0 = 0, w = tiles_n;
+    if (colblock > 0 && tiles_n > colblock) {
+        const int per_block = tiles_m * colblock;
+        const int b = rem / per_block;
+        rem -= b * per_block;
+        tn0 = b * colblock;
+        w = (tiles_n - tn0) < colblock ? (tiles_n - tn0) : colblock;
+    }
     constexpr int GM = 8;
-    const int group_sz = GM * tiles_n;
+    const int group_sz = GM * w;
     const int g = rem / group_sz;
     const int first_m = g * GM;
     const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
     rem -= g * group_sz;
     t.tm = first_m + rem % gm;
-    t.tn = rem / gm;
+    t.tn = tn0 + rem / gm;
     return t;
 }
 

@@ -51,6 +51,7 @@ struct F8Args {
     size_t strideA, strideB;
     int planeA[20], planeB[20];
     int kp, m, n, tiles_m, tiles_n;
+    int colblock;  // tile-columns per column block of the tile walk (map_colblock; 0 = full width)
     int t_begin;          // block b <-> modulus t_begin + b
     int16_t* out;         // EPI_PART: scratch plane b at out + b*strideO; EPI_FINAL: C_mid plane (t_begin+b) likewise
     size_t ldo, strideO;
@@ -311,7 +312,7 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
     };
 #define F8_SET_TILE(vb_)                                                                                                     \
     do {                                                                                                                     \
-        const TileMap tmap_ = map_tile((vb_), total, args.tiles_m, args.tiles_n);                                            \
+        const TileMap tmap_ = map_tile((vb_), total, args.tiles_m, args.tiles_n, args.colblock);                                            \
         const F8Plane pl_ = f8_plane(args, tmap_.plane);                                                                     \
         gsrc = uniform(isB ? args.B + pl_.boff + (size_t)args.planeB[pl_.tt] * args.strideB + (size_t)tmap_.tn * BN * args.kp \
                            : args.A + pl_.boff + (size_t)args.planeA[pl_.tt] * args.strideA + (size_t)tmap_.tm * BM * args.kp); \
@@ -458,7 +459,7 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n);
+            const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n, args.colblock);
             const int i0 = tmap.tm * BM + wm * 128, j0 = tmap.tn * BN + wn * 64;
             const F8Plane pl = f8_plane(args, tmap.plane);
             if constexpr (EPI == EPI_PART || EPI == EPI_FINAL || EPI == EPI_FINAL_CPLX) {
@@ -520,6 +521,7 @@ template <int EPI> static hipError_t launch(hipStream_t stream, F8Args& a, int p
     planes *= (int)g_batch.batch;
     a.total_tiles = planes * a.tiles_m * a.tiles_n;
     if (a.total_tiles <= 0) return hipSuccess;
+    a.colblock = map_colblock((size_t)a.tiles_n, (size_t)a.kp);
     int grid = num_cus() & ~7;  // persistent: one workgroup per CU (see oz2_gemm_i8.hip)
     if (grid <= 0) grid = 8;
     if (a.total_tiles < grid) grid = a.total_tiles;

@@ -62,6 +62,7 @@ struct GemmArgs {
     int kp;                // padded K (multiple of 256) = row pitch in bytes
     int m, n;              // valid rows / cols of C
     int tiles_m, tiles_n;
+    int colblock;          // tile-columns per column block of the tile walk (map_colblock; 0 = full width)
     int t_begin;           // plane p <-> modulus t_begin + p
     int8_t* out;           // EPI_MOD: plane p at out + p*strideO, [n][ldo] int8; EPI_CPLX: [n][ldo] char2
     size_t ldo;
@@ -570,7 +571,7 @@ __device__ __attribute__((noinline)) void i8_producer_crt(__attribute__((address
         const bool reads_c = mode == 0 || mode == 2 || mode == 4;
         const int S = KT * planes_per_tile;  // K-steps per output tile
         int c_vb = blockIdx.x, c_u = 0;      // CRT cursor: tile and next unit (0..63) to load
-        TileMap c_map = map_tile(c_vb, total, args.tiles_m, args.tiles_n);
+        TileMap c_map = map_tile(c_vb, total, args.tiles_m, args.tiles_n, args.colblock);
         int g = 0, ready_at = S + 1;         // K-steps completed; K-step from which the cursor tile's residues may be read
         unsigned rvN[20], rvC[20];           // residue words (4 rows): stage "loaded" / stage "accumulating"
         unsigned long long saN = 0, saC = 0; // four int16 shifts of A
@@ -655,7 +656,7 @@ __device__ __attribute__((noinline)) void i8_producer_crt(__attribute__((address
                 c_u = 0;                                                                                                     \
                 c_vb += G;                                                                                                   \
                 ready_at += S;                                                                                               \
-                if (c_vb < total) c_map = map_tile(c_vb, total, args.tiles_m, args.tiles_n);                                 \
+                if (c_vb < total) c_map = map_tile(c_vb, total, args.tiles_m, args.tiles_n, args.colblock);                                 \
             }                                                                                                                \
         }                                                                                                                    \
     } while (0)
@@ -930,7 +931,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     auto run = [&]<bool WM1>() {
         int sA = 0;  // slot of A(g); B(g) sits in the next slot (mod 5)
         for (int vb = blockIdx.x; vb < total; vb += G) {
-            const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n);
+            const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n, args.colblock);
             for (int pl = 0; pl < planes_per_tile; ++pl) {
             v4i acc[8][4];
             v4i af[4], bf[4];
@@ -1008,7 +1009,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     if (wm == 1) __builtin_amdgcn_s_barrier();  // trailing half: one segment behind
     int sA = 0;                                  // slot of A(g); B(g) sits in the next slot (mod 5)
     for (int vb = blockIdx.x; vb < total; vb += G) {
-        const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n);
+        const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n, args.colblock);
         for (int pl = 0; pl < planes_per_tile; ++pl) {
         v4i acc[8][4];
 #pragma unroll
@@ -1137,6 +1138,7 @@ template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int
     planes *= (int)g_batch.batch;
     a.total_tiles = planes * a.tiles_m * a.tiles_n;
     if (a.total_tiles <= 0) return hipSuccess;
+    a.colblock = map_colblock((size_t)a.tiles_n, (size_t)a.kp * (size_t)a.nseg);
     // (the bound GEMM keeps the ping-pong schedule at every k: with the row / column-maxima epilogue the K-step-barrier instantiation
     // spills accumulators INSIDE its MFMA loop -- five 16-byte stores and six loads per K-step -- and ran the 4096^3 bound GEMM at
     // half the rate of the residue GEMMs; OZ2_MAX_KBAR=1 restores it for A/B runs)
@@ -1210,6 +1212,7 @@ hipError_t launch_gemm_i8_mod_crt(hipStream_t stream, int dtype, const int8_t* A
     a.ppi = (int)N;
     a.total_tiles = a.tiles_m * a.tiles_n;
     if (a.total_tiles <= 0) return hipSuccess;
+    a.colblock = map_colblock((size_t)a.tiles_n, (size_t)a.kp);
     CrtArgs c{};
     c.m = m;
     c.n = n;

@@ -377,6 +377,22 @@ def test_residue_store_policy_both(dtype, policy, monkeypatch):
     gu.parity_case(A, B, 12 if dtype != np.float32 else 7, True, alpha=-1.0, beta=1.0, C0=rand((m, n), dtype, rng, phi=0.0))
 
 
+@pytest.mark.parametrize("width", ["1", "2", "3"])
+@pytest.mark.parametrize("dtype,backend_fp8", [(np.float64, False), (np.complex64, False), (np.float32, True)])
+def test_tile_walk_column_blocks(dtype, backend_fp8, width, monkeypatch):
+    """Planes wider than ~160 MiB of B panels are walked in column blocks (oz2_gemm_common.hpp map_colblock, map_tile); the width is a
+    kernel argument and GEMMUL8_MAP_COLBLOCK forces it, so small products exercise the blocked walk, ragged last block included
+    (5 tile-columns in blocks of 1, 2, 3).  Same bits as the oracle."""
+    import gemmul8_amd as g
+    import gpu_util as gu
+    monkeypatch.setenv("GEMMUL8_MAP_COLBLOCK", width)
+    rng = np.random.default_rng(int(width))
+    m, n, k = 520, 1100, 96
+    A = rand((m, k), dtype, rng, phi=1.0)
+    B = rand((k, n), dtype, rng, phi=1.0)
+    gu.parity_case(A, B, 8 if dtype == np.float64 else 6, False, backend=g.FP8 if backend_fp8 else g.INT8)
+
+
 def test_residue_store_policy_auto_at_size(monkeypatch):
     """8192 x 8192 x 512, 14 moduli: 112 MiB of operand planes and 896 MiB of residues -- the shape class where the library picks
     non-temporal residue stores by itself.  The result must equal the forced default-policy run bit for bit."""
