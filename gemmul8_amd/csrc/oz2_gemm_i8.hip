@@ -96,6 +96,11 @@ struct GemmArgs {
 #define OZ2_EPI_NT 0  // compile-time residue-store policy for A/B builds: 1 non-temporal always, 2 sc0, 3 sc1, 4 sc0 sc1 (sc bits: 2-6 % slower
                      // everywhere, profiles/r03_epi_store_policy.txt).  The shipped build chooses non-temporal stores per launch and plane: args.nt_planes
 #endif
+#ifndef OZ2_CPLX_NT
+#define OZ2_CPLX_NT 0  // 1: the size rule of nt_residue_planes also for the complex combine launch.  Forced (GEMMUL8_EPI_NT=1) it LOSES 1-3 % of the
+                      // whole call (ZGEMM 8192^2 x 512 ... 8192, 14 moduli; CGEMM x 768 ... 2048, 7 moduli): the operand planes of the three parts
+                      // never fit the Infinity Cache together, and the CRT finds more of the interleaved plane there with the default policy
+#endif
 #ifndef OZ2_RED_DOT4
 #define OZ2_RED_DOT4 1  // odd moduli: residue of an accumulator by byte dot product (4 full-rate 32-bit instructions) instead of the FP64 quotient (5):
                         // 14 planes 8192 x 8192, k = 1024 / 4096 / 8192: 1.011 -> 0.990 / 2.911 -> 2.891 / 5.356 -> 5.348 ms (profiles/r03_red_dot4_ab.txt)
@@ -283,7 +288,12 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
 #elif OZ2_CPLX_ABL & 4  // timing ablation (wrong results): half the stores
                         if (h == 0) *((uint4*)(args.out + po + 2 * e) + h) = make_uint4(o[0] ^ o[2], o[1] ^ o[3], o[2], o[3]);
 #else
-                        *((uint4*)(args.out + po + 2 * e) + h) = make_uint4(o[0], o[1], o[2], o[3]);
+                        if (pl.tt < args.nt_planes) {  // wave-uniform
+                            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                            __builtin_nontemporal_store(v4u{o[0], o[1], o[2], o[3]}, (v4u*)(args.out + po + 2 * e) + h);
+                        } else {
+                            *((uint4*)(args.out + po + 2 * e) + h) = make_uint4(o[0], o[1], o[2], o[3]);
+                        }
 #endif
                     }
                 }
@@ -1153,10 +1163,10 @@ template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int
 // 0.917 -> 0.815 / 1.059 -> 0.940 / 1.470 -> 1.285 ms; 16384^2: k = 256 / 512 3.22 -> 2.88 / 3.88 -> 3.59 ms); when they do not fit
 // there is nothing to protect and the CRT pass loses the tail of C_mid it would have found in the cache (-0.5 ... -2 % from k = 1536
 // at 8192^2, k = 1024 at 16384^2); with small outputs (4096^2 and below) it is a wash.  profiles/r03_epi_nt_grid.txt
-static int nt_residue_planes(const GemmArgs& a, int planes, bool stream_out) {
+static int nt_residue_planes(const GemmArgs& a, int planes, bool stream_out, bool automatic = true) {
     const char* e = getenv("GEMMUL8_EPI_NT");  // testing switch, read per launch: 0 / 1 forces the policy for all planes (results are identical)
-    if (e && (e[0] == '0' || e[0] == '1') && !e[1]) return e[0] == '1' ? planes : 0;
-    if (!stream_out) return 0;
+    if (e && (e[0] == '0' || e[0] == '1') && !e[1]) return e[0] == '1' && stream_out ? planes : 0;
+    if (!stream_out || !automatic) return 0;
     const size_t all = (size_t)planes * g_batch.batch;
     const size_t operands = all * (a.strideA + a.strideB), residues = all * a.strideO;
     // (keeping the default policy for the last 2-6 planes, so that the CRT finds them in the cache, and non-temporal stores for the
@@ -1246,6 +1256,7 @@ hipError_t launch_gemm_i8_cplx(hipStream_t stream, const int8_t* A, const int8_t
     a.ry = ry;
     a.strideR = strideR;
     fill_common(a, kp, m, n);
+    a.nt_planes = nt_residue_planes(a, t_end - t_begin, true, OZ2_CPLX_NT);
     return launch<EPI_CPLX>(stream, a, t_end - t_begin);
 }
 
