@@ -459,7 +459,7 @@ def main():
         {"kernel": "oz2 quantise pair: A (row-strided) + B (K-major), <double,MOD> (+ shift_finalize; fast mode: + the norm kernels)",
          "bound": "hbm", "ms": q_ms, "algorithmic_bytes": q_bytes, "achieved": q_bytes / q_ms * 1e-6, "peak": 8000.0, "unit": "GB/s",
          "frac": q_bytes / q_ms * 1e-6 / 8000.0},
-        {"kernel": "oz2::crt_kernel<double>", "bound": "hbm", "ms": c_ms, "algorithmic_bytes": c_bytes, "achieved": c_bytes / c_ms * 1e-6,
+        {"kernel": "oz2::crt_dma_kernel<double> (CRT + unscale + axpby; register form oz2::crt_kernel for ragged shapes)", "bound": "hbm", "ms": c_ms, "algorithmic_bytes": c_bytes, "achieved": c_bytes / c_ms * 1e-6,
          "peak": 8000.0, "unit": "GB/s", "frac": c_bytes / c_ms * 1e-6 / 8000.0}]
     if not args.fast:
         b_ms = float(np.mean([e[4].elapsed_time(e[0]) for e in phase_events]))

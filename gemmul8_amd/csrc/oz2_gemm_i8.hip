@@ -1169,8 +1169,10 @@ static int nt_residue_planes(const GemmArgs& a, int planes, bool stream_out, boo
     if (!stream_out || !automatic) return 0;
     const size_t all = (size_t)planes * g_batch.batch;
     const size_t operands = all * (a.strideA + a.strideB), residues = all * a.strideO;
-    // (keeping the default policy for the last 2-6 planes, so that the CRT finds them in the cache, and non-temporal stores for the
-    // leading planes of launches whose operands do NOT fit were both measured: no gain, profiles/r03_epi_nt_keep.txt)
+    // (keeping the default policy for the last 2-6 planes, so that the CRT finds them in the cache, non-temporal stores for the
+    // leading planes of launches whose operands do NOT fit, and walking the planes last to first -- the order the quantise kernels
+    // left them in the cache -- were all measured: no consistent gain, profiles/r03_epi_nt_keep.txt; between 240 and ~450 MiB of
+    // operand planes the sign of the effect differs from box to box, -2 ... +4 %)
     return residues >= ((size_t)256 << 20) && operands <= ((size_t)240 << 20) ? planes : 0;
 }
 

@@ -130,6 +130,9 @@ __device__ __forceinline__ void quad_transpose4(unsigned (&w)[4], unsigned q) {
     }
 }
 
+#ifndef OZ2_LOAD_NT
+#define OZ2_LOAD_NT 1  // 0: no non-temporal operand loads anywhere (experiment)
+#endif
 // v[0..3] = x[k0 .. k0+3], zero beyond k: 16-byte loads when the four elements exist and start on a 16-byte boundary
 // NT: non-temporal (the data is read once); false where the same workgroup re-reads the row right away (two-pass bound extract: with nt
 // loads in the maxima pass the second pass went back to HBM -- ZGEMM 8192^3 bounds phase 2.58 -> 2.81 ms)
@@ -140,7 +143,7 @@ template <typename T, bool NT = true> __device__ __forceinline__ void load4(cons
         constexpr int NQ = (int)(4 * sizeof(T) / 16);
         V4 r[NQ];
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) r[i] = NT ? __builtin_nontemporal_load((const V4*)p + i) : ((const V4*)p)[i];
+        for (int i = 0; i < NQ; ++i) r[i] = (NT && OZ2_LOAD_NT) ? __builtin_nontemporal_load((const V4*)p + i) : ((const V4*)p)[i];
         __builtin_memcpy(v, r, sizeof(r));
     } else {
 #pragma unroll
@@ -692,7 +695,7 @@ __global__ void __launch_bounds__(256) stage_strided_kernel(const StageArgs a) {
             V4 v = {0u, 0u, 0u, 0u};
             if (kg < a.k) {
                 if (pair_ok) {
-                    v = __builtin_nontemporal_load((const V4*)(x + kg * a.ld));
+                    v = OZ2_LOAD_NT ? __builtin_nontemporal_load((const V4*)(x + kg * a.ld)) : *(const V4*)(x + kg * a.ld);
                 } else {
                     T t0 = (row < a.rows) ? x[kg * a.ld] : E::zero(), t1 = (row + 1 < a.rows) ? x[kg * a.ld + 1] : E::zero();
                     __builtin_memcpy(&v, &t0, 8);
