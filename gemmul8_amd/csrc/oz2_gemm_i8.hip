@@ -72,6 +72,7 @@ struct GemmArgs {
     size_t strideR;
     int* rowmax;           // EPI_MAX
     int* colmax;
+    int kt_mid;            // EPI_MAX: > 0 = the maxima are ALSO taken after this many K-steps of every tile (partial sums of a K-concatenation)
     int total_tiles;       // planes * tiles_m * tiles_n (tile-stationary order, FUSE != 0: tiles_m * tiles_n)
     int planes;            // FUSE != 0: residue planes every workgroup runs through per output tile
     int ppi;               // planes per batch item (plane p = item p / ppi, modulus-relative plane p % ppi); = all planes for one GEMM
@@ -973,7 +974,13 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     const char* curA = smem + sA * TILE_BYTES + a_base;                                                                      \
     const char* curB = smem + (sA == 4 ? 0 : sA + 1) * TILE_BYTES + b_base;                                                  \
     sA = sA + 2 >= 5 ? sA - 3 : sA + 2
-            for (int kt = 0; kt < KT; ++kt) {
+            // EPI_MAX with kt_mid: two phases per tile (K-steps [0, kt_mid) and [kt_mid, KT)), the maxima epilogue after each; the
+            // accumulators run through.  Every other instantiation: one phase.
+            int kt = 0;
+            const int nph = (EPI == EPI_MAX && args.kt_mid > 0) ? 2 : 1;
+            for (int ph = 0; ph < nph; ++ph) {
+            const int kt_end = (EPI == EPI_MAX && ph + 1 < nph) ? args.kt_mid : KT;
+            for (; kt < kt_end; ++kt) {
                 OZ2_SET_PANELS();
 #pragma unroll
                 for (int seg = 0; seg < 4; ++seg) {
@@ -1005,6 +1012,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #else
             i8_epilogue<EPI>(acc, args, FUSE ? PlaneRef{0, pl} : plane_ref(args, tmap.plane), tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane);
 #endif
+            }  // phase
             }
             // FUSE: the producer waves accumulate the CRT of this tile during the next one; they read the residue planes one K-step
             // after the barrier that follows this wait
@@ -1029,7 +1037,11 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = (EPI == EPI_MAX || !OZ2_RED_DOT4) ? 0 : (int)0x80000000u;
 
-        for (int kt = 0; kt < KT; ++kt) {
+        int kt = 0;  // phases: see the K-step-barrier branch
+        const int nph = (EPI == EPI_MAX && args.kt_mid > 0) ? 2 : 1;
+        for (int ph = 0; ph < nph; ++ph) {
+        const int kt_end = (EPI == EPI_MAX && ph + 1 < nph) ? args.kt_mid : KT;
+        for (; kt < kt_end; ++kt) {
             const char* curA = smem + sA * TILE_BYTES + a_base;
             const char* curB = smem + (sA == 4 ? 0 : sA + 1) * TILE_BYTES + b_base;
             sA = sA + 2 >= 5 ? sA - 3 : sA + 2;
@@ -1081,6 +1093,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #else
         i8_epilogue<EPI>(acc, args, FUSE ? PlaneRef{0, pl} : plane_ref(args, tmap.plane), tmap.tm * BM + wm * 128, tmap.tn * BN + wn * 64, lane);
 #endif
+        }  // phase
         }
         if constexpr (FUSE != 0) i8_crt_tail<OutT>(args, tmap.tm * BM + wm * 128, tmap.tn * BN + wn * 64, lane);
     }
@@ -1265,20 +1278,24 @@ hipError_t launch_gemm_i8_cplx(hipStream_t stream, const int8_t* A, const int8_t
 #ifndef OZ2_MAX_SMALL_TILES
 #define OZ2_MAX_SMALL_TILES 128  // the bound GEMM takes the 128 x 128-tile kernel when (batch x) its 256 x 256 tiles number at most this (of 256 CUs): bounds phase 33 -> 28 / 41 -> 32 / 66 -> 55 us at 512^3 / 1024^3 / 2048^3, but 98 -> 111 us at 3072^3 (144 tiles), profiles/r03_bound_ab.txt
 #endif
+// mid_seg > 0: the row / column maxima are taken twice per tile -- of the partial sums after the first mid_seg K-segments and of the
+// full sums.  The complex bound (max over the elements of C1 = ArBi + AiBr and of C1 + C0, C0 = (Ar-Ai)(Br-Bi)) is then ONE launch over
+// three segments with mid_seg = 2 (three real GEMMs of work) instead of a 2-segment and a 3-segment launch (five).
 hipError_t launch_gemm_i8_max(hipStream_t stream, int nseg, const int8_t* const* A, const int8_t* const* B, size_t kp, size_t m, size_t n,
-                              int* rowmax, int* colmax) {
+                              int* rowmax, int* colmax, int mid_seg) {
     {
         // GEMMUL8_BOUND_TILE = 128 | 256 forces one kernel (tests run every case through both; the maxima are identical)
         const char* force = getenv("GEMMUL8_BOUND_TILE");
         const size_t tiles = ((m + BM - 1) / BM) * ((n + BN - 1) / BN) * g_batch.batch;
         const bool small = force && force[0] == '1' ? true : force && force[0] == '2' ? false : tiles <= (size_t)OZ2_MAX_SMALL_TILES;
-        if (small) return launch_gemm_i8_max_small(stream, nseg, A, B, kp, m, n, rowmax, colmax);
+        if (small) return launch_gemm_i8_max_small(stream, nseg, A, B, kp, m, n, rowmax, colmax, mid_seg);
     }
     GemmArgs a{};
     for (int s = 0; s < nseg; ++s) a.A[s] = A[s], a.B[s] = B[s];
     a.nseg = nseg;
     a.rowmax = rowmax;
     a.colmax = colmax;
+    a.kt_mid = mid_seg > 0 && mid_seg < nseg ? mid_seg * (int)(kp / BK) : 0;
     fill_common(a, kp, m, n);
     return launch<EPI_MAX>(stream, a, 1);
 }

@@ -32,6 +32,7 @@ struct SmallArgs {
     int tiles_m, tiles_n;
     int* rowmax;
     int* colmax;
+    int ks_mid;      // > 0: the maxima are also taken after this many K-steps (partial sums of a K-concatenation), see launch_gemm_i8_max
     size_t bstride;  // bytes between the workspaces of consecutive batch items (gridDim.z)
 };
 
@@ -91,7 +92,11 @@ __global__ void __launch_bounds__(256, 2) gemm_i8_max_small_kernel(const SmallAr
     OZ2_LSTORE(0)
     __syncthreads();
     const unsigned fr = lane & 15u, fq = lane >> 4;
-    for (int ks = 0; ks < ksteps; ++ks) {
+    int ks = 0;
+    const int nph = a.ks_mid > 0 ? 2 : 1;
+    for (int ph = 0; ph < nph; ++ph) {
+    const int ks_end = ph + 1 < nph ? a.ks_mid : ksteps;
+    for (; ks < ks_end; ++ks) {
         const int st = ks & 1;
         if (ks + 1 < ksteps) OZ2_GLOAD(ks + 1)
 #pragma unroll
@@ -110,8 +115,6 @@ __global__ void __launch_bounds__(256, 2) gemm_i8_max_small_kernel(const SmallAr
         if (ks + 1 < ksteps) OZ2_LSTORE(st ^ 1)
         __syncthreads();
     }
-#undef OZ2_GLOAD
-#undef OZ2_LSTORE
 
     // maxima of the wave's 64 x 64 block (accumulator map: col = lane & 15, row = 4 (lane >> 4) + reg)
     const int i0 = row0 + (int)wm * 64, j0 = col0 + (int)wn * 64;
@@ -152,11 +155,14 @@ __global__ void __launch_bounds__(256, 2) gemm_i8_max_small_kernel(const SmallAr
         }
         tile_rowmax_atomic16(w, rowmax_, i0 + ti * 16, a.m, (int)lane);
     }
+    }  // phase
+#undef OZ2_GLOAD
+#undef OZ2_LSTORE
 }
 }  // namespace
 
 hipError_t launch_gemm_i8_max_small(hipStream_t stream, int nseg, const int8_t* const* A, const int8_t* const* B, size_t kp, size_t m, size_t n,
-                                    int* rowmax, int* colmax) {
+                                    int* rowmax, int* colmax, int mid_seg) {
     if (m == 0 || n == 0) return hipSuccess;
     SmallArgs a{};
     for (int s = 0; s < nseg; ++s) a.A[s] = A[s], a.B[s] = B[s];
@@ -168,6 +174,7 @@ hipError_t launch_gemm_i8_max_small(hipStream_t stream, int nseg, const int8_t* 
     a.tiles_n = (int)((n + SBN - 1) / SBN);
     a.rowmax = rowmax;
     a.colmax = colmax;
+    a.ks_mid = mid_seg > 0 && mid_seg < nseg ? mid_seg * (int)(kp / BK) : 0;
     a.bstride = g_batch.ws;
     const size_t tiles = (size_t)a.tiles_m * a.tiles_n;
     if (tiles > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;

@@ -45,11 +45,11 @@ hipError_t launch_gemm_i8_cplx(hipStream_t stream, const int8_t* A, const int8_t
                                size_t n, int t_begin, int t_end, const int8_t* rx, const int8_t* ry, size_t strideR, int8_t* out,
                                size_t ldo, size_t strideO);
 hipError_t launch_gemm_i8_max(hipStream_t stream, int nseg, const int8_t* const* A, const int8_t* const* B, size_t kp, size_t m, size_t n,
-                              int* rowmax, int* colmax);
+                              int* rowmax, int* colmax, int mid_seg = 0);
 
 // 128 x 128-tile form of the bound GEMM for products whose 256 x 256 tiles would not fill the chip (oz2_gemm_i8_small.hip)
 hipError_t launch_gemm_i8_max_small(hipStream_t stream, int nseg, const int8_t* const* A, const int8_t* const* B, size_t kp, size_t m, size_t n,
-                                    int* rowmax, int* colmax);
+                                    int* rowmax, int* colmax, int mid_seg = 0);
 
 // ---- FP8 MFMA GEMM (oz2_gemm_f8.hip)
 hipError_t launch_gemm_f8(hipStream_t stream, int which, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp, size_t m,
