@@ -207,7 +207,8 @@ int gemmul8_scale_bounds(void* stream_, int dtype, int backend, int op_A, int op
             const int8_t* As[3] = {Ab, Ab + L->sizeA, Ab + 2 * L->sizeA};
             const int8_t* Bs[3] = {Bb + L->sizeB, Bb, Bb + 2 * L->sizeB};
             //   One launch over the three segments; the maxima are taken after the second (C1) and after the third (C1 + C0).
-            static const bool two_launches = [] { const char* e = getenv("GEMMUL8_CPLX_BOUND_LAUNCHES"); return e && e[0] == '2'; }();  // A/B switch
+            const char* bl = getenv("GEMMUL8_CPLX_BOUND_LAUNCHES");  // A/B and testing switch, read per call
+            const bool two_launches = bl && bl[0] == '2';
             if (two_launches) {
                 OZ2_HIP(launch_gemm_i8_max(stream, 2, As, Bs, L->kp, m, col_end - col_begin, rowmax, colmax + col_begin));
                 OZ2_HIP(launch_gemm_i8_max(stream, 3, As, Bs, L->kp, m, col_end - col_begin, rowmax, colmax + col_begin));

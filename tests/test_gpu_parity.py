@@ -393,6 +393,24 @@ def test_tile_walk_column_blocks(dtype, backend_fp8, width, monkeypatch):
     gu.parity_case(A, B, 8 if dtype == np.float64 else 6, False, backend=g.FP8 if backend_fp8 else g.INT8)
 
 
+@pytest.mark.parametrize("launches", ["1", "2"])
+@pytest.mark.parametrize("tile", ["128", "256"])
+@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+def test_complex_bound_one_or_two_launches(dtype, tile, launches, monkeypatch):
+    """Complex INT8 bound (find_max.hpp:99-114): maxima of C1 = |Ar||Bi| + |Ai||Br| and of C1 + C0.  Shipped: ONE 3-segment launch whose
+    maxima epilogue also runs on the partial sums after the second segment; GEMMUL8_CPLX_BOUND_LAUNCHES=2: the 2-segment + 3-segment
+    pair of rounds 1-2.  Both kernels (128 / 256 tiles), several K-steps per segment; parity_case asserts the integer row / column
+    maxima, the shifts and everything downstream against the oracle."""
+    import gpu_util as gu
+    monkeypatch.setenv("GEMMUL8_CPLX_BOUND_LAUNCHES", launches)
+    monkeypatch.setenv("GEMMUL8_BOUND_TILE", tile)
+    rng = np.random.default_rng(11)
+    m, n, k = 300, 270, 700
+    A = rand((m, k), dtype, rng, phi=2.0)
+    B = rand((k, n), dtype, rng, phi=2.0)
+    gu.parity_case(A, B, 10 if dtype == np.complex128 else 6, False)
+
+
 def test_residue_store_policy_auto_at_size(monkeypatch):
     """8192 x 8192 x 512, 14 moduli: 112 MiB of operand planes and 896 MiB of residues -- the shape class where the library picks
     non-temporal residue stores by itself.  The result must equal the forced default-policy run bit for bit."""
