@@ -1162,9 +1162,9 @@ template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int
     a.total_tiles = planes * a.tiles_m * a.tiles_n;
     if (a.total_tiles <= 0) return hipSuccess;
     a.colblock = map_colblock((size_t)a.tiles_n, (size_t)a.kp * (size_t)a.nseg);
-    // (the bound GEMM keeps the ping-pong schedule at every k: with the row / column-maxima epilogue the K-step-barrier instantiation
-    // spills accumulators INSIDE its MFMA loop -- five 16-byte stores and six loads per K-step -- and ran the 4096^3 bound GEMM at
-    // half the rate of the residue GEMMs; OZ2_MAX_KBAR=1 restores it for A/B runs)
+    // (the bound GEMM keeps the ping-pong schedule at every k.  In round 2 its K-step-barrier instantiation spilled accumulators INSIDE
+    // the MFMA loop; with the round-3 source it no longer does, but the single-plane launch still runs slower with it: bounds phase
+    // 88.4 -> 92.4 us at 3072^3, 130.9 -> 134.6 at 4096^3, equal at 2048^3 and 8192^3.  OZ2_MAX_KBAR=1 restores it for A/B runs)
     if ((EPI != EPI_MAX || OZ2_MAX_KBAR) && a.kp * a.nseg <= OZ2_KBAR_MAX_KP) return launch_sched<EPI, true>(stream, a);
     return launch_sched<EPI, false>(stream, a);
 }
