@@ -678,15 +678,18 @@ __global__ void __launch_bounds__(256) stage_strided_kernel(const StageArgs a) {
 #endif
     const size_t r0 = (size_t)rt * TR;
     const size_t kb = (size_t)kt * TK;
-    if constexpr (OZ2_STAGE_PAIRLOAD && sizeof(T) == 8) {
-        // 8-byte elements: a lane fetches TWO consecutive rows with one 16-byte load (half the load instructions, 1 KiB per wave
-        // instruction instead of 512 B) when both rows exist and the pair is 16-byte aligned; all loads of the tile are in flight at once
-        constexpr int RP = TR / 2;       // row pairs per column
+    if constexpr (OZ2_STAGE_PAIRLOAD && sizeof(T) <= 8) {
+        // 4- and 8-byte elements: a lane fetches RPL = 4 / 2 consecutive rows with one 16-byte load (a half / a quarter of the load
+        // instructions, 1 KiB per wave instruction) when the rows exist and the group is 16-byte aligned; all loads of the tile are in
+        // flight at once.  (float operands took the one-element-per-lane path until round 3: quantise A 222 us = 3.3 TB/s at 8192^2,
+        // against 5.4 TB/s for double.)
+        constexpr int RPL = 16 / (int)sizeof(T);
+        constexpr int RP = TR / RPL;     // row groups per column
         constexpr int KY = 256 / RP;     // k values fetched per pass
         const int rp = threadIdx.x % RP, ky = threadIdx.x / RP;
-        const size_t row = r0 + 2 * rp;
+        const size_t row = r0 + RPL * rp;
         const T* x = (const T*)((const char*)a.X + OZ2_ZX) + row;
-        const bool pair_ok = row + 1 < a.rows && ((reinterpret_cast<uintptr_t>(x) | (a.ld * sizeof(T))) & 15u) == 0;
+        const bool pair_ok = row + RPL - 1 < a.rows && ((reinterpret_cast<uintptr_t>(x) | (a.ld * sizeof(T))) & 15u) == 0;
         typedef unsigned V4 __attribute__((ext_vector_type(4)));
         V4 buf[TK / KY];
 #pragma unroll
@@ -697,9 +700,11 @@ __global__ void __launch_bounds__(256) stage_strided_kernel(const StageArgs a) {
                 if (pair_ok) {
                     v = OZ2_LOAD_NT ? __builtin_nontemporal_load((const V4*)(x + kg * a.ld)) : *(const V4*)(x + kg * a.ld);
                 } else {
-                    T t0 = (row < a.rows) ? x[kg * a.ld] : E::zero(), t1 = (row + 1 < a.rows) ? x[kg * a.ld + 1] : E::zero();
-                    __builtin_memcpy(&v, &t0, 8);
-                    __builtin_memcpy((char*)&v + 8, &t1, 8);
+#pragma unroll
+                    for (int e = 0; e < RPL; ++e) {
+                        const T t = (row + e < a.rows) ? x[kg * a.ld + e] : E::zero();
+                        __builtin_memcpy((char*)&v + e * sizeof(T), &t, sizeof(T));
+                    }
                 }
             }
             buf[it] = v;
@@ -707,8 +712,8 @@ __global__ void __launch_bounds__(256) stage_strided_kernel(const StageArgs a) {
 #pragma unroll
         for (int it = 0; it < TK / KY; ++it) {
             const int kk = ky + KY * it;
-            __builtin_memcpy(&tile[2 * rp][kk], &buf[it], 8);
-            __builtin_memcpy(&tile[2 * rp + 1][kk], (const char*)&buf[it] + 8, 8);
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) __builtin_memcpy(&tile[RPL * rp + e][kk], (const char*)&buf[it] + e * sizeof(T), sizeof(T));
         }
     } else {
         constexpr int KY = 256 / TR;  // k values fetched per pass
@@ -1116,6 +1121,24 @@ template <typename T> __global__ void __launch_bounds__(256) fast_shift_strided_
         size_t col = ty;
         if (vec) {
             typedef unsigned V4 __attribute__((ext_vector_type(4)));
+            // loads in flight per thread: 8 x 16 bytes; 4-byte elements have half as many workgroups (8 x 4 rows each: 256 at 8192 rows,
+            // one per CU), so they keep 16 in flight (8192^2 float: 88 us = 3.0 TB/s with 8).  The order of the accumulation -- columns
+            // ascending per thread -- does not depend on the depth.
+            constexpr int UNR = sizeof(T) == 4 ? 16 : 8;
+            if constexpr (UNR > 8) {
+                for (; col + (UNR - 1) * 32 < k; col += UNR * 32) {
+                    V4 raw[UNR];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) raw[u] = *(const V4*)(x + (col + 32 * u) * ld);
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        T v[RPL];
+                        __builtin_memcpy(v, &raw[u], 16);
+#pragma unroll
+                        for (int j = 0; j < RPL; ++j) take(v[j], j);
+                    }
+                }
+            }
             for (; col + 7 * 32 < k; col += 8 * 32) {
                 V4 raw[8];
 #pragma unroll
