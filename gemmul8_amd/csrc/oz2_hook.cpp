@@ -463,8 +463,8 @@ bool try_emulate(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, hipbl
     if (below_floor(dtype, m, n, k, N, fastmode, backend)) return false;
     if (backend == GEMMUL8_FP8) {
         // the FP8 backend exists for parity with the reference; on this chip it is dominated: three FP8 GEMMs per modulus at about the
-        // INT8 MFMA rate against one INT8 GEMM (profiles/sweeps/*_types_backends.csv: SGEMM 8192^3 126 vs 276 TFLOPS, native 153;
-        // DGEMM 67 vs 152, native 73).  Say so once.
+        // INT8 MFMA rate against one INT8 GEMM (profiles/sweeps/*_types_backends.csv: SGEMM 8192^3 133 vs 305 TFLOPS, native 152;
+        // DGEMM 69 vs 160, native 72).  Say so once.
         static std::once_flag told;
         std::call_once(told, [] {
             std::fprintf(stderr, "[GEMMUL8 HOOK] GEMMUL8_BACKEND=FP8: on MI355X the INT8 backend (GEMMUL8_BACKEND=0) is ~2.2x faster at equal or better "
