@@ -131,7 +131,8 @@ __device__ __forceinline__ void quad_transpose4(unsigned (&w)[4], unsigned q) {
 }
 
 #ifndef OZ2_LOAD_NT
-#define OZ2_LOAD_NT 1  // 0: no non-temporal operand loads anywhere (experiment)
+#define OZ2_LOAD_NT 1  // 0: no non-temporal operand loads anywhere.  Measured: no gain where the operands would fit the Infinity Cache (8192^2 x 256 ... 2048,
+                       // 4096^2), and -5 % of the whole call at 8192^2 x 1024, where they evict the operand planes the GEMMs are about to read
 #endif
 // v[0..3] = x[k0 .. k0+3], zero beyond k: 16-byte loads when the four elements exist and start on a 16-byte boundary
 // NT: non-temporal (the data is read once); false where the same workgroup re-reads the row right away (two-pass bound extract: with nt
