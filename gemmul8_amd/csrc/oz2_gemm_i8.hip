@@ -80,6 +80,7 @@ struct GemmArgs {
     int moduli[20];
     int pinv32[20];
     int nt_planes;         // EPI_MOD: planes tt < nt_planes (of each batch item) leave with non-temporal stores (launch_gemm_i8_mod decides)
+    int acc0;              // EPI_MOD / EPI_CPLX: initial accumulator value: -2^31 (RED_ODD reads the register as x + 2^31), or 0 when K <= 512 (RED_ODD_SMALL)
     unsigned dotw[20];     // RED_ODD: bytes (256^j mod p), j = 0..3 (byte 0 = 1)
     unsigned dotc[20];     //          (-2^31) mod p
 };
@@ -101,6 +102,10 @@ struct GemmArgs {
 #define OZ2_CPLX_NT 0  // 1: the size rule of nt_residue_planes also for the complex combine launch.  Forced (GEMMUL8_EPI_NT=1) it LOSES 1-3 % of the
                       // whole call (ZGEMM 8192^2 x 512 ... 8192, 14 moduli; CGEMM x 768 ... 2048, 7 moduli): the operand planes of the three parts
                       // never fit the Infinity Cache together, and the CRT finds more of the interleaved plane there with the default policy
+#endif
+#ifndef OZ2_RED_SMALL
+#define OZ2_RED_SMALL 1  // K <= 512: three-instruction residue straight from the (unbiased) accumulator, see RED_ODD_SMALL (8192^2 x 256 / 512,
+                         // 14 planes: 0.440 -> 0.394 / 0.614 -> 0.565 ms; profiles/r03_red_small_ab.txt)
 #endif
 #ifndef OZ2_RED_DOT4
 #define OZ2_RED_DOT4 1  // odd moduli: residue of an accumulator by byte dot product (4 full-rate 32-bit instructions) instead of the FP64 quotient (5):
@@ -136,7 +141,7 @@ template <typename Args> __device__ __forceinline__ PlaneRef plane_ref(const Arg
     const int b = p / args.ppi;
     return {(size_t)b * args.bstride, p - b * args.ppi};
 }
-enum { RED_GENERIC = 0, RED_ODD = 1, RED_256 = 2 };
+enum { RED_GENERIC = 0, RED_ODD = 1, RED_256 = 2, RED_ODD_SMALL = 3 };
 // RED selects how an accumulator is reduced (uniform per plane): RED_256: p = 256, the symmetric residue IS the low byte;
 // RED_ODD: odd p, ONE exact FP64 quotient step for any int32 accumulator (v_cvt_f64_i32, v_mul_f64, v_rndne_f64, v_fma_f64,
 // v_cvt_i32_f64: FP64 VALU runs at the FP32 rate on gfx950); the two-step fp32 form it replaced cost 10 instructions and 12 % of
@@ -164,11 +169,22 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
 #else
             return mod_i32_sym_odd_f64(x, pd, invpd);
 #endif
-        } else return mod_i32_sym((int)((unsigned)x ^ (OZ2_RED_DOT4 ? 0x80000000u : 0u)), p, pinv);
+        } else if constexpr (RED == RED_ODD_SMALL) {
+            // short K (kp * nseg <= 512: |x| <= 512 * 127^2 < 2^23; the accumulators start at 0, GemmArgs.acc0): the quotient comes
+            // straight from the accumulator -- v_cvt_f32_i32, one fma against 1.5 * 2^23 (its low 24 bits are 2^22 + q for either sign
+            // of q), v_mad_i32_i24: the canonical residue minus p 2^22, i.e. the canonical LOW BYTE, which is all the epilogue stores.
+            // Three instructions instead of four.  The bound is 2^23, not the 2^24 of fp32 exactness: |x| |RN(1/p) - 1/p| must stay
+            // below the 1/(2p) that separates x / p from a rounding tie (exhaustive CPU model: first wrong byte at |x| = 8 454 907 for
+            // p = 255, tests/test_residue_math.py; tests/test_gpu_parity.py::test_epilogue_reduction_on_extreme_accumulators).
+            const float qf = fmaf((float)x, invp, 12582912.0f);
+            int r;
+            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(__float_as_int(qf)), "s"(-p), "v"(x));
+            return r;
+        } else return mod_i32_sym((int)((unsigned)x ^ ((OZ2_RED_DOT4 && args.acc0) ? 0x80000000u : 0u)), p, pinv);
     };
     auto red_small = [&](int x) {
         if constexpr (RED == RED_256) return x;
-        else if constexpr (RED == RED_ODD) return mod_small_sym_odd(x, p, invp);
+        else if constexpr (RED == RED_ODD || RED == RED_ODD_SMALL) return mod_small_sym_odd(x, p, invp);
         else return mod_i32_sym(x, p, pinv);
     };
     // After the 4 x 4 dword transpose below lane (q, c16) owns the 16 consecutive rows i0 + 64 tg + 16 q .. + 15 of column
@@ -241,7 +257,7 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
 #pragma unroll
                         for (int w2 = 0; w2 < 2; ++w2) {
                             unsigned lo = 0, hi = 0;
-                            if constexpr (RED == RED_ODD && OZ2_CPLX_PK16) {
+                            if constexpr ((RED == RED_ODD || RED == RED_ODD_SMALL) && OZ2_CPLX_PK16) {
                                 // packed 16-bit form: |X|, |Y|, |Z| <= (p-1)/2, so X - Y lies in (-p, p) and Z - X - Y in (-1.5 p, 1.5 p):
                                 // ONE wrap r = d + p ([d < -h] - [d > h]) gives the canonical residue, and v_pk_*_i16 does two elements per
                                 // instruction (comparisons as arithmetic shifts of h -+ d).  Half the VALU work of the per-element fp32 steps.
@@ -311,6 +327,7 @@ __device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmAr
     if constexpr (EPI == EPI_MOD || EPI == EPI_CPLX) {
         const int p = args.moduli[args.t_begin + pl.tt];
         if (p == 256 || OZ2_ABL_EPI == 2) i8_epilogue_mod<EPI, RED_256>(acc, args, pl, i0, j0, lane);
+        else if ((p & 1) && OZ2_RED_DOT4 && args.acc0 == 0) i8_epilogue_mod<EPI, RED_ODD_SMALL>(acc, args, pl, i0, j0, lane);
         else if (p & 1) i8_epilogue_mod<EPI, RED_ODD>(acc, args, pl, i0, j0, lane);
         else i8_epilogue_mod<EPI, RED_GENERIC>(acc, args, pl, i0, j0, lane);
     } else {
@@ -951,7 +968,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][j][r] = (EPI == EPI_MAX || !OZ2_RED_DOT4) ? 0 : (int)0x80000000u;
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = (EPI == EPI_MAX || !OZ2_RED_DOT4) ? 0 : args.acc0;
 #define OZ2_LOAD_SEG(seg_)                                                                                                   \
     do {                                                                                                                     \
         const int coff_ = (((((seg_) >> 1) << 2) | q) ^ sw) << 4;                                                            \
@@ -1035,7 +1052,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = (EPI == EPI_MAX || !OZ2_RED_DOT4) ? 0 : (int)0x80000000u;
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = (EPI == EPI_MAX || !OZ2_RED_DOT4) ? 0 : args.acc0;
 
         int kt = 0;  // phases: see the K-step-barrier branch
         const int nph = (EPI == EPI_MAX && args.kt_mid > 0) ? 2 : 1;
@@ -1162,6 +1179,7 @@ template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int
     a.total_tiles = planes * a.tiles_m * a.tiles_n;
     if (a.total_tiles <= 0) return hipSuccess;
     a.colblock = map_colblock((size_t)a.tiles_n, (size_t)a.kp * (size_t)a.nseg);
+    a.acc0 = (OZ2_RED_SMALL && (size_t)a.kp * (size_t)a.nseg <= 512) ? 0 : (int)0x80000000u;
     // (the bound GEMM keeps the ping-pong schedule at every k.  In round 2 its K-step-barrier instantiation spilled accumulators INSIDE
     // the MFMA loop; with the round-3 source it no longer does, but the single-plane launch still runs slower with it: bounds phase
     // 88.4 -> 92.4 us at 3072^3, 130.9 -> 134.6 at 4096^3, equal at 2048^3 and 8192^3.  OZ2_MAX_KBAR=1 restores it for A/B runs)
@@ -1238,6 +1256,7 @@ hipError_t launch_gemm_i8_mod_crt(hipStream_t stream, int dtype, const int8_t* A
     a.total_tiles = a.tiles_m * a.tiles_n;
     if (a.total_tiles <= 0) return hipSuccess;
     a.colblock = map_colblock((size_t)a.tiles_n, (size_t)a.kp);
+    a.acc0 = (OZ2_RED_SMALL && (size_t)a.kp <= 512) ? 0 : (int)0x80000000u;
     CrtArgs c{};
     c.m = m;
     c.n = n;

@@ -411,6 +411,50 @@ def test_complex_bound_one_or_two_launches(dtype, tile, launches, monkeypatch):
     gu.parity_case(A, B, 10 if dtype == np.complex128 else 6, False)
 
 
+@pytest.mark.parametrize("k", [256, 512, 768, 1024, 4096])
+def test_epilogue_reduction_on_extreme_accumulators(k):
+    """The requantise epilogue on accumulators AT the bounds the residue planes allow (planes of +-127 with long runs of equal sign, so
+    |sum| reaches k * 127^2), fed straight to gemmul8_lowprec_gemm: K <= 512 takes the three-instruction form (exact below 2^23),
+    longer K the byte-dot form on biased accumulators (any int32).  Random operands never come near these values; the expected residues
+    are plain integer arithmetic."""
+    import ctypes as C
+    import gemmul8_amd as g
+    L = g.lib()
+    m, n, N = 256, 192, 14
+    tot, _, _ = g.work_size(False, g.INT8, m, n, k, N)
+    work = torch.zeros(tot, dtype=torch.uint8, device="cuda")
+    Lo = g.Layout()
+    g.check(L.gemmul8_get_layout(g.D, g.INT8, m, n, k, N, work.data_ptr(), None, None, 0, 0, C.byref(Lo)))
+    assert Lo.kp == k
+    rng = np.random.default_rng(k)
+    base = work.data_ptr()
+
+    def planes(rows, rows_pad):
+        x = rng.choice(np.array([-127, 127, 126, -126, 0, 1], dtype=np.int8), size=(N, rows, k), p=[0.3, 0.3, 0.15, 0.15, 0.05, 0.05])
+        x[:, 0, :] = 127                      # rows of one sign: the largest sums
+        x[:, 1, :] = -127
+        x[:, 2, ::2] = 127
+        out = np.zeros((N, rows_pad, k), dtype=np.int8)
+        out[:, :rows] = x
+        return x, out
+    A, Ap = planes(m, Lo.sizeA // k)
+    B, Bp = planes(n, Lo.sizeB // k)
+    offA, offB, offC = Lo.A_lo - base, Lo.B_lo - base, Lo.C_mid - base
+    work[offA:offA + Ap.size] = torch.from_numpy(Ap.view(np.uint8).ravel()).cuda()
+    work[offB:offB + Bp.size] = torch.from_numpy(Bp.view(np.uint8).ravel()).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    g.check(L.gemmul8_lowprec_gemm(st, g.D, g.INT8, m, n, k, N, 0, N, C.byref(Lo)))
+    torch.cuda.synchronize()
+    got = work[offC:offC + N * Lo.sizeC].cpu().numpy().view(np.int8).reshape(N, Lo.sizeC // Lo.mp, Lo.mp)[:, :n, :m]
+    moduli = [256, 255, 253, 251, 247, 241, 239, 233, 229, 227, 223, 217, 211, 199]
+    for t, p in enumerate(moduli):
+        acc = A[t].astype(np.int64) @ B[t].astype(np.int64).T          # (m, n)
+        assert np.abs(acc).max() == k * 127 * 127                      # the bound is reached
+        r = np.mod(acc, p)
+        r = np.where(r > (p - 1) // 2, r - p, r) if p != 256 else ((acc + 128) % 256 - 128)
+        assert np.array_equal(got[t], r.T.astype(np.int8)), (k, p)
+
+
 def test_residue_store_policy_auto_at_size(monkeypatch):
     """8192 x 8192 x 512, 14 moduli: 112 MiB of operand planes and 896 MiB of residues -- the shape class where the library picks
     non-temporal residue stores by itself.  The result must equal the forced default-policy run bit for bit."""

@@ -77,6 +77,29 @@ def test_biased_accumulator_byte_dot_reduction_is_exact(p):
 
 
 @pytest.mark.parametrize("p", [m for m in INT8_MODULI if m & 1])
+def test_short_k_accumulator_reduction_low_byte(p):
+    """INT8 GEMM epilogue for K <= 512 (oz2_gemm_i8.hip RED_ODD_SMALL): |x| <= 512 * 127^2 < 2^23; the quotient is read from the low 24
+    bits of fma(float(x), RN(1/p), 1.5 * 2^23) (= 2^22 + q for either sign of q) and v_mad_i32_i24 returns x - (2^22 + q) p, whose LOW
+    BYTE is the canonical residue's -- the only byte the epilogue stores.  EXHAUSTIVE over |x| <= 2^23; beyond that bound the single
+    quotient is no longer safe (|x| |RN(1/p) - 1/p| reaches 1/(2p)): the test also pins where the first wrong byte appears."""
+    def low_bytes(x):
+        invp = np.float32(1.0) / np.float32(p)
+        prod = x.astype(np.float32).astype(np.float64) * np.float64(invp)
+        qf = (prod + np.float64(12582912.0)).astype(np.float32)      # one rounding at unit spacing (the float64 sum is off by < 2^-28)
+        low24 = qf.view(np.uint32).astype(np.int64) & 0xFFFFFF
+        assert np.array_equal(low24, (1 << 22) + (qf.astype(np.int64) - 12582912))
+        return (x - low24 * p) & 0xFF
+    lim = 1 << 23
+    x = np.arange(-lim, lim + 1, dtype=np.int64)
+    assert np.array_equal(low_bytes(x), sym_exact(x, p) & 0xFF)
+    assert 512 * 127 * 127 < lim
+    if p == 255:   # the kernel's K bound is not slack: the form fails a little above 2^23
+        y = np.arange(lim, 2 * lim, dtype=np.int64)
+        bad = np.nonzero(low_bytes(y) != (sym_exact(y, p) & 0xFF))[0]
+        assert len(bad) and y[bad[0]] == 8454907
+
+
+@pytest.mark.parametrize("p", [m for m in INT8_MODULI if m & 1])
 def test_one_step_small(p):
     a = np.arange(-65535, 65536, dtype=np.int64)
     invp = np.float32(1.0) / np.float32(p)
