@@ -77,6 +77,16 @@ def test_biased_accumulator_byte_dot_reduction_is_exact(p):
 
 
 @pytest.mark.parametrize("p", [m for m in INT8_MODULI if m & 1])
+def test_mod_small_sym_u_exhaustive(p):
+    """oz2_device.hpp mod_small_sym_u over its whole documented domain 0 <= s < 2^22 (the epilogue's byte-dot sums stay below 2^18)."""
+    s_ = np.arange(0, 1 << 22, dtype=np.int64)
+    invp = np.float32(1.0) / np.float32(p)
+    qf = (s_.astype(np.float32).astype(np.float64) * np.float64(invp) + np.float64(8388608.0)).astype(np.float32)
+    q = qf.view(np.uint32).astype(np.int64) & 0xFFFFFF
+    assert np.array_equal(s_ - q * p, sym_exact(s_, p))
+
+
+@pytest.mark.parametrize("p", [m for m in INT8_MODULI if m & 1])
 def test_short_k_accumulator_reduction_low_byte(p):
     """INT8 GEMM epilogue for K <= 512 (oz2_gemm_i8.hip RED_ODD_SMALL): |x| <= 512 * 127^2 < 2^23; the quotient is read from the low 24
     bits of fma(float(x), RN(1/p), 1.5 * 2^23) (= 2^22 + q for either sign of q) and v_mad_i32_i24 returns x - (2^22 + q) p, whose LOW
