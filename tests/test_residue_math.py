@@ -327,3 +327,22 @@ def test_float_domain_two_level_residue(moduli, big):
                     assert abs(r) <= (p - 1) // 2, (x, p, r)          # the canonical symmetric representative
                 else:
                     assert abs(r) <= p // 2, (x, p, r)                # p = 256: +-128 is the same int8 byte; p = 1024: -512 is mapped to +512
+
+
+@pytest.mark.parametrize("moduli", [INT8_MODULI, FP8_MODULI])
+def test_level2_quotient_exhaustive(moduli):
+    """Level 2 of the float-domain residue (oz2_scale.hip residue_from_small) EXHAUSTIVELY over |R| <= 2^20, which contains every
+    level-1 remainder (|R| <= P/2 + 2, P = product of two moduli <= 1089 * 1024): vectorised form of _level2."""
+    R = np.arange(-(1 << 20), (1 << 20) + 1, dtype=np.int64)
+    Rf = R.astype(np.float32).astype(np.float64)                     # |R| < 2^24: exact
+    for p in moduli:
+        invp = np.float32(1.0) / np.float32(p)
+        qf = (Rf * np.float64(invp) + np.float64(12582912.0)).astype(np.float32)   # float64 sum off by < 2^-29: far inside the margin to a tie
+        low24 = qf.view(np.uint32).astype(np.int64) & 0xFFFFFF
+        r = R - low24 * p + (p << 22)
+        assert np.all((r - R) % p == 0), p
+        if p & 1:
+            assert np.array_equal(r, sym_exact(R, p)), p
+        else:
+            assert np.all(np.abs(r) <= p // 2), p
+
