@@ -69,6 +69,29 @@ def test_bad_arguments():
 
 
 @pytest.mark.parametrize("dt", ["d", "s", "z", "c"])
+def test_rule_on_a_second_box(dt):
+    """Cross-validation: the same scan repeated on ANOTHER MI355X box with the final round-3 binaries (r03_floor_scan2_*.csv; the model was
+    fitted to r03_floor_scan_*.csv).  The rule must hold up on data it was not fitted to: summed time within 15 % of always picking the
+    faster routine, far below always-native, no emulated call slower than 1.4x native (the one outlier: SGEMM 1024^2 x 16384 with 5
+    moduli, where the native routine ran 127 instead of 108 TFLOPS on this box)."""
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "sweeps", f"r03_floor_scan2_{dt}.csv"))))
+    assert len(rows) >= 150
+    t_rule = t_best = t_native = 0.0
+    worst = 0.0
+    for r in rows:
+        te, tn = float(r["emulated_ms"]), float(r["native_ms"])
+        em = would(dt, int(r["m"]), int(r["n"]), int(r["k"]), int(r["N"]), int(r["fast"]))
+        t_rule += te if em else tn
+        t_best += min(te, tn)
+        t_native += tn
+        if em:
+            worst = max(worst, te / tn)
+    assert worst <= 1.40, worst
+    assert t_rule <= 1.15 * t_best, (t_rule, t_best)
+    assert t_rule <= 0.90 * t_native, (t_rule, t_native)
+
+
+@pytest.mark.parametrize("dt", ["d", "s", "z", "c"])
 def test_rule_against_the_measurements(dt):
     """On every measured shape the rule emulates, the emulation must not have lost by more than a few per cent (one known outlier:
     SGEMM 1024^2 x 16384 with 5 moduli, 1.19x); and the rule must keep most of the time the better choice would have saved."""
