@@ -455,6 +455,50 @@ def test_epilogue_reduction_on_extreme_accumulators(k):
         assert np.array_equal(got[t], r.T.astype(np.int8)), (k, p)
 
 
+@pytest.mark.parametrize("kernel", ["dma", "reg"])
+@pytest.mark.parametrize("dtype,N", [(np.float64, 14), (np.float64, 20), (np.float32, 7), (np.complex128, 16)])
+def test_crt_on_extreme_residues(dtype, N, kernel, monkeypatch):
+    """CRT + unscale + axpby on residue planes AT the ends of their ranges (all +-(p-1)/2, alternating by plane, zeros, +-1), fed straight
+    to gemmul8_crt and compared bit for bit with the oracle's inverse scaling (inverse_scaling_real.hpp:8-89): the reduction mod P
+    next to its rounding boundaries, which random products never produce.  Both kernels (LDS-DMA slices / register form)."""
+    import ctypes as C
+    import gemmul8_amd as g
+    import oracle_lib as ol
+    monkeypatch.setenv("GEMMUL8_CRT_KERNEL", kernel)
+    cplx = np.dtype(dtype).kind == "c"
+    comps = 2 if cplx else 1
+    m, n = (512 if cplx else 1024), 24
+    moduli = [256, 255, 253, 251, 247, 241, 239, 233, 229, 227, 223, 217, 211, 199, 197, 193, 191, 181, 179, 173][:N]
+    rng = np.random.default_rng(N)
+    Cm = np.zeros((N, n, m, comps), np.int8)
+    for t, p in enumerate(moduli):
+        hi = 127 if p == 256 else (p - 1) // 2
+        lo = -128 if p == 256 else -hi
+        pool = np.array([hi, lo, hi - 1, lo + 1, 0, 1, -1], dtype=np.int64)
+        Cm[t] = rng.choice(pool, size=(n, m, comps)).astype(np.int8)
+        Cm[t, 0] = hi                                   # column 0: every plane at its maximum
+        Cm[t, 1] = lo                                   # column 1: every plane at its minimum
+        Cm[t, 2] = hi if t % 2 == 0 else lo             # column 2: alternating
+        Cm[t, 3] = 0
+    Cm[0, 3] = 1                                        # column 3: the value 1 in the first plane only
+    sftA = rng.integers(-70, 70, size=m).astype(np.int16)
+    sftB = rng.integers(-70, 70, size=n).astype(np.int16)
+    code = g._dtype_code(torch.from_numpy(np.zeros(1, dtype)).dtype)
+    for alpha, beta in [(1.0, 0.0), (-1.0, 1.0), (0.75, -0.5)]:
+        al, be = np.array([alpha], dtype), np.array([beta], dtype)
+        C0 = rand((n, m), dtype, rng, phi=0.0)          # column-major m x n as (n, m)
+        want = C0.copy()
+        ol.lib().oz2_invscal(code, ol.INT8, N, m, n, ol._p(Cm), ol._p(sftA), ol._p(sftB), ol._p(al), ol._p(be), ol._p(want), m, 0)
+        dC = torch.from_numpy(C0.copy()).cuda()
+        dM = torch.from_numpy(Cm.copy()).cuda()
+        dA, dB = torch.from_numpy(sftA).cuda(), torch.from_numpy(sftB).cuda()
+        g.check(g.lib().gemmul8_crt(torch.cuda.current_stream().cuda_stream, code, g.INT8, N, m, n, dM.data_ptr(), m, n * m, dA.data_ptr(),
+                                    dB.data_ptr(), al.ctypes.data, be.ctypes.data, dC.data_ptr(), m))
+        torch.cuda.synchronize()
+        got = dC.cpu().numpy()
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (dtype, N, kernel, alpha, beta)
+
+
 def test_residue_store_policy_auto_at_size(monkeypatch):
     """8192 x 8192 x 512, 14 moduli: 112 MiB of operand planes and 896 MiB of residues -- the shape class where the library picks
     non-temporal residue stores by itself.  The result must equal the forced default-policy run bit for bit."""
