@@ -499,6 +499,35 @@ def test_crt_on_extreme_residues(dtype, N, kernel, monkeypatch):
         assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (dtype, N, kernel, alpha, beta)
 
 
+@pytest.mark.parametrize("fast", [False, True])
+@pytest.mark.parametrize("k", [512, 1024, 3000])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32, np.complex128])
+def test_parity_constant_and_sign_pattern_matrices(dtype, k, fast):
+    """Operands whose scaled integers repeat along k (constant rows, +-1 checkerboards, one huge entry): every product of a dot product
+    has the same residues, so the INT32 sums reach k * r_a * r_b -- the largest accumulators the whole pipeline can produce -- and the
+    bound GEMM's sums reach the value the shift formula is designed around.  Whole pipeline against the oracle, bit for bit."""
+    import gpu_util as gu
+    rng = np.random.default_rng(k)
+    m, n = 70, 66
+    A = np.ones((m, k), dtype)
+    B = np.ones((k, n), dtype)
+    A[1] = -1.0
+    A[2, ::2] = -1.0
+    A[3] = 0.999999                       # scaled integer just below a power of two
+    A[4] = 1.000001
+    A[5] = rng.choice([-1.0, 1.0], size=k)
+    A[6, 0] = 1e6                         # one dominant entry in the row
+    B[:, 1] = -1.0
+    B[::2, 2] = -1.0
+    B[:, 3] = 3.0
+    B[:, 4] = 1.0 / 3.0
+    if np.dtype(dtype).kind == "c":
+        A = A + 1j * np.roll(A, 1, axis=0)
+        B = B - 1j * np.roll(B, 1, axis=1)
+    N = 7 if dtype == np.float32 else 14
+    gu.parity_case(A.astype(dtype), B.astype(dtype), N, fast)
+
+
 def test_residue_store_policy_auto_at_size(monkeypatch):
     """8192 x 8192 x 512, 14 moduli: 112 MiB of operand planes and 896 MiB of residues -- the shape class where the library picks
     non-temporal residue stores by itself.  The result must equal the forced default-policy run bit for bit."""
