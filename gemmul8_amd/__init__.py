@@ -34,7 +34,7 @@ _lib = None
 
 EXPORTS = ["gemmul8_version", "gemmul8_work_size", "gemmul8_gemm", "gemmul8_get_layout", "gemmul8_scale",
            "gemmul8_scale_bounds", "gemmul8_scale_finish", "gemmul8_lowprec_gemm", "gemmul8_crt", "gemmul8_set_fp8_bound_mode",
-           "gemmul8_hook_would_emulate"]
+           "gemmul8_hook_would_emulate", "gemmul8_reload_knobs"]
 
 
 def _bind_hip_runtime():
@@ -65,7 +65,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} not found: the HIP extension is not built (python -c 'import __graft_entry__ as g; g.build()')")
     _bind_hip_runtime()
-    L = C.CDLL(LIB_PATH)
+    _lib = bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def bind(L):
+    """Declare the C-ABI signatures (include/gemmul8_c.h) on a loaded library object: libgemmul8.so, or a laboratory build of it
+    (tools/build_probes.sh, tools/experiments/) that a measurement script wants to drive through the same helpers."""
     L.gemmul8_version.restype = C.c_char_p
     L.gemmul8_work_size.restype = C.c_size_t
     L.gemmul8_work_size.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.c_int, C.c_int,
@@ -96,11 +102,6 @@ def lib():
     L.gemmul8_crt.restype = C.c_int
     L.gemmul8_crt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                               C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
-    L.gemmul8_lowprec_gemm_crt.restype = C.c_int
-    L.gemmul8_lowprec_gemm_crt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.POINTER(Layout),
-                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
-    L.gemmul8_fused_crt_selected.restype = C.c_int
-    L.gemmul8_fused_crt_selected.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_uint]
     L.gemmul8_work_size_batched.restype = C.c_size_t
     L.gemmul8_work_size_batched.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.c_size_t]
     L.gemmul8_batched_item_bytes.restype = C.c_size_t
@@ -113,9 +114,10 @@ def lib():
     L.gemmul8_set_fp8_bound_mode.argtypes = [C.c_int]
     L.gemmul8_hook_would_emulate.restype = C.c_int
     L.gemmul8_hook_would_emulate.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.c_int, C.c_size_t]
+    L.gemmul8_reload_knobs.restype = None
+    L.gemmul8_reload_knobs.argtypes = []
     L.gemmul8_add_row_bias.restype = C.c_int
     L.gemmul8_add_row_bias.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
-    _lib = L
     return L
 
 

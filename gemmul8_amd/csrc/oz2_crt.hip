@@ -24,6 +24,7 @@
 
 #include "oz2_crt_common.hpp"
 #include "oz2_kernels.h"
+#include "oz2_knobs.hpp"
 
 namespace oz2 {
 
@@ -667,12 +668,12 @@ hipError_t launch_crt(hipStream_t stream, int dtype, int backend, unsigned N, si
     {
         // LDS-DMA form: int8 residues, whole 1024-byte units per column, 16-byte aligned slices and C columns
         const size_t comps = cplx ? 2 : 1, usz = is_f32(dtype) ? 4 : 8;
-        const char* force = getenv("GEMMUL8_CRT_KERNEL");  // "dma" | "reg": testing switch (default: dma when eligible and large enough)
+        const int force = knobs().crt_kernel;  // 1 = dma, 2 = reg: testing switch (default: dma when eligible and large enough)
         const bool eligible = OZ2_CRT_DMA && i8 && (m * comps) % 1024 == 0 && (ld_mid * comps) % 16 == 0 && (plane_stride * comps) % 16 == 0 &&
-                              ((uintptr_t)Cmid & 15u) == 0 && ((uintptr_t)C & 15u) == 0 && (ldc * comps * usz) % 16 == 0 && (g_batch.ws & 15u) == 0 &&
+                              ((uintptr_t)Cmid & 15u) == 0 && ((uintptr_t)C & 15u) == 0 && ((uintptr_t)sftA & 3u) == 0 /* dword loads of two int16 shifts */ && (ldc * comps * usz) % 16 == 0 && (g_batch.ws & 15u) == 0 &&
                               (g_batch.sc & 15u) == 0;
         const size_t units = m * comps / 1024 * n;
-        const bool want = force && force[0] == 'd' ? true : force && force[0] == 'r' ? false : units >= 4096;
+        const bool want = force == 1 ? true : force == 2 ? false : units >= 4096;
         if (eligible && want && units <= 0x7FFFFFFFull) {
             const unsigned upc = (unsigned)(m * comps / 1024);
             const size_t lds = (size_t)N * 1024;

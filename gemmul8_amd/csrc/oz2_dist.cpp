@@ -157,10 +157,12 @@ bool recv_all(int fd, void* p, size_t n) {
     return true;
 }
 
-// Rank 0 listens on MASTER_ADDR only (not INADDR_ANY), every client introduces itself with a 16-byte hello {magic, rank, world,
-// nonce = MASTER_PORT} before it is handed the id, each rank is served once, and every accept / recv has a deadline: a stray
-// connection (port scanner, another job's retry) is dropped instead of starving a real rank, and a missing rank ends in an error
-// message after GEMMUL8_DIST_TIMEOUT seconds (default 120) instead of a silent hang inside ncclCommInitRank.
+// Rank 0 listens on all interfaces (as torch's TCPStore does: MASTER_ADDR may be a service / NAT address the host does not own, or
+// resolve to 127.0.1.1 on rank 0 itself; if that bind fails it falls back to the address MASTER_ADDR resolves to).  Every client
+// introduces itself with a 16-byte hello {magic, rank, world, nonce = MASTER_PORT} before it is handed the id, which filters stray
+// connections (port scanner, another job's retry); a rank that asks again is served again (handing out the id is idempotent: its
+// first reply may have been lost to its 5 s receive timeout), and every accept / recv has a deadline: a missing rank ends in an
+// error message after GEMMUL8_DIST_TIMEOUT seconds (default 120) instead of a silent hang inside ncclCommInitRank.
 struct IdHello {
     uint32_t magic, rank, world, nonce;
 };
@@ -193,7 +195,13 @@ int exchange_id_tcp(const char* addr, int port, int rank, int world, uint32_t no
         int ls = ::socket(AF_INET, SOCK_STREAM, 0);
         int one = 1;
         if (ls >= 0) setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
-        if (ls < 0 || ::bind(ls, res->ai_addr, res->ai_addrlen) != 0 || ::listen(ls, world) != 0) {
+        sockaddr_in any{};
+        any.sin_family = AF_INET;
+        any.sin_addr.s_addr = htonl(INADDR_ANY);
+        any.sin_port = htons((uint16_t)port);
+        const bool bound = ls >= 0 && (::bind(ls, reinterpret_cast<const sockaddr*>(&any), sizeof any) == 0 ||
+                                       ::bind(ls, res->ai_addr, res->ai_addrlen) == 0);
+        if (!bound || ::listen(ls, world) != 0) {
             std::fprintf(stderr, "[GEMMUL8 DIST] cannot listen on %s:%d\n", addr, port);
             if (ls >= 0) ::close(ls);
             freeaddrinfo(res);
@@ -212,7 +220,7 @@ int exchange_id_tcp(const char* addr, int port, int rank, int world, uint32_t no
             set_io_timeout(fd, 5);
             IdHello h{};
             if (recv_all(fd, &h, sizeof h) && h.magic == kHelloMagic && h.world == (uint32_t)world && h.nonce == nonce && h.rank >= 1 &&
-                h.rank < (uint32_t)world && !served[h.rank] && send_all(fd, id, sizeof *id)) {
+                h.rank < (uint32_t)world && send_all(fd, id, sizeof *id) && !served[h.rank]) {
                 served[h.rank] = 1;
                 --left;
             }

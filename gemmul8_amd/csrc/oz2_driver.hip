@@ -15,8 +15,12 @@
 
 #include <algorithm>
 
+#include <atomic>
+#include <mutex>
+
 #include "../../include/gemmul8_c.h"
 #include "oz2_kernels.h"
+#include "oz2_knobs.hpp"
 
 using namespace oz2;
 
@@ -64,7 +68,44 @@ Timer* thread_timer() {
 
 static bool scalars_on_device(const void* alpha);
 
+// ---- testing / A-B knobs (oz2_knobs.hpp): parsed once; gemmul8_reload_knobs publishes a fresh snapshot (old snapshots are kept: a
+// launch in another thread may still be reading one -- a handful of tiny structs per process at most)
+namespace oz2 {
+static Knobs parse_knobs() {
+    Knobs k;
+    auto num = [](const char* name, int dflt) {
+        const char* s = getenv(name);
+        return s && *s ? atoi(s) : dflt;
+    };
+    if (const char* e = getenv("GEMMUL8_EPI_NT"); e && (e[0] == '0' || e[0] == '1') && !e[1]) k.epi_nt = e[0] - '0';
+    if (const int t = num("GEMMUL8_BOUND_TILE", 0); t == 128 || t == 256) k.bound_tile = t;
+    if (num("GEMMUL8_CPLX_BOUND_LAUNCHES", 1) == 2) k.cplx_bound_launches = 2;
+    if (const int c = num("GEMMUL8_CPLX_CHUNK", 0); c >= 1) k.cplx_chunk = c;
+    if (const char* e = getenv("GEMMUL8_CRT_KERNEL")) k.crt_kernel = e[0] == 'd' ? 1 : e[0] == 'r' ? 2 : 0;
+    if (const char* e = getenv("GEMMUL8_MAP_COLBLOCK"); e && *e) k.map_colblock = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = getenv("GEMMUL8_SHORTK"); e && (e[0] == '0' || e[0] == '1') && !e[1]) k.short_k = e[0] - '0';
+    return k;
+}
+static std::atomic<const Knobs*> g_knobs{nullptr};
+static std::mutex g_knobs_mtx;
+void reload_knobs() {
+    std::lock_guard<std::mutex> lk(g_knobs_mtx);
+    g_knobs.store(new Knobs(parse_knobs()), std::memory_order_release);
+}
+const Knobs& knobs() {
+    const Knobs* k = g_knobs.load(std::memory_order_acquire);
+    if (!k) {
+        std::lock_guard<std::mutex> lk(g_knobs_mtx);
+        k = g_knobs.load(std::memory_order_acquire);
+        if (!k) g_knobs.store(k = new Knobs(parse_knobs()), std::memory_order_release);
+    }
+    return *k;
+}
+}  // namespace oz2
+
 extern "C" {
+
+void gemmul8_reload_knobs(void) { oz2::reload_knobs(); }
 
 int gemmul8_set_fp8_bound_mode(int mode) {
     if (mode != 0 && mode != 1) return GEMMUL8_E_ARG;
@@ -73,7 +114,7 @@ int gemmul8_set_fp8_bound_mode(int mode) {
     return old;
 }
 
-const char* gemmul8_version(void) { return "gemmul8-mi355x 0.3 (gfx950; v_mfma_i32_16x16x64_i8 / v_mfma_scale_f32_16x16x128_f8f6f4, fused epilogues)"; }
+const char* gemmul8_version(void) { return "gemmul8-mi355x 0.4 (gfx950; v_mfma_i32_16x16x64_i8 / v_mfma_scale_f32_16x16x128_f8f6f4, fused epilogues)"; }
 
 size_t gemmul8_work_size(int is_complex, int backend, size_t m, size_t n, size_t k, unsigned N, int enA, int enB, size_t* wA,
                          size_t* wB) {
@@ -207,8 +248,7 @@ int gemmul8_scale_bounds(void* stream_, int dtype, int backend, int op_A, int op
             const int8_t* As[3] = {Ab, Ab + L->sizeA, Ab + 2 * L->sizeA};
             const int8_t* Bs[3] = {Bb + L->sizeB, Bb, Bb + 2 * L->sizeB};
             //   One launch over the three segments; the maxima are taken after the second (C1) and after the third (C1 + C0).
-            const char* bl = getenv("GEMMUL8_CPLX_BOUND_LAUNCHES");  // A/B and testing switch, read per call
-            const bool two_launches = bl && bl[0] == '2';
+            const bool two_launches = knobs().cplx_bound_launches == 2;  // A/B and testing switch (oz2_knobs.hpp)
             if (two_launches) {
                 OZ2_HIP(launch_gemm_i8_max(stream, 2, As, Bs, L->kp, m, col_end - col_begin, rowmax, colmax + col_begin));
                 OZ2_HIP(launch_gemm_i8_max(stream, 3, As, Bs, L->kp, m, col_end - col_begin, rowmax, colmax + col_begin));
@@ -328,10 +368,7 @@ int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t
     const size_t per_mod = 2 * L->sizeC;
     size_t chunk = L->scratch_bytes / per_mod;
     if (chunk == 0) return GEMMUL8_E_ARG;
-    if (const char* cs = getenv("GEMMUL8_CPLX_CHUNK")) {  // experiment switch: moduli per X / Y / Z launch group
-        const size_t want = (size_t)atoi(cs);
-        if (want >= 1 && want < chunk) chunk = want;
-    }
+    if (const size_t want = (size_t)knobs().cplx_chunk; want >= 1 && want < chunk) chunk = want;  // A/B switch (oz2_knobs.hpp)
     int8_t* rx = (int8_t*)L->scratch;
     for (unsigned t0 = t_begin; t0 < t_end; t0 += (unsigned)chunk) {
         const unsigned t1 = std::min<unsigned>(t_end, t0 + (unsigned)chunk);
@@ -344,28 +381,6 @@ int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t
                                     B_lo + 2 * L->part_strideB + (size_t)t0 * L->sizeB, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1, rx,
                                     ry, L->sizeC, (int8_t*)L->C_mid + (size_t)t0 * 2 * L->sizeC, L->mp, 2 * L->sizeC));
     }
-    return GEMMUL8_OK;
-}
-
-int gemmul8_fused_crt_selected(int dtype, int backend, size_t m, size_t n, unsigned N) {
-    if (backend != kINT8 || dtype < 0 || dtype > 3 || is_complex(dtype) || N < 2 || N > 20) return 0;
-    const char* s = getenv("GEMMUL8_FUSED_CRT");
-    if (s && (s[0] == '1' || s[0] == '2')) return s[0] - '0';          // whenever it is legal (2: the consumer-tail variant)
-    if (s && s[0] == 'a') return gemm_i8_crt_fusable(m, n, N) ? 1 : 0;  // "auto": when the tiles of one plane fill the chip
-    return 0;  // default off: measured slower than the two-launch path
-}
-
-int gemmul8_lowprec_gemm_crt(void* stream_, int dtype, int backend, size_t m, size_t n, size_t k, unsigned N, const gemmul8_layout* L,
-                             const void* alpha, const void* beta, void* C, size_t ldc) {
-    (void)k;
-    if (!L || !alpha || !beta || !C) return GEMMUL8_E_ARG;
-    if (dtype < 0 || dtype > 3 || backend < 0 || backend > 1) return GEMMUL8_E_ARG;
-    if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
-    if (backend != kINT8 || is_complex(dtype)) return GEMMUL8_E_UNSUPPORTED;
-    const char* env_fused = getenv("GEMMUL8_FUSED_CRT");
-    OZ2_HIP(launch_gemm_i8_mod_crt((hipStream_t)stream_, dtype, (const int8_t*)L->A_lo, (const int8_t*)L->B_lo, L->sizeA, L->sizeB, L->kp, m, n, N,
-                                   (int8_t*)L->C_mid, L->mp, L->sizeC, L->sftA, L->sftB, alpha, beta, scalars_on_device(alpha), C, ldc,
-                                   (env_fused && env_fused[0] == '2') ? 2 : 1));
     return GEMMUL8_OK;
 }
 
@@ -431,18 +446,11 @@ int gemmul8_gemm(void* stream_, int dtype, int backend, int op_A, int op_B, size
     rc = gemmul8_scale(stream, dtype, backend, op_A, op_B, m, n, k, A, lda, B, ldb, N, fastmode, 0, N, &L, skipA, skipB);
     if (rc) return rc;
     if (T) OZ2_HIP(hipEventRecord(T->ev[1], stream));
-    if (gemmul8_fused_crt_selected(dtype, backend, m, n, N)) {
-        // one launch for the residue GEMMs and the CRT (timer slot 1 then covers both, slot 3 stays ~0)
-        rc = gemmul8_lowprec_gemm_crt(stream, dtype, backend, m, n, k, N, &L, alpha, beta, C, ldc);
-        if (rc) return rc;
-        if (T) OZ2_HIP(hipEventRecord(T->ev[2], stream));
-    } else {
-        rc = gemmul8_lowprec_gemm(stream, dtype, backend, m, n, k, N, 0, N, &L);
-        if (rc) return rc;
-        if (T) OZ2_HIP(hipEventRecord(T->ev[2], stream));
-        rc = gemmul8_crt(stream, dtype, backend, N, m, n, L.C_mid, L.mp, L.sizeC, L.sftA, L.sftB, alpha, beta, C, ldc);
-        if (rc) return rc;
-    }
+    rc = gemmul8_lowprec_gemm(stream, dtype, backend, m, n, k, N, 0, N, &L);
+    if (rc) return rc;
+    if (T) OZ2_HIP(hipEventRecord(T->ev[2], stream));
+    rc = gemmul8_crt(stream, dtype, backend, N, m, n, L.C_mid, L.mp, L.sizeC, L.sftA, L.sftB, alpha, beta, C, ldc);
+    if (rc) return rc;
     if (T) {
         OZ2_HIP(hipEventRecord(T->ev[3], stream));
         OZ2_HIP(hipEventSynchronize(T->ev[3]));

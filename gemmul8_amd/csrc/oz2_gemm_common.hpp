@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "oz2_knobs.hpp"
+
 namespace oz2 {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -35,10 +37,8 @@ struct TileMap {
 // (6 planes 16384^2 x 16384: 19.19 -> 18.32 ms, 12288^2 x 16384: 10.47 -> 10.24; profiles/r03_map_colblock_ab.txt).
 inline int map_colblock(size_t tiles_n, size_t kbytes) {
     if (!OZ2_MAP_COLBLOCK) return 0;
-    if (const char* e = getenv("GEMMUL8_MAP_COLBLOCK")) {  // experiment / testing switch: tile-columns per block, 0 = full width
-        const int w = atoi(e);
+    if (const int w = knobs().map_colblock; w >= 0)  // testing switch (oz2_knobs.hpp): tile-columns per block, 0 = full width
         return w > 0 && (size_t)w < tiles_n ? w : 0;
-    }
     const size_t panel = (size_t)BN * kbytes;
     if (tiles_n * panel <= ((size_t)160 << 20)) return 0;
     size_t w = (((size_t)128 << 20) / panel) & ~(size_t)3;

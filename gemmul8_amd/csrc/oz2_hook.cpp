@@ -13,8 +13,9 @@
 //       pre-sizing applied when a SKIP_SCALE switch is on                      hook.cu:232-281,656-662
 //   early outs: m|n|k <= 0 -> SUCCESS, null A/B/C -> INVALID_VALUE            hook.cu:616-617
 //   GEMMUL8_DIST (this build only)  blocks | moduli | fp64sum: shard every emulated GEMM over the ranks of an SPMD job (see try_dist)
-//   GEMMUL8_MIN_FLOPS (this build only) calls with 2*m*n*k below it use the native routine; 0 = emulate every call (the reference's
-//                     behaviour); UNSET = automatic: a fitted cost model decides per call whether the emulation wins (below_floor)
+//   GEMMUL8_MIN_FLOPS (this build only) UNSET or 0 = emulate every selected call (the reference's behaviour, hook.cu:600-660);
+//                     "auto" = a fitted cost model decides per call whether the emulation wins (below_floor); a number = calls with
+//                     2*m*n*k below it use the native routine.  The first call a floor hands to the native routine is logged once.
 //   per-handle state under a mutex: three grow-only stream-ordered buffers (hipMallocAsync /
 //   hipFreeAsync), event hand-off when the handle's stream changes, skip-scaling cache
 //   (hook.cu:70-162,331-374,684-727); hipblasDestroy frees the state first (hook.cu:846-856).
@@ -405,8 +406,9 @@ bool try_dist(int kind, int dtype, int backend, hipblasOperation_t ta, hipblasOp
 // latency-bound launches (1024^3: 21 vs 48 TFLOPS native), and what a hooked solver issues most -- trailing updates with large m = n
 // and small k, panel products with one small dimension -- pays the per-output cost of the scheme (N bytes of residues written, read
 // and recombined per element) without the k to amortise it (DGEMM 8192^2 x 256: 45 vs 65 TFLOPS native; x 512: 71 vs 69; x 1024:
-// 107 vs 70).  With the variable UNSET the hook therefore evaluates a fitted cost model per call and emulates only where the
-// emulation is predicted to win:
+// 107 vs 70).  With GEMMUL8_MIN_FLOPS=auto the hook therefore evaluates a fitted cost model per call and emulates only where the
+// emulation is predicted to win (opt-in: the numerics of a call then depend on its shape, and the constants were fitted on one
+// MI355X pool -- the default stays the reference's: every selected call is emulated):
 //     emulated  t_e = c0 + (a1 + b1 N)(m + n) k + (a2 + b2 N) m n + b3 N m n k      per (type, accurate / fast), N = number of moduli
 //     native    t_n = d0 + d2 m n + d3 m n k                                        per type (the library at its normal rate)
 //     emulate   iff t_e <= 0.95 t_n        (a strided batch: one set of launches, so c0 / d0 once and the rest times the batch)
@@ -416,7 +418,7 @@ bool try_dist(int kind, int dtype, int backend, hipblasOperation_t ta, hipblasOp
 // within 0.3-10 % of always picking the faster of the two (always-native: +25-45 %); repeated on a second box with the final binaries
 // (r03_floor_scan2_*.csv, not used for the fit) it stays within 0.4-12 % (tests/test_hook_floor.py).  The FP8 backend costs ~2.2x
 // the INT8 one.
-// GEMMUL8_MIN_FLOPS=0 restores the reference's behaviour (emulate every call); any other value is a plain floor on 2*m*n*k per call.
+// GEMMUL8_MIN_FLOPS unset / 0 = the reference's behaviour (emulate every call); any other number is a plain floor on 2*m*n*k per call.
 struct FloorModel {
     double e[6];  // ms: 1, (m+n)k, N(m+n)k, mn, N mn, N mnk
     double n[3];  // ms: 1, mn, mnk
@@ -428,18 +430,35 @@ static const FloorModel kFloor[4][2] = {  // [S, D, C, Z][accurate, fast]
     {{{0.09541, 7.142e-09, 1.221e-09, 2.907e-09, 2.514e-09, 1.793e-12}, {0.01247, 3.124e-10, 5.502e-11}}, {{0.06607, 3.724e-09, 1.237e-09, 1.175e-09, 2.57e-09, 1.612e-12}, {0.01247, 3.124e-10, 5.502e-11}}},
     {{{0.1111, 1.222e-08, 1.376e-09, 7.487e-10, 2.956e-09, 1.689e-12}, {0.00809, 2.584e-10, 1.076e-10}}, {{0.07812, 7.692e-09, 1.346e-09, 4.235e-11, 3.05e-09, 1.503e-12}, {0.00809, 2.584e-10, 1.076e-10}}},
 };
-bool below_floor(int dtype, double m, double n, double k, unsigned N, bool fast, int backend, double batch = 1.0) {
-    const char* s = std::getenv("GEMMUL8_MIN_FLOPS");
-    if (s && *s) {
-        const unsigned long long f = env_u64("GEMMUL8_MIN_FLOPS", 0);
-        return f && 2.0 * m * n * k < (double)f;
-    }
+static bool floor_model_declines(int dtype, double m, double n, double k, unsigned N, bool fast, int backend, double batch) {
     const FloorModel& fm = kFloor[dtype][fast ? 1 : 0];
     const double mk = (m + n) * k, mn = m * n, mnk = mn * k, Nd = (double)N;
     double te = fm.e[0] + batch * ((fm.e[1] + fm.e[2] * Nd) * mk + (fm.e[3] + fm.e[4] * Nd) * mn + fm.e[5] * Nd * mnk);
     if (backend == GEMMUL8_FP8) te *= 2.2;
     const double tn = fm.n[0] + batch * (fm.n[1] * mn + fm.n[2] * mnk);
     return te > 0.95 * tn;
+}
+// quiet = a query (gemmul8_hook_would_emulate), not a call: no log line
+bool below_floor(int dtype, double m, double n, double k, unsigned N, bool fast, int backend, double batch = 1.0, bool quiet = false) {
+    const char* s = std::getenv("GEMMUL8_MIN_FLOPS");
+    if (!s || !*s) return false;  // the reference's behaviour: every selected call is emulated
+    bool declined;
+    const bool automatic = (s[0] == 'a' || s[0] == 'A');
+    if (automatic) {
+        declined = floor_model_declines(dtype, m, n, k, N, fast, backend, batch);
+    } else {
+        const unsigned long long f = env_u64("GEMMUL8_MIN_FLOPS", 0);
+        declined = f && 2.0 * m * n * k < (double)f;
+    }
+    if (declined && !quiet) {
+        static std::once_flag told;
+        std::call_once(told, [&] {
+            std::fprintf(stderr, "[GEMMUL8 HOOK] GEMMUL8_MIN_FLOPS=%s: a %cGEMM %.0f x %.0f x %.0f (batch %.0f, %u moduli%s) stays on the native routine -- "
+                                 "calls below the floor are NOT emulated (this message is printed once)\n",
+                         s, "SDCZ"[dtype], m, n, k, batch, N, backend == GEMMUL8_FP8 ? ", FP8 backend: cost x 2.2" : "");
+        });
+    }
+    return declined;
 }
 
 }  // namespace
@@ -449,7 +468,7 @@ extern "C" GEMMUL8_API int gemmul8_hook_would_emulate(int dtype, int backend, si
         num_moduli > kTypes[dtype].max_moduli)
         return GEMMUL8_E_ARG;
     if (m == 0 || n == 0 || k == 0) return 0;
-    return below_floor(dtype, (double)m, (double)n, (double)k, num_moduli, fastmode != 0, backend, (double)batch) ? 0 : 1;
+    return below_floor(dtype, (double)m, (double)n, (double)k, num_moduli, fastmode != 0, backend, (double)batch, true) ? 0 : 1;
 }
 namespace {
 // explicit_stream: hipblasLtMatmul carries its stream as an argument (a hipblasLt handle has none)
@@ -462,7 +481,6 @@ bool try_emulate(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, hipbl
     const bool fastmode = env_one(ti.fast);
     const bool enA = env_one("GEMMUL8_SKIP_SCALE_A"), enB = env_one("GEMMUL8_SKIP_SCALE_B");
     const int backend = env_backend("GEMMUL8_BACKEND", 0, false);
-    if (below_floor(dtype, m, n, k, N, fastmode, backend)) return false;
     if (backend == GEMMUL8_FP8) {
         // the FP8 backend exists for parity with the reference; on this chip it is dominated: three FP8 GEMMs per modulus at about the
         // INT8 MFMA rate against one INT8 GEMM (profiles/sweeps/*_types_backends.csv: SGEMM 8192^3 133 vs 305 TFLOPS, native 152;
@@ -473,6 +491,7 @@ bool try_emulate(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, hipbl
                                  "accuracy for S/D/C/Z, and the FP8 backend is slower than the native SGEMM / DGEMM; continuing with FP8 as requested\n");
         });
     }
+    if (below_floor(dtype, m, n, k, N, fastmode, backend)) return false;
 
     auto sp = state_of(handle);
     std::lock_guard<std::mutex> lk(sp->mtx);

@@ -35,12 +35,6 @@ inline thread_local BatchCtx g_batch;
 hipError_t launch_gemm_i8_mod(hipStream_t stream, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp, size_t m,
                               size_t n, int t_begin, int t_end, int8_t* out, size_t ldo, size_t strideO, bool stream_out);
                               // stream_out: the planes are read next by the CRT pass only (non-temporal stores allowed, see the definition)
-// tile-stationary variant with the CRT accumulation inside the kernel (real types)
-bool gemm_i8_crt_fusable(size_t m, size_t n, unsigned N);
-hipError_t launch_gemm_i8_mod_crt(hipStream_t stream, int dtype, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp,
-                                  size_t m, size_t n, unsigned N, int8_t* out, size_t ldo, size_t strideO, const int16_t* sftA,
-                                  const int16_t* sftB, const void* alpha, const void* beta, bool scalars_on_device, void* C, size_t ldc,
-                                  int variant);
 hipError_t launch_gemm_i8_cplx(hipStream_t stream, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp, size_t m,
                                size_t n, int t_begin, int t_end, const int8_t* rx, const int8_t* ry, size_t strideR, int8_t* out,
                                size_t ldo, size_t strideO);

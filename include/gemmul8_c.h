@@ -115,16 +115,6 @@ GEMMUL8_API int gemmul8_crt(void *stream, int dtype, int backend, unsigned num_m
                 size_t ld_mid, size_t plane_stride, const int16_t *sftA, const int16_t *sftB, const void *alpha,
                 const void *beta, void *C, size_t ldc);
 
-/* Low-precision GEMMs of ALL moduli + CRT accumulation + inverse scaling + axpby in ONE launch (real types on
- * the INT8 backend): the kernel keeps an output tile, runs its num_moduli residue GEMMs back to back and accumulates the CRT for the
- * tile itself -- the stand-alone pass over C_mid and its launch disappear; results are bit-identical to gemmul8_lowprec_gemm followed
- * by gemmul8_crt (the residue planes still land in L->C_mid).  Returns GEMMUL8_E_UNSUPPORTED for complex types and the FP8 backend.
- * gemmul8_fused_crt_selected: 1 when gemmul8_gemm takes this path for the shape: opt-in with GEMMUL8_FUSED_CRT=1 (whenever legal) or
- * =auto (when the tiles of one plane fill the chip); unset = the two-launch path.  Replaces the loop at src/gemmul8_real.hpp:144-204 as a whole. */
-GEMMUL8_API int gemmul8_lowprec_gemm_crt(void *stream, int dtype, int backend, size_t m, size_t n, size_t k, unsigned num_moduli,
-                             const gemmul8_layout *L, const void *alpha, const void *beta, void *C, size_t ldc);
-GEMMUL8_API int gemmul8_fused_crt_selected(int dtype, int backend, size_t m, size_t n, unsigned num_moduli);
-
 /* A strided batch of GEMMs (same shape, alpha / beta shared; strides in ELEMENTS of the matrix type, as in
  * hipblas{S,D,C,Z}gemmStridedBatched) as ONE set of launches: every kernel of the pipeline takes the item from gridDim.z, the
  * persistent GEMM kernels run over the items' residue planes in one launch.  `work` holds gemmul8_work_size_batched bytes (the items'
@@ -169,6 +159,11 @@ GEMMUL8_API int gemmul8_set_fp8_bound_mode(int mode);
  * the reference, whose hook emulates every call. */
 GEMMUL8_API int gemmul8_hook_would_emulate(int dtype, int backend, size_t m, size_t n, size_t k, unsigned num_moduli, int fastmode,
                                            size_t batch);
+
+/* Testing / A-B knobs (GEMMUL8_EPI_NT, _BOUND_TILE, _CPLX_BOUND_LAUNCHES, _CPLX_CHUNK, _CRT_KERNEL, _MAP_COLBLOCK, _SHORTK; INTEGRATION.md
+ * "Testing switches"): every one selects between bit-identical code paths.  They are parsed from the environment ONCE, at the first
+ * launch; a test harness that changes the environment inside one process calls this afterwards.  No counterpart in the reference. */
+GEMMUL8_API void gemmul8_reload_knobs(void);
 
 /* Library identification (build arch, version) */
 GEMMUL8_API const char *gemmul8_version(void);

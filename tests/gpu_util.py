@@ -11,6 +11,17 @@ NP2T = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64
         np.dtype(np.complex64): torch.complex64, np.dtype(np.complex128): torch.complex128}
 
 
+def setknob(monkeypatch, name, value):
+    """Set (value=None: unset) one of the library's testing knobs for the rest of the test.  The library parses its knobs once
+    (csrc/oz2_knobs.hpp), so the environment change is followed by gemmul8_reload_knobs; tests/conftest.py reloads again after the
+    test, when monkeypatch has restored the environment."""
+    if value is None:
+        monkeypatch.delenv(name, raising=False)
+    else:
+        monkeypatch.setenv(name, str(value))
+    g.lib().gemmul8_reload_knobs()
+
+
 def to_dev(M):
     """numpy (rows x cols) matrix -> column-major device tensor of shape (cols, rows)."""
     return torch.from_numpy(np.ascontiguousarray(M.T)).cuda()

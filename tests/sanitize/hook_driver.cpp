@@ -164,11 +164,16 @@ int main() {
     long nat = mock_native_calls();
     CHECK(hipblasDgemm(h, HIPBLAS_OP_N, HIPBLAS_OP_N, 64, 64, 64, &one, A.data(), 64, B.data(), 64, &zero, C.data(), 64) == HIPBLAS_STATUS_SUCCESS);
     CHECK(mock_native_calls() == nat + 1);
-    unsetenv("GEMMUL8_MIN_FLOPS");  // unset = the automatic floor: a 64^3 call is far below the measured crossover -> native again
+    setenv("GEMMUL8_MIN_FLOPS", "auto", 1);  // the opt-in fitted cost model: a 64^3 call is far below the measured crossover -> native again
     nat = mock_native_calls();
     CHECK(hipblasDgemm(h, HIPBLAS_OP_N, HIPBLAS_OP_N, 64, 64, 64, &one, A.data(), 64, B.data(), 64, &zero, C.data(), 64) == HIPBLAS_STATUS_SUCCESS);
     CHECK(mock_native_calls() == nat + 1);
-    setenv("GEMMUL8_MIN_FLOPS", "0", 1);  // 0 = emulate every call (the reference's behaviour)
+    unsetenv("GEMMUL8_MIN_FLOPS");  // unset = emulate every selected call (the reference's behaviour)
+    {
+        const long emu0 = mock_emulated_calls();
+        CHECK(hipblasDgemm(h, HIPBLAS_OP_N, HIPBLAS_OP_N, 64, 64, 64, &one, A.data(), 64, B.data(), 64, &zero, C.data(), 64) == HIPBLAS_STATUS_SUCCESS);
+        CHECK(mock_emulated_calls() == emu0 + 1);
+    }
     setenv("GEMMUL8_DIST", "blocks", 1);  // no RANK / WORLD_SIZE: one warning, then single-GPU emulation
     long emu = mock_emulated_calls();
     CHECK(hipblasDgemm(h, HIPBLAS_OP_N, HIPBLAS_OP_N, 64, 64, 64, &one, A.data(), 64, B.data(), 64, &zero, C.data(), 64) == HIPBLAS_STATUS_SUCCESS);

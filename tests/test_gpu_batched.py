@@ -149,7 +149,8 @@ def test_batched_fuzz(seed):
 def test_batched_with_dma_crt_kernel(dtype, m, monkeypatch):
     """The LDS-DMA form of the CRT kernel inside a batched launch (item in gridDim.z: workspace and C offsets per item), forced with
     GEMMUL8_CRT_KERNEL=dma on a shape with whole 1024-byte units per column; beta != 0 so that the old C is read per item."""
-    monkeypatch.setenv("GEMMUL8_CRT_KERNEL", "dma")
+    import gpu_util as gu
+    gu.setknob(monkeypatch, "GEMMUL8_CRT_KERNEL", "dma")
     rng = np.random.default_rng(77)
     batch, n, k = 3, 40, 96
     A = torch.from_numpy(rand((batch, k, m), dtype, rng)).cuda()

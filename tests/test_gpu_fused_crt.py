@@ -1,13 +1,51 @@
-"""-m gpu: the tile-stationary INT8 GEMM kernel with the CRT accumulation inside (gemmul8_lowprec_gemm_crt,
-csrc/oz2_gemm_i8.hip FUSE != 0) against the CPU oracle and against the two-launch path, bit for bit.  The fused kernel still
-writes the residue planes to C_mid, so every intermediate the parity tests look at stays comparable."""
+"""-m gpu: the tile-stationary INT8 GEMM kernel with the CRT accumulation inside against the CPU oracle and against
+the two-launch path, bit for bit.  LABORATORY code since round 4: both in-kernel CRT forms measured 10-28 % slower than the
+two-launch path and live in tools/experiments/fused_crt/ (libgemmul8_lab.so: the product's objects with the INT8
+GEMM object replaced by the FUSE = 1 | 2 instantiations, and gemmul8_lab_gemm = gemmul8_scale + gemmul8_lowprec_gemm_crt).
+libgemmul8.so exports none of it (last test).  The fused kernel still writes the residue planes to C_mid, so every intermediate
+the parity tests look at stays comparable."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LAB = os.path.join(ROOT, "tools", "experiments", "fused_crt", "lib", "libgemmul8_lab.so")
+
+
+class _LabLib:
+    """The laboratory library behind the interface gpu_util drives: gemmul8_gemm is its gemmul8_lab_gemm."""
+
+    def __init__(self, cdll):
+        self._l = cdll
+        self.gemmul8_gemm = cdll.gemmul8_lab_gemm
+
+    def __getattr__(self, name):
+        return getattr(self._l, name)
+
+
+@pytest.fixture(autouse=True)
+def lab_library():
+    """Every test of this module runs gpu_util's helpers on libgemmul8_lab.so."""
+    import gemmul8_amd as g
+    assert os.path.exists(LAB), "laboratory library not built: make -C tools/experiments/fused_crt (done by __graft_entry__.build())"
+    product = g.lib()
+    L = g.bind(C.CDLL(LAB))
+    L.gemmul8_lab_gemm.restype = C.c_int
+    L.gemmul8_lab_gemm.argtypes = product.gemmul8_gemm.argtypes
+    L.gemmul8_lowprec_gemm_crt.restype = C.c_int
+    L.gemmul8_lowprec_gemm_crt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.POINTER(g.Layout),
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.gemmul8_fused_crt_selected.restype = C.c_int
+    L.gemmul8_fused_crt_selected.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_uint]
+    g._lib = _LabLib(L)
+    try:
+        yield product
+    finally:
+        g._lib = product
 
 
 def rand(shape, dtype, rng, phi=1.0):
@@ -17,7 +55,7 @@ def rand(shape, dtype, rng, phi=1.0):
 
 @pytest.fixture(params=["1", "2"], ids=["producer-crt", "consumer-tail"])
 def fused(monkeypatch, request):
-    # read by gemmul8_gemm on every call: fused whenever it is legal; 1 = CRT on the producer waves, 2 = CRT tail on the consumer waves
+    # read by gemmul8_lab_gemm on every call: fused whenever it is legal; 1 = CRT on the producer waves, 2 = CRT tail on the consumer waves
     monkeypatch.setenv("GEMMUL8_FUSED_CRT", request.param)
 
 
@@ -128,3 +166,27 @@ def test_fused_selection_rule(monkeypatch):
     assert sel(g.D, g.INT8, 2048, 2048, 14) == 1
     assert sel(g.Z, g.INT8, 8192, 8192, 14) == 0 and sel(g.D, g.FP8, 8192, 8192, 14) == 0
     assert g.lib().gemmul8_lowprec_gemm_crt(None, g.Z, g.INT8, 8, 8, 8, 14, C.byref(g.Layout()), C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 8) == -3
+
+
+@pytest.mark.parametrize("alpha", [1.0, -1.5])
+def test_fused_beta0_never_reads_c(fused, alpha):
+    """beta == 0 must not read C (round-3 ADVICE: the stand-alone CRT kernels had the rule, the in-kernel forms evaluated fma(0, C, alpha*AB)):
+    a NaN-filled C comes back finite and bit-equal to the oracle."""
+    import gemmul8_amd as g
+    import gpu_util as gu
+    import oracle_lib as ol
+    rng = np.random.default_rng(3)
+    m, n, k, N = 144, 80, 190, 14
+    A, B = rand((m, k), np.float64, rng), rand((k, n), np.float64, rng)
+    C0 = np.full((m, n), np.nan)
+    got, inter = gu.hip_gemm(A, B, N, alpha=alpha, beta=0.0, C0=C0, want_intermediates=True)
+    assert np.isfinite(got).all()
+    want = ol.gemm(A, B, N, alpha=alpha, beta=0.0, C0=np.zeros((m, n)), sftA_in=inter["sftA"], sftB_in=inter["sftB"])
+    assert gu.bits_equal(got, want)
+
+
+def test_product_library_has_no_in_kernel_crt(lab_library):
+    """libgemmul8.so instantiates FUSE = 0 only and exports neither laboratory entry point."""
+    product = lab_library
+    for name in ("gemmul8_lowprec_gemm_crt", "gemmul8_fused_crt_selected", "gemmul8_lab_gemm"):
+        assert not hasattr(product, name), name

@@ -43,14 +43,14 @@ def test_random_case_bit_exact(seed, monkeypatch):
     if crt_force == "dma" and backend == g.INT8:
         m, n = (512 if np.dtype(dtype).kind == "c" else 1024), min(n, 64)
     if crt_force:
-        monkeypatch.setenv("GEMMUL8_CRT_KERNEL", crt_force)
+        gu.setknob(monkeypatch, "GEMMUL8_CRT_KERNEL", crt_force)
     if tile_force:
-        monkeypatch.setenv("GEMMUL8_BOUND_TILE", tile_force)
+        gu.setknob(monkeypatch, "GEMMUL8_BOUND_TILE", tile_force)
     if nt_force:
-        monkeypatch.setenv("GEMMUL8_EPI_NT", nt_force)
+        gu.setknob(monkeypatch, "GEMMUL8_EPI_NT", nt_force)
     cb_force = str(rng.choice(["", "1", "2", "3"]))   # column-block width of the tile walk (oz2_gemm_common.hpp map_colblock)
     if cb_force:
-        monkeypatch.setenv("GEMMUL8_MAP_COLBLOCK", cb_force)
+        gu.setknob(monkeypatch, "GEMMUL8_MAP_COLBLOCK", cb_force)
     cplx = np.dtype(dtype).kind == "c"
     opA = str(rng.choice(["N", "T", "C"] if cplx else ["N", "T"]))
     opB = str(rng.choice(["N", "T", "C"] if cplx else ["N", "T"]))

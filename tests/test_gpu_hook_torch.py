@@ -57,22 +57,17 @@ def test_torch_float32_matmul_is_emulated_under_ld_preload():
     assert emulated < 0.25 * native, (native, emulated)
 
 
-def test_default_floor_keeps_small_calls_native():
-    """GEMMUL8_MIN_FLOPS unset: calls the fitted cost model predicts to lose (oz2_hook.cpp below_floor; tests/test_hook_floor.py) go to the
-    native routine, so the drop-in never slows a small GEMM down; the demo's matrices are far below any crossover -> results identical
-    to the un-hooked run."""
+def test_auto_floor_keeps_small_calls_native():
+    """GEMMUL8_MIN_FLOPS=auto (opt-in): calls the fitted cost model predicts to lose (oz2_hook.cpp below_floor; tests/test_hook_floor.py) go
+    to the native routine; the demo's matrices are far below any crossover -> results identical to the un-hooked run, and the hook says
+    ONCE that calls below the floor are not emulated."""
     native, native_b = _run({})
-    env = {"LD_PRELOAD": SHIM, "GEMMUL8_NUM_MOD_D": "18", "GEMMUL8_NUM_MOD_S": "13"}
-    keep = os.environ.pop("GEMMUL8_MIN_FLOPS", None)
-    try:
-        floor_unset = dict(env)
-        out_env = dict(os.environ)
-        out_env.update(floor_unset)
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hook_torch_demo.py")], env=out_env, capture_output=True, text=True, timeout=600)
-    finally:
-        if keep is not None:
-            os.environ["GEMMUL8_MIN_FLOPS"] = keep
+    env = {"LD_PRELOAD": SHIM, "GEMMUL8_NUM_MOD_D": "18", "GEMMUL8_NUM_MOD_S": "13", "GEMMUL8_MIN_FLOPS": "auto"}
+    out_env = dict(os.environ)
+    out_env.update(env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hook_torch_demo.py")], env=out_env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stderr.count("stays on the native routine") == 1, out.stderr[-2000:]
     m = re.search(r"TFLOPS, normwise err ([0-9.e+-]+)", out.stdout)
     mb = re.search(r"bmm normwise err ([0-9.e+-]+)", out.stdout)
     big = re.search(r"torch DGEMM (\d+)\^3", out.stdout)

@@ -328,7 +328,7 @@ def test_bound_gemm_both_tile_sizes(dtype, tile, monkeypatch):
     with ragged tile edges, several tiles per dimension, K-major and strided operands, and the complex K-concatenated products."""
     import gemmul8_amd as g
     import gpu_util as gu
-    monkeypatch.setenv("GEMMUL8_BOUND_TILE", tile)
+    gu.setknob(monkeypatch, "GEMMUL8_BOUND_TILE", tile)
     rng = np.random.default_rng(11)
     for (m, n, k), (opA, opB) in [((37, 41, 300), ("N", "N")), ((300, 520, 700), ("T", "N")), ((513, 255, 1025), ("N", "T")),
                                   ((129, 385, 520), ("T", "T")), ((1, 1, 1), ("N", "N"))]:
@@ -347,7 +347,7 @@ def test_crt_kernels_both_forms(dtype, m, kernel, monkeypatch):
     through global_load_lds, sign-extending byte reads) that large products with whole 1024-byte units per column take.
     GEMMUL8_CRT_KERNEL forces either; both must reproduce the oracle bit for bit, for every axpby form."""
     import gpu_util as gu
-    monkeypatch.setenv("GEMMUL8_CRT_KERNEL", kernel)
+    gu.setknob(monkeypatch, "GEMMUL8_CRT_KERNEL", kernel)
     rng = np.random.default_rng(5)
     n, k = 37, 160
     cplx = np.dtype(dtype).kind == "c"
@@ -368,7 +368,7 @@ def test_residue_store_policy_both(dtype, policy, monkeypatch):
     """The INT8 GEMM writes its residue planes with non-temporal stores when the operand planes of the launch fit the Infinity Cache
     and the output is large (oz2_gemm_i8.hip nt_residue_stores); GEMMUL8_EPI_NT forces either policy.  Same bits either way."""
     import gpu_util as gu
-    monkeypatch.setenv("GEMMUL8_EPI_NT", policy)
+    gu.setknob(monkeypatch, "GEMMUL8_EPI_NT", policy)
     rng = np.random.default_rng(77)
     m, n, k = 300, 290, 200
     A = rand((m, k), dtype, rng, phi=1.0)
@@ -385,7 +385,7 @@ def test_tile_walk_column_blocks(dtype, backend_fp8, width, monkeypatch):
     (5 tile-columns in blocks of 1, 2, 3).  Same bits as the oracle."""
     import gemmul8_amd as g
     import gpu_util as gu
-    monkeypatch.setenv("GEMMUL8_MAP_COLBLOCK", width)
+    gu.setknob(monkeypatch, "GEMMUL8_MAP_COLBLOCK", width)
     rng = np.random.default_rng(int(width))
     m, n, k = 520, 1100, 96
     A = rand((m, k), dtype, rng, phi=1.0)
@@ -402,8 +402,8 @@ def test_complex_bound_one_or_two_launches(dtype, tile, launches, monkeypatch):
     pair of rounds 1-2.  Both kernels (128 / 256 tiles), several K-steps per segment; parity_case asserts the integer row / column
     maxima, the shifts and everything downstream against the oracle."""
     import gpu_util as gu
-    monkeypatch.setenv("GEMMUL8_CPLX_BOUND_LAUNCHES", launches)
-    monkeypatch.setenv("GEMMUL8_BOUND_TILE", tile)
+    gu.setknob(monkeypatch, "GEMMUL8_CPLX_BOUND_LAUNCHES", launches)
+    gu.setknob(monkeypatch, "GEMMUL8_BOUND_TILE", tile)
     rng = np.random.default_rng(11)
     m, n, k = 300, 270, 700
     A = rand((m, k), dtype, rng, phi=2.0)
@@ -464,7 +464,8 @@ def test_crt_on_extreme_residues(dtype, N, kernel, monkeypatch):
     import ctypes as C
     import gemmul8_amd as g
     import oracle_lib as ol
-    monkeypatch.setenv("GEMMUL8_CRT_KERNEL", kernel)
+    import gpu_util as gu
+    gu.setknob(monkeypatch, "GEMMUL8_CRT_KERNEL", kernel)
     cplx = np.dtype(dtype).kind == "c"
     comps = 2 if cplx else 1
     m, n = (512 if cplx else 1024), 24
@@ -537,9 +538,10 @@ def test_residue_store_policy_auto_at_size(monkeypatch):
     n, k = 8192, 512
     A = torch.randn((k, n), dtype=torch.float64, device="cuda")
     B = torch.randn((n, k), dtype=torch.float64, device="cuda")
-    monkeypatch.delenv("GEMMUL8_EPI_NT", raising=False)
+    import gpu_util as gu
+    gu.setknob(monkeypatch, "GEMMUL8_EPI_NT", None)
     C_auto, _, work = g.gemm(A, B, 14)
-    monkeypatch.setenv("GEMMUL8_EPI_NT", "0")
+    gu.setknob(monkeypatch, "GEMMUL8_EPI_NT", "0")
     C_plain, _, _ = g.gemm(A, B, 14, work=work)
     torch.cuda.synchronize()
     assert torch.equal(C_auto, C_plain)

@@ -1,6 +1,7 @@
-"""The hook's automatic floor (oz2_hook.cpp below_floor, exported as gemmul8_hook_would_emulate): with GEMMUL8_MIN_FLOPS unset a
-hooked call is emulated only where the fitted cost model predicts a win over the native routine.  Checked here, without a GPU,
-against the measurements the model was fitted to (profiles/sweeps/r03_floor_scan_*.csv, tools/floor_scan.py on one MI355X)."""
+"""The hook's opt-in automatic floor (oz2_hook.cpp below_floor, exported as gemmul8_hook_would_emulate): with GEMMUL8_MIN_FLOPS=auto a
+hooked call is emulated only where the fitted cost model predicts a win over the native routine; UNSET (the default) every selected
+call is emulated, as the reference's hook does.  Checked here, without a GPU, against the measurements the model was fitted to
+(profiles/sweeps/r03_floor_scan_*.csv, tools/floor_scan.py on one MI355X)."""
 import csv
 import os
 
@@ -17,8 +18,21 @@ def would(dtype, m, n, k, N, fast=0, backend=None, batch=1):
 
 
 @pytest.fixture(autouse=True)
-def _floor_unset(monkeypatch):
-    monkeypatch.delenv("GEMMUL8_MIN_FLOPS", raising=False)
+def _floor_auto(monkeypatch):
+    monkeypatch.setenv("GEMMUL8_MIN_FLOPS", "auto")
+
+
+def test_default_is_the_references_behaviour(monkeypatch):
+    """GEMMUL8_MIN_FLOPS unset (or empty, or 0): every selected call is emulated, whatever its shape, type or backend."""
+    for v in (None, "", "0"):
+        if v is None:
+            monkeypatch.delenv("GEMMUL8_MIN_FLOPS", raising=False)
+        else:
+            monkeypatch.setenv("GEMMUL8_MIN_FLOPS", v)
+        assert would("d", 64, 64, 64, 14) == 1
+        assert would("d", 8192, 8192, 256, 14) == 1
+        assert would("d", 8192, 8192, 1024, 14, backend=g.FP8) == 1
+        assert would("s", 16384, 256, 1024, 7, fast=1, batch=3) == 1
 
 
 def test_known_crossovers():

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Interleaved A/B of the whole emulated GEMM call with the CRT fused into the tile-stationary INT8 kernel (GEMMUL8_FUSED_CRT=1)
-against the two-launch path (=0), same process, same buffers, alternating rounds (box-to-box spread is +-3 %).
+against the two-launch path (=0), same process, same buffers, alternating rounds (box-to-box spread is +-3 %).  Runs on the
+LABORATORY library (tools/experiments/fused_crt/lib/libgemmul8_lab.so: the in-kernel CRT is not part of libgemmul8.so).
 usage: tools/fused_ab.py [dtype=d|s] [N=14] [shapes m,n,k ...]"""
+import ctypes as C
 import os
 import sys
 import time
@@ -10,6 +12,15 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import gemmul8_amd as g
+
+_product = g.lib()
+_lab = g.bind(C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "experiments", "fused_crt", "lib", "libgemmul8_lab.so")))
+_lab.gemmul8_lab_gemm.restype = C.c_int
+_lab.gemmul8_lab_gemm.argtypes = _product.gemmul8_gemm.argtypes
+_lab.gemmul8_gemm = _lab.gemmul8_lab_gemm  # g.gemm() now runs the laboratory pipeline
+_lab.gemmul8_fused_crt_selected.restype = C.c_int
+_lab.gemmul8_fused_crt_selected.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_uint]
+g._lib = _lab
 
 typ = sys.argv[1] if len(sys.argv) > 1 else "d"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 14

@@ -20,6 +20,8 @@ ap.add_argument("--size", type=int, default=8192)
 ap.add_argument("--moduli", type=int, default=14)
 ap.add_argument("--k", default="8192")
 ap.add_argument("--rounds", type=int, default=9)
+ap.add_argument("--check", action="store_true", help="compare the residue planes every build writes with the first build's (bit for bit)")
+ap.add_argument("--smi", action="store_true", help="sample sclk / socket power (rocm-smi) while each build loops for ~1.5 s")
 ap.add_argument("--fused", action="store_true", help="time gemmul8_lowprec_gemm_crt (GEMMs + CRT in one launch) of every build; the first build's two-launch path (lowprec_gemm + crt) is timed beside it")
 a = ap.parse_args()
 n, N = a.size, a.moduli
@@ -32,8 +34,10 @@ for i, pth in enumerate(a.libs):
     L = C.CDLL(cp)
     L.gemmul8_lowprec_gemm.restype = C.c_int
     L.gemmul8_lowprec_gemm.argtypes = ref.gemmul8_lowprec_gemm.argtypes
-    L.gemmul8_lowprec_gemm_crt.restype = C.c_int
-    L.gemmul8_lowprec_gemm_crt.argtypes = ref.gemmul8_lowprec_gemm_crt.argtypes
+    if a.fused:  # laboratory builds only (tools/experiments/fused_crt/lib/libgemmul8_lab.so and its ablation builds)
+        L.gemmul8_lowprec_gemm_crt.restype = C.c_int
+        L.gemmul8_lowprec_gemm_crt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.POINTER(g.Layout),
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.gemmul8_crt.restype = C.c_int
     L.gemmul8_crt.argtypes = ref.gemmul8_crt.argtypes
     libs.append(L)
@@ -74,6 +78,46 @@ for k in [int(x) for x in a.k.split(",")]:
             torch.cuda.synchronize()
             if r >= 2:
                 ts[i].append(e0.elapsed_time(e1) / 3)
+    if a.check and not a.fused:
+        offC = Lo.C_mid - work.data_ptr()
+        refC = None
+        for i, L in enumerate(libs):
+            work[offC:offC + N * Lo.sizeC] = 0x5A
+            g.check(L.gemmul8_lowprec_gemm(st, g.D, g.INT8, n, n, k, N, 0, N, C.byref(Lo)))
+            torch.cuda.synchronize()
+            cur = work[offC:offC + N * Lo.sizeC].clone()
+            if refC is None:
+                refC = cur
+            else:
+                print(f"k={k:5d} {os.path.basename(a.libs[i]):40s} residue planes {'IDENTICAL to' if torch.equal(cur, refC) else 'DIFFER from'} {os.path.basename(a.libs[0])}")
+        del refC, cur
+    if a.smi and not a.fused:
+        import subprocess, threading, time, re
+        for i, L in enumerate(libs):
+            stop = False
+            samples = []
+            def sample():
+                while not stop:
+                    try:
+                        o = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+                        m1 = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", o)
+                        m2 = re.search(r"Power \(W\): ([0-9.]+)", o)
+                        if m1 and m2:
+                            samples.append((int(m1.group(1)), float(m2.group(1))))
+                    except Exception:
+                        pass
+            th = threading.Thread(target=sample)
+            th.start()
+            t0 = time.time()
+            while time.time() - t0 < 2.5:
+                for _ in range(20):
+                    g.check(L.gemmul8_lowprec_gemm(st, g.D, g.INT8, n, n, k, N, 0, N, C.byref(Lo)))
+                torch.cuda.synchronize()
+            stop = True
+            th.join()
+            busy = [s_ for s_ in samples if s_[1] > 600]
+            if busy:
+                print(f"k={k:5d} {os.path.basename(a.libs[i]):40s} smi: sclk {sum(s_[0] for s_ in busy) / len(busy):6.0f} MHz  power {sum(s_[1] for s_ in busy) / len(busy):6.0f} W  ({len(busy)} samples)")
     for i, pth in enumerate(a.libs):
         t = sorted(ts[i])
         med = t[len(t) // 2]
