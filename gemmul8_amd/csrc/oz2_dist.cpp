@@ -422,7 +422,7 @@ int gemmul8_dist_create(const gemmul8_comm* comm, const gemmul8_dist_engine* eng
     if (!comm || !out || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world) return GEMMUL8_E_ARG;
     if (kind < GEMMUL8_DIST_BLOCKS || kind > GEMMUL8_DIST_MODULI_FP64SUM) return GEMMUL8_E_ARG;
     if (dtype < 0 || dtype > 3 || backend < 0 || backend > 1) return GEMMUL8_E_ARG;
-    if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
+    if (N < 2 || N > ((dtype == GEMMUL8_S || dtype == GEMMUL8_C) ? 13u : 20u)) return GEMMUL8_E_NUM_MODULI;  // float types: 2..13 (gemmul8.hpp:30)
     op_A = norm_op(op_A), op_B = norm_op(op_B);
     if (op_A < 0 || op_A > 2 || op_B < 0 || op_B > 2 || m == 0 || n == 0 || k == 0) return GEMMUL8_E_ARG;
     if (k > (size_t(1) << 17) || (backend == GEMMUL8_FP8 && k > 65536)) return GEMMUL8_E_ARG;

@@ -38,6 +38,11 @@ inline int norm_op(int op) {
 inline size_t low_size(int) { return 1; }
 inline size_t mid_size(int backend, bool cplx) { return (backend == kINT8 ? 1 : 2) * (cplx ? 2 : 1); }
 
+// num_moduli range of a type: 2..20 for double / complex-double, 2..13 for float / complex-float (reference contract,
+// GEMMul8/include/gemmul8.hpp:30; its float pipeline accepts more but overflows: P reaches 2^128 at 16 moduli -- the oracle's
+// restatement returns inf there, tests/test_gpu_parity.py::test_float_types_reject_more_than_13_moduli)
+static inline bool moduli_ok(int dtype, unsigned N) { return N >= 2 && N <= (is_f32(dtype) ? 13u : 20u); }
+
 #define OZ2_HIP(expr)                       \
     do {                                    \
         hipError_t e__ = (expr);            \
@@ -108,7 +113,7 @@ extern "C" {
 void gemmul8_reload_knobs(void) { oz2::reload_knobs(); }
 
 int gemmul8_set_fp8_bound_mode(int mode) {
-    if (mode != 0 && mode != 1) return GEMMUL8_E_ARG;
+    if (mode < 0 || mode > 2) return GEMMUL8_E_ARG;
     const int old = get_f8_bound_mode();
     set_f8_bound_mode(mode);
     return old;
@@ -138,7 +143,7 @@ size_t gemmul8_work_size(int is_complex, int backend, size_t m, size_t n, size_t
 int gemmul8_get_layout(int dtype, int backend, size_t m, size_t n, size_t k, unsigned N, void* work, void* workA, void* workB,
                        int enA, int enB, gemmul8_layout* L) {
     if (!L || !work) return GEMMUL8_E_ARG;
-    if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
+    if (!moduli_ok(dtype, N)) return GEMMUL8_E_NUM_MODULI;
     const bool cplx = is_complex(dtype);
     memset(L, 0, sizeof(*L));
     L->kp = padding256(k);
@@ -196,7 +201,7 @@ int gemmul8_scale_bounds(void* stream_, int dtype, int backend, int op_A, int op
                          int skipA, int skipB) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!L || !A || !B) return GEMMUL8_E_ARG;
-    if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
+    if (!moduli_ok(dtype, N)) return GEMMUL8_E_NUM_MODULI;
     if (backend == kFP8 && k > 65536) return GEMMUL8_E_ARG;  // exact FP32 accumulation needs k*16*16 <= 2^24
     op_A = norm_op(op_A);
     op_B = norm_op(op_B);
@@ -265,7 +270,7 @@ int gemmul8_scale_finish(void* stream_, int dtype, int backend, int op_A, int op
                          const gemmul8_layout* L, int skipA, int skipB) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!L || !A || !B) return GEMMUL8_E_ARG;
-    if (N < 2 || N > 20 || t_end > N || t_begin > t_end) return GEMMUL8_E_NUM_MODULI;
+    if (!moduli_ok(dtype, N) || t_end > N || t_begin > t_end) return GEMMUL8_E_NUM_MODULI;
     if (backend == kFP8 && k > 65536) return GEMMUL8_E_ARG;
     op_A = norm_op(op_A);
     op_B = norm_op(op_B);
@@ -308,7 +313,7 @@ int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t
     hipStream_t stream = (hipStream_t)stream_;
     (void)k;
     if (!L) return GEMMUL8_E_ARG;
-    if (N < 2 || N > 20 || t_end > N || t_begin > t_end) return GEMMUL8_E_NUM_MODULI;
+    if (!moduli_ok(dtype, N) || t_end > N || t_begin > t_end) return GEMMUL8_E_NUM_MODULI;
     const int8_t* A_lo = (const int8_t*)L->A_lo;
     const int8_t* B_lo = (const int8_t*)L->B_lo;
     if (backend == kFP8 && !is_complex(dtype)) {
@@ -388,7 +393,7 @@ int gemmul8_crt(void* stream_, int dtype, int backend, unsigned N, size_t m, siz
                 size_t plane_stride, const int16_t* sftA, const int16_t* sftB, const void* alpha, const void* beta, void* C, size_t ldc) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!C_mid || !sftA || !sftB || !alpha || !beta || !C) return GEMMUL8_E_ARG;
-    if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
+    if (!moduli_ok(dtype, N)) return GEMMUL8_E_NUM_MODULI;
     OZ2_HIP(launch_crt(stream, dtype, backend, N, m, n, C_mid, ld_mid, plane_stride, sftA, sftB, alpha, beta, scalars_on_device(alpha), C, ldc));
     return GEMMUL8_OK;
 }
@@ -406,7 +411,7 @@ int gemmul8_crt_partial(void* stream_, int dtype, int backend, unsigned N, unsig
                         size_t col_block, size_t block_stride) {
     if (!C_mid || !out_hi || !out_lo || col_block == 0) return GEMMUL8_E_ARG;
     if (dtype < 0 || dtype > 3 || backend < 0 || backend > 1) return GEMMUL8_E_ARG;
-    if (N < 2 || N > 20 || t_end > N || t_begin > t_end) return GEMMUL8_E_NUM_MODULI;
+    if (!moduli_ok(dtype, N) || t_end > N || t_begin > t_end) return GEMMUL8_E_NUM_MODULI;
     OZ2_HIP(launch_crt_partial((hipStream_t)stream_, dtype, backend, N, t_begin, t_end, m, n, C_mid, ld_mid, plane_stride, out_hi, out_lo,
                                ld_out, col_block, block_stride));
     return GEMMUL8_OK;
@@ -416,7 +421,7 @@ int gemmul8_crt_finish(void* stream_, int dtype, int backend, unsigned N, size_t
                        size_t ld_in, const int16_t* sftA, const int16_t* sftB, const void* alpha, const void* beta, void* C, size_t ldc) {
     if (!in_hi || !in_lo || !sftA || !sftB || !alpha || !beta || !C) return GEMMUL8_E_ARG;
     if (dtype < 0 || dtype > 3 || backend < 0 || backend > 1) return GEMMUL8_E_ARG;
-    if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
+    if (!moduli_ok(dtype, N)) return GEMMUL8_E_NUM_MODULI;
     OZ2_HIP(launch_crt_finish((hipStream_t)stream_, dtype, backend, N, m, n, in_hi, in_lo, ld_in, sftA, sftB, alpha, beta,
                               scalars_on_device(alpha), C, ldc));
     return GEMMUL8_OK;
@@ -428,7 +433,7 @@ int gemmul8_gemm(void* stream_, int dtype, int backend, int op_A, int op_B, size
     hipStream_t stream = (hipStream_t)stream_;
     if (timers_ns) timers_ns[0] = timers_ns[1] = timers_ns[2] = timers_ns[3] = 0.0;
     if (dtype < 0 || dtype > 3 || backend < 0 || backend > 1) return GEMMUL8_E_ARG;
-    if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
+    if (!moduli_ok(dtype, N)) return GEMMUL8_E_NUM_MODULI;
     if (!alpha || !beta || !A || !B || !C || !work) return GEMMUL8_E_ARG;
     if (k > (size_t(1) << 17)) return GEMMUL8_E_ARG;
     if (m == 0 || n == 0 || k == 0) return GEMMUL8_OK;  // success, C untouched: what the reference's hook does (hook.cu:616-617); its gemm() itself has no check
@@ -488,7 +493,7 @@ int gemmul8_gemm_batched(void* stream_, int dtype, int backend, int op_A, int op
                          const void* A, size_t lda, long long strideA, const void* B, size_t ldb, long long strideB, const void* beta,
                          void* C, size_t ldc, long long strideC, size_t batch, unsigned N, int fastmode, void* work) {
     if (dtype < 0 || dtype > 3 || backend < 0 || backend > 1) return GEMMUL8_E_ARG;
-    if (N < 2 || N > 20) return GEMMUL8_E_NUM_MODULI;
+    if (!moduli_ok(dtype, N)) return GEMMUL8_E_NUM_MODULI;
     if (!alpha || !beta || !A || !B || !C || !work) return GEMMUL8_E_ARG;
     if (k > (size_t(1) << 17)) return GEMMUL8_E_ARG;
     if (backend == kFP8 && k > 65536) return GEMMUL8_E_ARG;  // exact FP32 accumulation needs k*16*16 <= 2^24

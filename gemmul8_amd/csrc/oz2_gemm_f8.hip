@@ -41,8 +41,11 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 // EPI_FINAL_CPLX: like EPI_FINAL for the third complex part Z = (Ar+Ai)(Br+Bi), then (Cr, Ci) = (X - Y, Z - X - Y) mod p with
 // the residues X, Y of the first two parts -> interleaved int16 pairs (conv_hi2mid_complex.hpp:28-41).
-// EPI_FB1/2/3: the three bound GEMMs of the complex accurate mode (find_max.hpp, complex FP8): u = fma_ru(ku, c, c);
-//   1: store u (ArBi)   2: store add_ru(stored, u) (+ AiBr = s12)   3: s0 = add_ru(u, s12), maxima of max(s0, s12)
+// EPI_FB1/2/3: the three bound GEMMs of the complex accurate mode (find_max.hpp:117-140,218-251, complex FP8): u = fma_ru(ku, c, c);
+//   1: store u (ArBi)   2: store add_ru(stored, u) (+ AiBr = s12)   3: s0 from c = (|Ar|-|Ai|)(|Br|-|Bi|) and s12, maxima of max(s0, s12)
+//   Stage 3, reference (args.cplx_rule = 0): s0 = add_ru(fma_ru(ku, c, c), s12).  Default here (cplx_rule = 1):
+//   s0 = add_ru(fma_ru(ku, add_ru(|c|, 2 s12), c), s12) -- c is a sum of products of BOTH signs, so the engine's truncation error on it
+//   scales with the sum of the MAGNITUDES of its terms (<= T + C1, T = the bound sought, C1 <= s12), not with |c|: see bound_ku below
 enum { EPI_PART = 0, EPI_FINAL = 1, EPI_FMAX = 2, EPI_FINAL_CPLX = 3, EPI_FB1 = 4, EPI_FB2 = 5, EPI_FB3 = 6 };
 
 struct F8Args {
@@ -64,6 +67,7 @@ struct F8Args {
     int* rowmax;          // EPI_FMAX (float bit patterns)
     int* colmax;
     float ku;             // bound inflation, see bound_ku (reference: (k+1) * 2^-24)
+    int cplx_rule;        // EPI_FB3: 1 = inflate the mixed-sign product by ku (|c| + 2 s12) (default), 0 = by ku c as the reference does
     int total_tiles;      // planes * tiles_m * tiles_n
     int ppi;              // planes per batch item (plane p = item p / ppi, item-relative plane p % ppi); = all planes for one GEMM
     size_t bstride;       // bytes between the workspaces of consecutive batch items (every pointer above lives in the workspace)
@@ -238,7 +242,9 @@ __device__ __forceinline__ void f8_epilogue_bound(v4f (&acc)[8][4], const F8Args
                         } else {
 #pragma unroll
                             for (int b = 0; b < 4; ++b) {
-                                const float s0 = __fadd_ru(u[b], ws[b]);
+                                const float c = acc[ti][tj][b];
+                                const float up = args.cplx_rule ? __fmaf_ru(ku, __fadd_ru(fabsf(c), __fadd_ru(ws[b], ws[b])), c) : u[b];
+                                const float s0 = __fadd_ru(up, ws[b]);
                                 u[b] = s0 > ws[b] ? s0 : ws[b];
                             }
                         }
@@ -577,8 +583,15 @@ hipError_t launch_gemm_f8(hipStream_t stream, int which, const int8_t* A, const 
 // <= 2 (k+1) * 2^-24 overall).  A bound that comes out LOW can push the shift up by one and break accurate mode's no-wrap guarantee
 // |A'B'| < P/2, so the default here covers the engine: ku = 7 * 2^-13 + 4 (k+1) * 2^-24 (a factor 2 of margin on the accumulator
 // term; costs < 0.015 bit of shift at k = 65536).  Mode 1 restores the reference's formula (gemmul8_set_fp8_bound_mode).
+// Complex types (round 4): the bound of |Re C| is T = C0 + C1 with C0 = sum (|Ar|-|Ai|)(|Br|-|Bi|) -- terms of both signs -- and
+// C1 = sum |Ar||Bi| + |Ai||Br|.  With eps the engine's relative loss on a sum of magnitudes, computed C0 >= C0 - eps (T + C1) (the
+// magnitudes of C0's terms sum to at most T + C1), so T <= (C0_computed + (1 + eps) C1) / (1 - eps): the inflation of C0 must scale with
+// |C0| + 2 C1, not with C0 -- where the large terms of C0 cancel (T ~ C1) the reference's form fma_ru(ku, C0, C0) + s12 leaves T low by up
+// to 2 eps - ku (tests/test_gpu_fp8_bound.py::test_fp8_bound_adversarial_complex builds such matrices: with mode 2 every element of C
+// comes back wrong).  Mode 0 uses s0 = fma_ru(ku, |C0| + 2 s12, C0) + s12 (all rounded up); mode 2 = mode 0's ku with the reference's
+// combination (the round-3 default, kept for that test); mode 1 = the reference throughout.
 static std::atomic<int> g_f8_bound_mode{0};
-void set_f8_bound_mode(int mode) { g_f8_bound_mode.store(mode == 1 ? 1 : 0); }
+void set_f8_bound_mode(int mode) { g_f8_bound_mode.store(mode == 1 || mode == 2 ? mode : 0); }
 int get_f8_bound_mode() { return g_f8_bound_mode.load(); }
 static float bound_ku(size_t k) {
     const float ieee = (float)(k + 1) * 0x1.0p-24f;
@@ -608,6 +621,7 @@ hipError_t launch_gemm_f8_bound_cplx(hipStream_t stream, int stage, const int8_t
     a.fbuf = fbuf;
     a.ldo = ldf;
     a.ku = bound_ku(k);
+    a.cplx_rule = g_f8_bound_mode.load() == 0 ? 1 : 0;
     fill_common(a, kp, m, n);
     if (stage == 1) return launch<EPI_FB1>(stream, a, 1);
     if (stage == 2) return launch<EPI_FB2>(stream, a, 1);

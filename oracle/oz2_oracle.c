@@ -333,8 +333,11 @@ void oz2_bound_maxima_i8(int cplx, size_t m, size_t n, size_t k, const uint8_t *
 /* Inflation factor: mode 1 = the reference's (k+1)*2^-24 (find_max.hpp:82-96), mode 0 (default, what the product ships) =
  * 7*2^-13 + 4(k+1)*2^-24, which covers gfx950's truncating FP8 MFMA accumulation (include/gemmul8_c.h,
  * gemmul8_set_fp8_bound_mode); the same float operations as oz2_gemm_f8.hip:bound_ku. */
+/* Complex types, mode 0: the mixed-sign product C0 = (|Ar|-|Ai|)(|Br|-|Bi|) is inflated by ku (|C0| + 2 s12) instead of the
+ * reference's ku C0 (find_max.hpp:117-140): the engine's error on C0 scales with the magnitudes of its terms (oz2_gemm_f8.hip,
+ * bound_ku).  Mode 2 = mode 0's ku with the reference's combination (the round-3 default, kept for the adversarial test). */
 static int g_f8_bound_mode = 0;
-void oz2_set_fp8_bound_mode(int mode) { g_f8_bound_mode = mode == 1; }
+void oz2_set_fp8_bound_mode(int mode) { g_f8_bound_mode = (mode == 1 || mode == 2) ? mode : 0; }
 static float f8_bound_ku(size_t k) {
     const float ieee = (float)(k + 1) * 0x1.0p-24f;
     if (g_f8_bound_mode == 1) return ieee;
@@ -367,7 +370,9 @@ void oz2_bound_maxima_f8(int cplx, size_t m, size_t n, size_t k, const uint8_t *
                 float ArBi_up = fmaf_dir(ku, ArBi, ArBi, FE_UPWARD);
                 float AiBr_up = fmaf_dir(ku, AiBr, AiBr, FE_UPWARD);
                 float s12 = addf_dir(ArBi_up, AiBr_up, FE_UPWARD);
-                float AriBri_up = fmaf_dir(ku, AriBri, AriBri, FE_UPWARD);
+                float AriBri_up = g_f8_bound_mode == 0
+                                      ? fmaf_dir(ku, addf_dir(fabsf(AriBri), addf_dir(s12, s12, FE_UPWARD), FE_UPWARD), AriBri, FE_UPWARD)
+                                      : fmaf_dir(ku, AriBri, AriBri, FE_UPWARD);
                 float s0 = addf_dir(AriBri_up, s12, FE_UPWARD);
                 v = s0 > s12 ? s0 : s12;
             }

@@ -165,12 +165,15 @@ def bounds_case(A, B, N, opA="N", opB="N", backend=g.INT8, skip_layout=False):
             assert np.all(d64 >= ex), f"{what} maxima of the FP8 bound GEMM BELOW the exact sum by {np.min((d64 - ex) / np.maximum(ex, 1e-300))}"
             assert np.all(d64 <= o.astype(np.float64) * (1 + 2.0 ** -22)), f"{what} maxima of the FP8 bound GEMM above the inflated exact sum"
         return int((rmax != orm).sum() + (cmax != ocm).sum())
-    # complex: (Ar-Ai)(Br-Bi) has products of both signs, no one-sided statement; same band around the oracle as before
-    up, down = 2.0 ** -9, 2.0 ** -9
-    for d, o, what in ((rmax, orm, "row"), (cmax, ocm, "column")):
-        with np.errstate(invalid="ignore", divide="ignore"):   # all-zero rows: 0 / 1e-300
-            rel = (d.astype(np.float64) - o) / np.maximum(o.astype(np.float64), 1e-300)
-        assert np.all((d == o) | ((rel <= up) & (rel >= -down))), f"{what} maxima of the FP8 bound GEMM off by {rel.min()} .. {rel.max()}"
+    # complex (round 4): T = C0 + C1 with C0 = (|Ar|-|Ai|)(|Br|-|Bi|) of both signs.  The default combination inflates C0 by
+    # ku (|C0| + 2 s12) (oz2_gemm_f8.hip bound_ku), which covers the engine's loss on the MAGNITUDES of C0's terms, so the same one-sided
+    # GUARANTEE holds: exact un-inflated max(T, C1) <= device value.  Above, the device may exceed the oracle's inflated value of the exact
+    # sums by what the engine loses on C0's NEGATIVE terms (at most eps (T + C1), inflated again): a 2^-9 band.
+    ex_r, ex_c = ol.bound_maxima_f8_exact_cplx(oA, oB)
+    for d, o, ex, what in ((rmax, orm, ex_r, "row"), (cmax, ocm, ex_c, "column")):
+        d64 = d.astype(np.float64)
+        assert np.all(d64 >= ex), f"{what} maxima of the complex FP8 bound BELOW the exact sum by {np.min((d64 - ex) / np.maximum(ex, 1e-300))}"
+        assert np.all(d64 <= o.astype(np.float64) * (1 + 2.0 ** -9)), f"{what} maxima of the complex FP8 bound above the oracle's inflated value"
     return int((rmax != orm).sum() + (cmax != ocm).sum())
 
 

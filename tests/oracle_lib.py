@@ -177,8 +177,20 @@ def bound_maxima_f8_exact(Abar, Bbar):
     return P.max(axis=1), P.max(axis=0)
 
 
+def bound_maxima_f8_exact_cplx(Abar, Bbar):
+    """Complex FP8 bound, exactly accumulated and UN-inflated, from the three e4m3 bound planes (|Re|, |Im|, RU(|Re| - |Im|)) of each
+    operand: element-wise max(T, C1) with C1 = |Ar||Bi| + |Ai||Br| and T = C0 + C1, C0 = D_A D_B (find_max.hpp:117-140 without the
+    inflation).  What the device's accurate-mode bound must not fall below, whatever the engine does to the sums."""
+    ar, ai, ad = (e4m3_decode(Abar[i]) for i in range(3))
+    br, bi, bd = (e4m3_decode(Bbar[i]) for i in range(3))
+    C1 = ar @ bi.T + ai @ br.T
+    T = ad @ bd.T + C1
+    P = np.maximum(T, C1)
+    return P.max(axis=1), P.max(axis=0)
+
+
 def set_fp8_bound_mode(mode):
-    """0 = the product's engine-safe inflation (default), 1 = the reference's (k+1)*2^-24 (find_max.hpp:82-96)."""
+    """0 = the product's engine-safe inflation (default), 1 = the reference's (k+1)*2^-24 (find_max.hpp:82-96), 2 = round-3 default."""
     lib().oz2_set_fp8_bound_mode(int(mode))
 
 

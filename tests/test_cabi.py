@@ -57,3 +57,28 @@ def test_argument_validation_without_gpu():
     rc = L.gemmul8_gemm(None, g.D, g.INT8, 0, 0, 2, 2, (1 << 17) + 1, a.ctypes.data, a.ctypes.data, 2, a.ctypes.data, 2,
                         a.ctypes.data, a.ctypes.data, 2, 14, 0, a.ctypes.data, None, None, 0, 0, 0, 0, tm)
     assert rc == -2
+
+
+def test_float_types_reject_more_than_13_moduli():
+    """Contract of the reference (GEMMul8/include/gemmul8.hpp:30): 2..20 moduli for double / complex-double, 2..13 for float /
+    complex-float.  The reference's float pipeline accepts more and overflows (P reaches 2^128 at 16 moduli); the restated oracle
+    shows it (inf), so the C ABI refuses instead of returning inf: GEMMUL8_E_NUM_MODULI before any HIP call, every entry point."""
+    import oracle_lib as ol
+    L = g.lib()
+    a = np.zeros(64)
+    p = a.ctypes.data
+    lay = g.Layout()
+    for dt in (g.S, g.Cx):
+        for be in (g.INT8, g.FP8):
+            for N in (14, 16, 20):
+                assert L.gemmul8_gemm(None, dt, be, 0, 0, 2, 2, 2, p, p, 2, p, 2, p, p, 2, N, 0, p, None, None, 0, 0, 0, 0, None) == -1
+                assert L.gemmul8_gemm_batched(None, dt, be, 0, 0, 2, 2, 2, p, p, 2, 4, p, 2, 4, p, p, 2, 4, 2, N, 0, p) == -1
+                assert L.gemmul8_get_layout(dt, be, 2, 2, 2, N, p, None, None, 0, 0, C.byref(lay)) == -1
+                assert L.gemmul8_crt(None, dt, be, N, 2, 2, p, 2, 4, p, p, p, p, p, 2) == -1
+    for dt in (g.D, g.Z):
+        assert L.gemmul8_get_layout(dt, g.INT8, 2, 2, 2, 20, p, None, None, 0, 0, C.byref(lay)) == 0
+    # why: the float pipeline of the reference, restated, overflows beyond 13-15 moduli
+    rng = np.random.default_rng(0)
+    A, B = (rng.random((5, 24)) - 0.5).astype(np.float32), (rng.random((24, 4)) - 0.5).astype(np.float32)
+    assert np.isfinite(ol.gemm(A, B, 13)).all()
+    assert not np.isfinite(ol.gemm(A, B, 20)).all()

@@ -87,13 +87,10 @@ def build_case(N, delta=2.0e-4, k=K):
     return A, B, S_x / 128.0 ** 2, v_x, v_l
 
 
-@pytest.mark.parametrize("N", [6, 8, 12])
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("N,dtype", [(6, np.float64), (8, np.float64), (12, np.float64), (6, np.float32), (8, np.float32)])
 def test_fp8_bound_adversarial_no_wrap(N, dtype):
     import gemmul8_amd as g
     import gpu_util as gu
-    if dtype == np.float32 and N > 8:
-        pytest.skip("float32 quantised integers would exceed 2^24 * ... keep the float case at N <= 8")
     A, B, exact, v_x, v_l = build_case(N)
     A, B = A.astype(dtype), B.astype(dtype)
     ref = np.full((A.shape[0], B.shape[1]), exact)
@@ -118,6 +115,109 @@ def test_fp8_bound_adversarial_no_wrap(N, dtype):
     assert out[0]["wrong_elements"] == 0 and out[0]["max_rel_err"] < tol, f"default inflation: {out[0]}"
 
 
+def build_case_cplx(N, k=1024, delta=1.2e-4):
+    """Complex counterpart.  The bound of |Re C| is T = C0 + C1, C0 = sum (|Ar|-|Ai|)(|Br|-|Bi|) (both signs),
+    C1 = sum |Ar||Bi| + |Ai||Br| (find_max.hpp:117-140).  Two kinds of groups of 8 consecutive k, every value an e4m3 number:
+      X  k0: A = BIG, B = b            k1-7: A = SMALL, B = b/64          -> T += BIG b + 7 SMALL b/64, the small products of C0 vanish
+      Y  k0: A = BIG, B = -i b         k1-7: A = SMALL (1 + i), B = -i b/64
+         -> C0 -= BIG b (big NEGATIVE term), C1 += BIG b + 7 SMALL b/64 (the small products of the |Ar||Bi| GEMM vanish beside BIG b),
+            T += 7 SMALL b/64 (= |Ai||Bi|; in C0 these positions are exact zeros: RU(|Ar| - |Ai|) = 0, nothing to lose)
+    Engine: C0 = sumX_big - sumY_big, C1 = sumY_big; exact T = sumX_big (1 + e) + e sumY_big with e = 7 SMALL / (64 BIG): with sumY ~ sumX the
+    engine's T is low by ~2 e = 12.8 * 2^-13, more than ku = 7 * 2^-13 + 4 (k+1) 2^-24 = 9 * 2^-13 at k = 1024 covers when it multiplies
+    C0 + C1 only.  The sums are chosen so that the pre-floor value of the shift sits `delta` ABOVE an integer with the engine's value
+    inflated the round-3 way and below it with the exact T.  Re C = T exactly (every product of Re C is non-negative), so a shift that is
+    one too large wraps the CRT."""
+    L = log2P_fp8(N)
+    c = 1.0 + 6.0 * 2.0 ** -24
+    ku_eng = 1.75 * 2.0 ** -11 + 4 * (k + 1) * 2.0 ** -24
+    e = 7 * SMALL_A * 2.0 / (BIG_A * 128.0)
+    ngroups = k // 8
+    JMAX = 8                                              # b = 128 * 2^-j bound-plane units, j = 0..8 (small = 2 * 2^-j >= 2^-7: an e4m3 number)
+    best = None
+    for b_int in range(int(L) - 14, int(L) - 6):
+        S_l = 2.0 ** (2.0 * (L - b_int - delta) / c) / (1 + ku_eng)     # engine-side T = sumX_big (round-3 combination)
+        unit = BIG_A * 128.0 * 2.0 ** -JMAX
+        units = int(round(S_l / unit))
+        counts, rest = [], units
+        for j in range(JMAX + 1):
+            u = 2 ** (JMAX - j)
+            cnt = rest // u
+            counts.append(cnt)
+            rest -= cnt * u
+        nX = sum(counts)
+        nY = int(0.97 * units * unit / (BIG_A * 128.0))   # Y groups all with b = 128: sumY_big = nY * 2^14 ~ 0.97 sumX_big
+        if nX + nY <= ngroups and nY >= 8:
+            best = (counts, nY, b_int)
+            break
+    assert best is not None, "no group decomposition found"
+    counts, nY, b_int = best
+    a = np.zeros(k, np.complex128)
+    b = np.zeros(k, np.complex128)
+    g = 0
+    for j, cnt in enumerate(counts):
+        for _ in range(cnt):
+            a[8 * g] = BIG_A
+            a[8 * g + 1:8 * g + 8] = SMALL_A
+            b[8 * g] = 128.0 * 2.0 ** -j
+            b[8 * g + 1:8 * g + 8] = 2.0 * 2.0 ** -j
+            g += 1
+    for _ in range(nY):
+        a[8 * g] = BIG_A
+        a[8 * g + 1:8 * g + 8] = SMALL_A * (1 + 1j)
+        b[8 * g] = -128.0j
+        b[8 * g + 1:8 * g + 8] = -2.0j
+        g += 1
+    ar, ai, br, bi = np.abs(a.real), np.abs(a.imag), np.abs(b.real), np.abs(b.imag)
+    T = float(ar @ br + ai @ bi)
+    C1 = float(ar @ bi + ai @ br)
+    big = ar == BIG_A
+    X_big = float((ar * big) @ br)
+    Y_big = float((ar * big) @ bi)
+    assert T > C1 and abs(T - (X_big * (1 + e) + e * Y_big)) < 1e-6 * T
+    v_exact = L - 0.5 * c * np.log2(T)                                   # the shift any valid bound must not exceed
+    v_r3 = L - 0.5 * c * np.log2(X_big * (1 + ku_eng))                   # engine value, round-3 combination
+    v_new = L - 0.5 * c * np.log2((X_big - Y_big) + Y_big * (1 + ku_eng) + ku_eng * (abs(X_big - Y_big) + 2 * Y_big * (1 + ku_eng)))
+    assert np.floor(v_r3) == np.floor(v_exact) + 1, (v_exact, v_r3)       # the window
+    assert np.floor(v_new) <= np.floor(v_exact), (v_exact, v_new)
+    m = n = 48
+    A = np.tile(a / 128.0, (m, 1))                     # amax of every row / column = 1.0 -> sft0 = 7 -> bound planes = the patterns exactly
+    B = np.tile((b / 128.0)[:, None], (1, n))
+    exact = complex((a / 128.0) @ (b / 128.0))         # small dyadic rationals: exact in float64
+    assert abs(exact.real - T / 128.0 ** 2) < 1e-9 * T / 128.0 ** 2
+    return A, B, exact, v_exact, v_r3, v_new
+
+
+@pytest.mark.parametrize("N,dtype", [(8, np.complex128), (12, np.complex128), (8, np.complex64)])
+def test_fp8_bound_adversarial_complex(N, dtype):
+    """Complex accurate mode on matrices built so that the engine's loss on the mixed-sign product decides the shift: with the default
+    combination (mode 0) every element of C must equal the exact product; the round-3 default (mode 2: same ku, reference's combination)
+    and the reference's formula (mode 1) are recorded (gpurun_out/fp8_bound_adversarial_complex.jsonl), not asserted."""
+    import gemmul8_amd as g
+    import gpu_util as gu
+    A, B, exact, v_exact, v_r3, v_new = build_case_cplx(N)
+    A, B = A.astype(dtype), B.astype(dtype)
+    gu.bounds_case(A, B, N, backend=g.FP8)             # the guarantee itself: device maxima >= exact un-inflated max(T, C1)
+    lib = g.lib()
+    out = {}
+    try:
+        for mode in (0, 2, 1):
+            assert lib.gemmul8_set_fp8_bound_mode(mode) >= 0
+            Cd = gu.hip_gemm(A, B, N, fastmode=False, backend=g.FP8).astype(np.complex128)
+            rel = np.abs(Cd - exact) / abs(exact)
+            out[mode] = {"max_rel_err": float(rel.max()), "wrong_elements": int((rel > 1e-3).sum()), "elements": int(rel.size),
+                         "re_sign_flips": int((Cd.real < 0).sum())}
+    finally:
+        lib.gemmul8_set_fp8_bound_mode(0)
+    rec = {"N": N, "dtype": np.dtype(dtype).name, "k": A.shape[1], "prefloor_exact_T": float(v_exact), "prefloor_engine_round3": float(v_r3),
+           "prefloor_engine_default": float(v_new), "default": out[0], "round3_default": out[2], "reference": out[1]}
+    print("fp8 bound adversarial complex:", json.dumps(rec))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "fp8_bound_adversarial_complex.jsonl"), "a") as f:
+        f.write(json.dumps(rec) + "\n")
+    tol = 2.0 ** -20 if dtype == np.complex64 else 2.0 ** -40
+    assert out[0]["wrong_elements"] == 0 and out[0]["max_rel_err"] < tol, f"default combination: {out[0]}"
+
+
 def test_fp8_bound_never_below_exact_on_wide_rows():
     """Rows spanning > 20 binades with the big products scattered over the groups: the device's inflated maxima must not fall below
     the exactly accumulated ones (bounds_case asserts exactly that for real types)."""
@@ -129,3 +229,8 @@ def test_fp8_bound_never_below_exact_on_wide_rows():
     B = np.abs(rng.standard_normal((k, n))) * 2.0 ** rng.integers(-22, 1, (k, n))
     gu.bounds_case(A, B, 10, backend=g.FP8)
     gu.bounds_case(A.astype(np.float32), B.astype(np.float32), 6, backend=g.FP8)
+    # complex: wide rows with random signs -- the mixed-sign product C0 is far smaller than the magnitudes of its terms
+    Ac = A * np.exp(2j * np.pi * rng.random((m, k)))
+    Bc = B * np.exp(2j * np.pi * rng.random((k, n)))
+    gu.bounds_case(Ac, Bc, 10, backend=g.FP8)
+    gu.bounds_case(Ac.astype(np.complex64), Bc.astype(np.complex64), 6, backend=g.FP8)

@@ -40,13 +40,10 @@ def test_kat_sample_on_gpu():
         gu.parity_case(A, B, 15, fast)
 
 
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("dtype,N", [(np.float64, 2), (np.float64, 6), (np.float64, 7), (np.float64, 8), (np.float64, 14), (np.float64, 15), (np.float64, 16), (np.float64, 20), (np.float32, 2), (np.float32, 6), (np.float32, 7), (np.float32, 8)])  # float types: 2..13 moduli (more is rejected: tests/test_cabi.py)
 @pytest.mark.parametrize("fast", [False, True])
-@pytest.mark.parametrize("N", [2, 6, 7, 8, 14, 15, 16, 20])
 def test_parity_small_real(dtype, fast, N):
     import gpu_util as gu
-    if dtype == np.float32 and N > 13:
-        pytest.skip("float documented for N<=13")
     rng = np.random.default_rng(100 * N + fast)
     m, n, k = 37, 41, 300
     A, B = rand((m, k), dtype, rng), rand((k, n), dtype, rng)
@@ -88,13 +85,10 @@ def test_config1_sgemm_256_moduli2():
         gu.parity_case(A, B, 2, fast)
 
 
-@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+@pytest.mark.parametrize("dtype,N", [(np.complex128, 2), (np.complex128, 7), (np.complex128, 13), (np.complex128, 16), (np.complex128, 20), (np.complex64, 2), (np.complex64, 7), (np.complex64, 13)])  # float types: 2..13 moduli (more is rejected: tests/test_cabi.py)
 @pytest.mark.parametrize("fast", [False, True])
-@pytest.mark.parametrize("N", [2, 7, 13, 16, 20])
 def test_parity_small_complex(dtype, fast, N):
     import gpu_util as gu
-    if dtype == np.complex64 and N > 13:
-        pytest.skip("complex-float documented for N<=13")
     rng = np.random.default_rng(7000 + 10 * N + fast)
     m, n, k = 37, 41, 300
     A, B = rand((m, k), dtype, rng), rand((k, n), dtype, rng)
@@ -193,15 +187,12 @@ def test_fp8_rejects_k_beyond_exactness_bound():
         g.gemm(A, B, 6, backend=g.FP8)
 
 
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("dtype,N", [(np.float64, 2), (np.float64, 5), (np.float64, 6), (np.float64, 7), (np.float64, 12), (np.float64, 13), (np.float64, 20), (np.float32, 2), (np.float32, 5), (np.float32, 6), (np.float32, 7), (np.float32, 12), (np.float32, 13)])  # float types: 2..13 moduli (more is rejected: tests/test_cabi.py)
 @pytest.mark.parametrize("fast", [False, True])
-@pytest.mark.parametrize("N", [2, 5, 6, 7, 12, 13, 20])
 def test_parity_small_real_fp8(dtype, fast, N):
     """FP8-e4m3 backend (gemmLt<T,FP8> in the reference): e4m3 planes, int16 C_mid, final C -- bit-exact."""
     import gemmul8_amd as g
     import gpu_util as gu
-    if dtype == np.float32 and N > 13:
-        pytest.skip("float documented for N<=13")
     rng = np.random.default_rng(300 * N + fast)
     m, n, k = 37, 41, 300
     A, B = rand((m, k), dtype, rng), rand((k, n), dtype, rng)
@@ -222,16 +213,13 @@ def test_parity_shapes_fp8(m, n, k):
     gu.parity_case(Ad, Bd, 13, False, backend=g.FP8, alpha=-1.5, beta=1.5, C0=rand((m, n), np.float64, rng))
 
 
-@pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
+@pytest.mark.parametrize("dtype,N", [(np.complex128, 2), (np.complex128, 6), (np.complex128, 7), (np.complex128, 13), (np.complex128, 20), (np.complex64, 2), (np.complex64, 6), (np.complex64, 7), (np.complex64, 13)])  # float types: 2..13 moduli (more is rejected: tests/test_cabi.py)
 @pytest.mark.parametrize("fast", [False, True])
-@pytest.mark.parametrize("N", [2, 6, 7, 13, 20])
 def test_parity_small_complex_fp8(dtype, fast, N):
     """FP8 backend, complex types: 9 e4m3 GEMMs per modulus (gemmul8_complex.hpp:170-195), three separately inflated bound
     products in accurate mode, interleaved int16 (Cr, Ci) planes -- bit-exact against the oracle."""
     import gemmul8_amd as g
     import gpu_util as gu
-    if dtype == np.complex64 and N > 13:
-        pytest.skip("float documented for N<=13")
     rng = np.random.default_rng(700 * N + fast)
     m, n, k = 37, 41, 300
     A, B = rand((m, k), dtype, rng), rand((k, n), dtype, rng)

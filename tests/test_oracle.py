@@ -37,11 +37,10 @@ def test_kat_sample(backend, N, fast):
             assert float(ex) == Cx[i, j]
 
 
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("N,fast", [(2, True), (5, False), (8, True), (14, False), (16, False), (20, True)])
+@pytest.mark.parametrize("dtype,N,fast", [(np.float64, 2, True), (np.float64, 5, False), (np.float64, 8, True), (np.float64, 14, False),
+                                          (np.float64, 16, False), (np.float64, 20, True), (np.float32, 2, True), (np.float32, 5, False),
+                                          (np.float32, 8, True), (np.float32, 13, False)])  # float types: 2..13 moduli (gemmul8.hpp:30)
 def test_bigint_identities_real(dtype, N, fast):
-    if dtype == np.float32 and N > 13:
-        pytest.skip("float path documented for N<=13")
     rng = np.random.default_rng(1000 + N)
     m, n, k = 7, 5, 19
     A = ((rng.random((m, k)) - 0.5) * np.exp(2 * rng.standard_normal((m, k)))).astype(dtype)
