@@ -88,7 +88,6 @@ static Knobs parse_knobs() {
     if (const int c = num("GEMMUL8_CPLX_CHUNK", 0); c >= 1) k.cplx_chunk = c;
     if (const char* e = getenv("GEMMUL8_CRT_KERNEL")) k.crt_kernel = e[0] == 'd' ? 1 : e[0] == 'r' ? 2 : 0;
     if (const char* e = getenv("GEMMUL8_MAP_COLBLOCK"); e && *e) k.map_colblock = atoi(e) > 0 ? atoi(e) : 0;
-    if (const char* e = getenv("GEMMUL8_SHORTK"); e && (e[0] == '0' || e[0] == '1') && !e[1]) k.short_k = e[0] - '0';
     return k;
 }
 static std::atomic<const Knobs*> g_knobs{nullptr};

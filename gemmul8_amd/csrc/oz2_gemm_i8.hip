@@ -52,25 +52,6 @@
 
 namespace oz2 {
 
-// ---- Laboratory boundary.  This translation unit is the PRODUCT: it instantiates exactly the kernels gemmul8_gemm can reach and carries
-// no timing ablation.  Laboratory builds (tools/experiments/: real-data timing probes, the in-kernel CRT forms) compile a second TU that
-// defines OZ2_LAB_* and #includes this file; the shipped Makefile passes -DOZ2_PRODUCT_BUILD, which refuses every such macro, so no
-// -D in EXTRA can turn libgemmul8.so into a library with wrong results.
-#if defined(OZ2_PRODUCT_BUILD) && (defined(OZ2_LAB_HOOKS) || defined(OZ2_LAB_FUSED_CRT))
-#error "laboratory switches (OZ2_LAB_*) are not allowed in the product build of libgemmul8.so: use tools/experiments/"
-#endif
-#ifdef OZ2_LAB_HOOKS
-#include OZ2_LAB_HOOKS  // tools/experiments/probes/lab_hooks.hpp: redefines the three hook points below (timing probes on real data)
-#endif
-#ifndef OZ2_HOOK_DMA_ON
-#define OZ2_HOOK_DMA_ON(first_tile) true  // producers: issue the LDS-DMA of this K-step
-#endif
-#ifndef OZ2_HOOK_KSTEP
-#define OZ2_HOOK_KSTEP(kin) (kin)         // producers: K-step of the segment whose panel is fetched
-#endif
-#ifndef OZ2_HOOK_SKIP_EPILOGUE
-#define OZ2_HOOK_SKIP_EPILOGUE 0          // consumers: 1 = keep the accumulators live, no epilogue
-#endif
 #ifndef OZ2_PB
 #define OZ2_PB 4
 #endif
@@ -444,6 +425,11 @@ template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int
     // (the bound GEMM keeps the ping-pong schedule at every k.  In round 2 its K-step-barrier instantiation spilled accumulators INSIDE
     // the MFMA loop; with the round-3 source it no longer does, but the single-plane launch still runs slower with it: bounds phase
     // 88.4 -> 92.4 us at 3072^3, 130.9 -> 134.6 at 4096^3, equal at 2048^3 and 8192^3.  round-3 A/B: profiles/r03_bound_ab.txt)
+#ifdef OZ2_LAB_SHORTK  // laboratory build only (tools/experiments/shortk): the half-tile ping-pong kernel for padded k <= OZ2_LAB_SHORTK
+    if constexpr (EPI != EPI_MAX) {
+        if (a.nseg == 1 && a.kp <= OZ2_LAB_SHORTK) return launch_gemm_i8_shortk(stream, a, EPI);
+    }
+#endif
     if (EPI != EPI_MAX && a.kp * a.nseg <= OZ2_KBAR_MAX_KP) return launch_sched<EPI, true>(stream, a);
     return launch_sched<EPI, false>(stream, a);
 }

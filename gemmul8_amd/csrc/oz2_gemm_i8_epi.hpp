@@ -11,6 +11,26 @@
 
 namespace oz2 {
 
+// ---- Laboratory boundary.  The INT8 GEMM translation units (oz2_gemm_i8.hip, oz2_gemm_i8_shortk.hip) are the PRODUCT: they instantiate exactly the kernels gemmul8_gemm can reach and carry
+// no timing ablation.  Laboratory builds (tools/experiments/: real-data timing probes, the in-kernel CRT forms) compile a second TU that
+// defines OZ2_LAB_* and #includes this file; the shipped Makefile passes -DOZ2_PRODUCT_BUILD, which refuses every such macro, so no
+// -D in EXTRA can turn libgemmul8.so into a library with wrong results.
+#if defined(OZ2_PRODUCT_BUILD) && (defined(OZ2_LAB_HOOKS) || defined(OZ2_LAB_FUSED_CRT) || defined(OZ2_LAB_SHORTK))
+#error "laboratory switches (OZ2_LAB_*) are not allowed in the product build of libgemmul8.so: use tools/experiments/"
+#endif
+#ifdef OZ2_LAB_HOOKS
+#include OZ2_LAB_HOOKS  // tools/experiments/probes/lab_hooks.hpp: redefines the three hook points below (timing probes on real data)
+#endif
+#ifndef OZ2_HOOK_DMA_ON
+#define OZ2_HOOK_DMA_ON(first_tile) true  // producers: issue the LDS-DMA of this K-step
+#endif
+#ifndef OZ2_HOOK_KSTEP
+#define OZ2_HOOK_KSTEP(kin) (kin)         // producers: K-step of the segment whose panel is fetched
+#endif
+#ifndef OZ2_HOOK_SKIP_EPILOGUE
+#define OZ2_HOOK_SKIP_EPILOGUE 0          // consumers: 1 = keep the accumulators live, no epilogue
+#endif
+
 enum { EPI_MOD = 0, EPI_MAX = 1, EPI_CPLX = 2 };
 
 struct GemmArgs {
@@ -64,8 +84,8 @@ enum { RED_GENERIC = 0, RED_ODD = 1, RED_256 = 2, RED_ODD_SMALL = 3 };
 // the kernel time at k = 1024.  (Reading the quotient from the low dword of fma(a, 1/p, 1.5 * 2^52) and finishing with
 // v_mad_i32_i24 -- three instructions -- measured 10 % SLOWER at k = 1024: the dependent FP64 chains no longer overlap.)
 // RED_GENERIC: 32-bit multiply-high (even p other than 256: no INT8 modulus, kept for completeness).
-// Hook: called as hook(s, 0) before and hook(s, 1) after the stores of sub-block s = 2 tj + tg (64 rows x 16 columns; 8 per wave tile): the
-// short-K kernel places its workgroup barriers and its LDS-DMA wait there (oz2_gemm_i8_shortk.hip); NoHook elsewhere.
+// Hook: called as hook(s, 0) before and hook(s, 1) after the stores of sub-block s = 2 tj + tg (64 rows x 16 columns; 8 per wave tile); NoHook
+// (nothing) in every product kernel -- the laboratory short-K kernel places its workgroup barriers there (tools/experiments/shortk).
 struct NoHook {
     __device__ __forceinline__ void operator()(int, int) const {}
 };
@@ -232,5 +252,9 @@ __device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmAr
     }
 }
 
+
+#ifdef OZ2_LAB_SHORTK  // laboratory kernel (tools/experiments/shortk/oz2_gemm_i8_shortk.hip); `a` complete as launch<EPI> of oz2_gemm_i8.hip leaves it
+hipError_t launch_gemm_i8_shortk(hipStream_t stream, const GemmArgs& a, int epi);
+#endif
 
 }  // namespace oz2

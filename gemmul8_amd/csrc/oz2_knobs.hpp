@@ -13,7 +13,6 @@ struct Knobs {
     int cplx_chunk = 0;            // GEMMUL8_CPLX_CHUNK=<n>: moduli per X / Y / Z launch group of the complex INT8 path (0: as many as the scratch holds)
     int crt_kernel = 0;            // GEMMUL8_CRT_KERNEL=dma|reg: force the LDS-DMA (1) / register (2) form of the CRT kernel (0: by eligibility and size)
     int map_colblock = -1;         // GEMMUL8_MAP_COLBLOCK=<w>: tile-columns per column block of the GEMM tile walk, 0 = full width (-1: map_colblock's rule)
-    int short_k = -1;              // GEMMUL8_SHORTK=0|1: never / always (when legal) the short-K INT8 kernel (-1: by k)
 };
 const Knobs& knobs();  // oz2_driver.hip
 void reload_knobs();

@@ -163,7 +163,7 @@ GEMMUL8_API int gemmul8_set_fp8_bound_mode(int mode);
 GEMMUL8_API int gemmul8_hook_would_emulate(int dtype, int backend, size_t m, size_t n, size_t k, unsigned num_moduli, int fastmode,
                                            size_t batch);
 
-/* Testing / A-B knobs (GEMMUL8_EPI_NT, _BOUND_TILE, _CPLX_BOUND_LAUNCHES, _CPLX_CHUNK, _CRT_KERNEL, _MAP_COLBLOCK, _SHORTK; INTEGRATION.md
+/* Testing / A-B knobs (GEMMUL8_EPI_NT, _BOUND_TILE, _CPLX_BOUND_LAUNCHES, _CPLX_CHUNK, _CRT_KERNEL, _MAP_COLBLOCK; INTEGRATION.md
  * "Testing switches"): every one selects between bit-identical code paths.  They are parsed from the environment ONCE, at the first
  * launch; a test harness that changes the environment inside one process calls this afterwards.  No counterpart in the reference. */
 GEMMUL8_API void gemmul8_reload_knobs(void);
