@@ -214,6 +214,68 @@ def event_pair():
     return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
 
+def single_gpu_phases(args, n, N, A, B, dev, stream):
+    """Phase times of the single-GPU call (bounds | quantise | INT8 GEMMs | CRT, ms; events on the launch stream, mean of 3 calls after one
+    warm-up): the inputs of plan_model."""
+    import ctypes as C
+    import gemmul8_amd as g
+    lib = g.lib()
+    Cmat = torch.zeros((n, n), dtype=torch.float64, device=dev)
+    one, zero = np.array([1.0]), np.array([0.0])
+    tot, _, _ = g.work_size(False, g.INT8, n, n, n, N)
+    work = torch.empty(tot, dtype=torch.uint8, device=dev)
+    L = g.Layout()
+    g.check(lib.gemmul8_get_layout(g.D, g.INT8, n, n, n, N, work.data_ptr(), None, None, 0, 0, C.byref(L)))
+    st = stream.cuda_stream
+    acc = np.zeros(4)
+    for it in range(4):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev[0].record(stream)
+        if not args.fast:
+            g.check(lib.gemmul8_scale_bounds(st, g.D, g.INT8, 0, 0, n, n, n, A.data_ptr(), n, B.data_ptr(), n, N, 0, n, C.byref(L), 0, 0))
+        ev[1].record(stream)
+        g.check(lib.gemmul8_scale_finish(st, g.D, g.INT8, 0, 0, n, n, n, A.data_ptr(), n, B.data_ptr(), n, N, int(args.fast), 0, N, C.byref(L), 0, 0))
+        ev[2].record(stream)
+        g.check(lib.gemmul8_lowprec_gemm(st, g.D, g.INT8, n, n, n, N, 0, N, C.byref(L)))
+        ev[3].record(stream)
+        g.check(lib.gemmul8_crt(st, g.D, g.INT8, N, n, n, L.C_mid, L.mp, L.sizeC, L.sftA, L.sftB, one.ctypes.data, zero.ctypes.data, Cmat.data_ptr(), n))
+        ev[4].record(stream)
+        torch.cuda.synchronize()
+        if it:
+            acc += np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(4)])
+    del work, Cmat
+    return dict(zip(("bounds", "quantise", "lowprec_gemm", "crt"), (acc / 3).tolist()))
+
+
+def plan_model(name, world, N, n, ph, grid):
+    """DESIGN.md 5's per-rank time model of a plan, from the single-GPU phase times `ph` measured in this run -- so that the first curve
+    measured on an 8-GPU node can be held against a prediction made before it existed.  Assumptions (all stated in the JSON):
+      * every kernel scales with the share of rows / columns / moduli a rank works on (no efficiency loss on smaller problems);
+      * bounds phase = 30 % A side (amax + extract), 17 % B side (extract), 53 % bound GEMM; quantise = 52 % A, 48 % B (DESIGN.md 3);
+      * an all-reduce(MAX) of 4 (m + n) bytes: 0.05 ms; point-to-point: every xGMI peer link carries 45 GB/s per direction, all peers at
+        once; reduce-scatter of FP64 partials: ring over min(G - 1, 7) links in parallel at the same rate."""
+    G = world
+    gr, gc = grid
+    b, q, gm, cr = ph["bounds"], ph["quantise"], ph["lowprec_gemm"], ph["crt"]
+    link = 45e9
+    ar = 0.05 if (b > 0 and G > 1) else 0.0
+    mr = -(-N // G)  # moduli of the busiest rank
+    if name == "blocks":
+        terms = {"bounds": b * (0.30 / gr + 0.17 / gc + 0.53 / G), "quantise": q * (0.52 / gr + 0.48 / gc), "lowprec_gemm": gm / G, "crt": cr / G,
+                 "allreduce": ar, "exchange": 0.0}
+    elif name == "moduli":
+        out_bytes = (G - 1) / G * mr * n * n                    # INT8 residue blocks this rank sends; (G - 1) peers in parallel
+        terms = {"bounds": b * (0.30 + 0.17 / G + 0.53 / G), "quantise": q * mr / N, "lowprec_gemm": gm * mr / N, "crt": cr / G, "allreduce": ar,
+                 "exchange": (out_bytes / max(1, G - 1)) / link * 1e3 if G > 1 else 0.0}
+    else:  # fp64sum
+        part_bytes = (mr + 16.0) * n * n                        # partial CRT: read mr residue planes, write two double planes
+        rs_bytes = (G - 1) / G * 16.0 * n * n
+        terms = {"bounds": b * (0.30 + 0.17 / G + 0.53 / G), "quantise": q * mr / N, "lowprec_gemm": gm * mr / N,
+                 "crt": part_bytes / 5.0e12 * 1e3 + cr / G * 0.5, "allreduce": ar,
+                 "exchange": rs_bytes / (link * max(1, min(G - 1, 7))) * 1e3 if G > 1 else 0.0}
+    return {"model_ms": float(sum(terms.values())), "model_terms_ms": {k_: float(v) for k_, v in terms.items()}}
+
+
 def run_plans(args, n, N, A, B, dev, stream, backend, rank, world):
     """N > 1: every plan of include/gemmul8_dist.h in ONE invocation (blocks, moduli, fp64sum), each with `warmup` untimed and `steps`
     timed calls bracketed by barrier + synchronize, max over ranks.  Returns (records by plan name, gathered C of the headline plan,
@@ -224,6 +286,30 @@ def run_plans(args, n, N, A, B, dev, stream, backend, rank, world):
     comm = gd.RcclComm() if backend == "nccl" else gd.TorchTransport(device=True)
     rccl_ranks = comm.rccl_ranks()
     peak = 5000.0
+    # First contact with the transport, before anything is timed (GEMMUL8_DIST_SELFTEST=0 skips it): communicator size, all-reduce(MAX),
+    # grouped send/recv ring, reduce-scatter(sum) against host arithmetic -- a failure ends the run with ONE line that says which
+    selftest = "skipped"
+    if os.environ.get("GEMMUL8_DIST_SELFTEST", "1") != "0":
+        ok, msg = gd.selftest(comm, dev, stream.cuda_stream, expect_rccl=(backend == "nccl"))
+        flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if not ok:
+            print(f"[bench] DIST SELFTEST FAILED: {msg}", file=sys.stderr, flush=True)
+        if int(flag.item()) != 0:
+            if rank == 0:
+                print(json.dumps({"metric": f"emulated DGEMM TFLOPS (N={n}, moduli={N})", "value": None, "n_gpus": world, "error": "dist selftest failed",
+                                  "dist_selftest": msg if not ok else "failed on another rank (see stderr)"}))
+            comm.close()
+            dist.barrier()
+            dist.destroy_process_group()
+            sys.exit(3)
+        selftest = "ok: ncclCommCount, all-reduce(MAX,int32), grouped send/recv ring, reduce-scatter(sum,f64) checked against host arithmetic" if backend == "nccl" \
+            else "ok (gloo test transport): all-reduce(MAX,int32), grouped send/recv ring, reduce-scatter(sum,f64) checked against host arithmetic"
+    # single-GPU phase times on rank 0 (the other ranks wait): the inputs of the per-plan time model in the JSON
+    phases = None
+    if rank == 0:
+        phases = single_gpu_phases(args, n, N, A, B, dev, stream)
+    dist.barrier()
 
     def barrier():
         dist.barrier()
@@ -283,11 +369,16 @@ def run_plans(args, n, N, A, B, dev, stream, backend, rank, world):
         if rank == 0:
             gathered[name] = full.clone()
             rec["max_rel_err"] = sampled_error(A, B, full, n)
+            gr = max(1, round(n / max(1, plan.work_rows))) if name == "blocks" else 1   # rank 0 owns the first row block of the Gr x Gc grid
+            rec.update(plan_model(name, world, N, n, phases, (gr, max(1, world // gr))))
         results[name] = rec
         plan.close()
         barrier()
     info = {"transport": "RCCL (ncclCommInitRank inside libgemmul8.so)" if backend == "nccl" else f"gloo TEST transport, host-staged ({world} ranks on {torch.cuda.device_count()} GPU(s))",
-            "rccl_ranks": rccl_ranks}
+            "rccl_ranks": rccl_ranks, "dist_selftest": selftest, "single_gpu_phase_ms": phases,
+            "model_assumptions": "plans[*].model_ms = DESIGN.md 5's per-rank model from single_gpu_phase_ms: kernels scale with the rank's share; bounds = 30 % A side + 17 % B "
+                                 "side + 53 % bound GEMM; quantise 52 % A / 48 % B; all-reduce(MAX) 0.05 ms; 45 GB/s per xGMI peer link and direction, all peers at once; "
+                                 "FP64 reduce-scatter as a ring over min(G-1, 7) links"}
     headline = None
     if rank == 0:
         ref = gathered["moduli"]

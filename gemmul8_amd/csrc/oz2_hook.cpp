@@ -19,12 +19,17 @@
 //   per-handle state under a mutex: three grow-only stream-ordered buffers (hipMallocAsync /
 //   hipFreeAsync), event hand-off when the handle's stream changes, skip-scaling cache
 //   (hook.cu:70-162,331-374,684-727); hipblasDestroy frees the state first (hook.cu:846-856).
+//   GEMMUL8_HOOK_ROCBLAS=1 (this build only) also intercept rocblas_{s,d,c,z}gemm, their strided-batched forms and rocblas_gemm_ex: callers
+//                     that use rocBLAS directly (HPL-style codes) -- NOT rocSOLVER, whose factorizations call rocBLAS's internal C++ templates
+//                     (INTEGRATION.md "What the hook reaches")
+//   GEMMUL8_HOOK_STATS=1 print at exit how many GEMM calls / flops were emulated and how many went to the native routines
 // This file has no kernels and calls no BLAS routine itself.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <hipblas/hipblas.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -419,6 +424,32 @@ bool try_dist(int kind, int dtype, int backend, hipblasOperation_t ta, hipblasOp
 // (r03_floor_scan2_*.csv, not used for the fit) it stays within 0.4-12 % (tests/test_hook_floor.py).  The FP8 backend costs ~2.2x
 // the INT8 one.
 // GEMMUL8_MIN_FLOPS unset / 0 = the reference's behaviour (emulate every call); any other number is a plain floor on 2*m*n*k per call.
+// GEMMUL8_HOOK_STATS=1: how much of an application's GEMM work the hook reaches (tests/test_gpu_hook_reach.py)
+struct HookStats {
+    std::atomic<unsigned long long> emu_calls{0}, nat_calls{0};
+    std::atomic<unsigned long long> emu_mflops{0}, nat_mflops{0};  // 2 m n k batch / 1e6 (x 4 for complex), rounded down
+    static void dump();
+    HookStats() { std::atexit(&HookStats::dump); }
+};
+HookStats& hook_stats() {
+    static HookStats* st = new HookStats;  // leaked on purpose: dumped from atexit
+    return *st;
+}
+void HookStats::dump() {
+    if (!env_one("GEMMUL8_HOOK_STATS")) return;
+    HookStats& h = hook_stats();
+    std::fprintf(stderr, "[GEMMUL8 HOOK] stats: emulated %llu GEMM calls (%.3f TFLOP), native %llu GEMM calls through the hooked entry points (%.3f TFLOP)\n",
+                 h.emu_calls.load(), h.emu_mflops.load() * 1e-6, h.nat_calls.load(), h.nat_mflops.load() * 1e-6);
+}
+void count_call(bool emulated, int dtype, double m, double n, double k, double batch = 1.0) {
+    static const bool on = env_one("GEMMUL8_HOOK_STATS");
+    if (!on) return;
+    HookStats& h = hook_stats();
+    const unsigned long long mf = (unsigned long long)(2.0 * m * n * k * batch * (dtype >= 2 ? 4.0 : 1.0) * 1e-6);
+    (emulated ? h.emu_calls : h.nat_calls).fetch_add(1, std::memory_order_relaxed);
+    (emulated ? h.emu_mflops : h.nat_mflops).fetch_add(mf, std::memory_order_relaxed);
+}
+
 struct FloorModel {
     double e[6];  // ms: 1, (m+n)k, N(m+n)k, mn, N mn, N mnk
     double n[3];  // ms: 1, mn, mnk
@@ -472,9 +503,9 @@ extern "C" GEMMUL8_API int gemmul8_hook_would_emulate(int dtype, int backend, si
 }
 namespace {
 // explicit_stream: hipblasLtMatmul carries its stream as an argument (a hipblasLt handle has none)
-bool try_emulate(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, hipblasOperation_t tb, int m, int n, int k, const void* alpha,
-                 const void* A, int lda, const void* B, int ldb, const void* beta, void* C, int ldc, hipblasStatus_t* status,
-                 const hipStream_t* explicit_stream = nullptr) {
+bool try_emulate_impl(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, hipblasOperation_t tb, int m, int n, int k, const void* alpha,
+                      const void* A, int lda, const void* B, int ldb, const void* beta, void* C, int ldc, hipblasStatus_t* status,
+                      const hipStream_t* explicit_stream) {
     const TypeInfo& ti = kTypes[dtype];
     const unsigned N = (unsigned)env_u64(ti.nmod, 0);
     if (N < 2u || N > ti.max_moduli) return false;
@@ -552,6 +583,14 @@ bool try_emulate(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, hipbl
     u.workA = sp->wA.ptr, u.workB = sp->wB.ptr;
     u.dtype = dtype, u.backend = backend, u.fastmode = fastmode;
     return *status = HIPBLAS_STATUS_SUCCESS, true;
+}
+// counted front end (GEMMUL8_HOOK_STATS): true = the call was served here (emulated, or failed with *status set); false = native routine
+bool try_emulate(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, hipblasOperation_t tb, int m, int n, int k, const void* alpha,
+                 const void* A, int lda, const void* B, int ldb, const void* beta, void* C, int ldc, hipblasStatus_t* status,
+                 const hipStream_t* explicit_stream = nullptr) {
+    const bool served = try_emulate_impl(dtype, handle, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, status, explicit_stream);
+    count_call(served, dtype, m, n, k);
+    return served;
 }
 
 // lt: the key is a hipblasLtHandle_t (hipblasLtDestroy) -- hipblasGetStream on such an object would be a type confusion
@@ -781,7 +820,7 @@ static bool emulate_batch(int dtype, size_t elem, hipblasHandle_t handle, hipbla
                                               (char*)C + (long long)b0 * sc * (long long)elem, (size_t)ldc, sc, nb, N, fastmode, sp->wC.ptr);
                     if (rc < 0 && b0 > 0) rc = 1;  // declined after earlier chunks were written: cannot hand the call to another path
                 }
-                if (rc == 0) return true;
+                if (rc == 0) return count_call(true, dtype, m, n, k, (double)batch), true;
                 if (rc > 0) return *status = HIPBLAS_STATUS_INTERNAL_ERROR, true;
                 // negative on the first chunk: declined (nothing written) -- fall through to the per-item path
             } else {
@@ -898,6 +937,162 @@ hipblasStatus_t hipblasGemmStridedBatchedEx(hipblasHandle_t handle, hipblasOpera
                 : HIPBLAS_STATUS_NOT_INITIALIZED;
 }
 
+
+// ---- rocBLAS entry points, opt-in with GEMMUL8_HOOK_ROCBLAS=1 (no counterpart in the reference: src/hook.cu:846-1055 hooks the cuBLAS / hipBLAS
+// names only).  For applications that call rocBLAS directly.  The handle of a hipBLAS call IS the rocBLAS handle, so a call the hipBLAS hooks
+// above declined arrives here again through the real hipBLAS and is declined again by the same rules.  rocSOLVER / hipSOLVER factorizations do
+// NOT come through here: they call rocBLAS's internal C++ templates, not these exported C entry points (INTEGRATION.md "What the hook
+// reaches", tests/test_gpu_hook_reach.py).  rocblas_operation / rocblas_status are plain ints here (111 / 112 / 113 = the hipBLAS values;
+// 0 = success, 6 = internal error); rocblas_int is 32-bit in this build of rocBLAS (rocblas-types.h:79).
+}  // extern "C"
+#pragma GCC visibility pop
+namespace {
+void* mapped_rocblas() {
+    static void* h = mapped_library("librocblas.so");
+    return h;
+}
+template <typename Fn> Fn real_rocblas(const char* name) {
+    void* f = dlsym(RTLD_NEXT, name);
+    if (!f)
+        if (void* h = mapped_rocblas()) f = dlsym(h, name);
+    return reinterpret_cast<Fn>(f);
+}
+bool rocblas_stream(void* handle, hipStream_t* s) {
+    using Fn = int (*)(void*, hipStream_t*);
+    static Fn fn = real_rocblas<Fn>("rocblas_get_stream");
+    return fn && fn(handle, s) == 0;
+}
+int rocblas_status_of(hipblasStatus_t st) { return st == HIPBLAS_STATUS_SUCCESS ? 0 : st == HIPBLAS_STATUS_ALLOC_FAILED ? 5 : 6; }
+}  // namespace
+#pragma GCC visibility push(default)
+extern "C" {
+
+int rocblas_destroy_handle(void* handle) {
+    if (handle) release_state((hipblasHandle_t)handle, true);
+    using Fn = int (*)(void*);
+    static Fn real = real_rocblas<Fn>("rocblas_destroy_handle");
+    return real ? real(handle) : 6;
+}
+
+#define OZ2_ROCBLAS_GEMM_HOOK(NAME, T, CODE)                                                                                             \
+    int NAME(void* handle, int transA, int transB, int m, int n, int k, const T* alpha, const T* A, int lda, const T* B, int ldb,        \
+             const T* beta, T* C, int ldc) {                                                                                             \
+        using Fn = int (*)(void*, int, int, int, int, int, const T*, const T*, int, const T*, int, const T*, T*, int);                   \
+        static Fn real = real_rocblas<Fn>(#NAME);                                                                                        \
+        hipStream_t s_;                                                                                                                  \
+        hipblasStatus_t st_;                                                                                                             \
+        if (env_one("GEMMUL8_HOOK_ROCBLAS") && handle && m > 0 && n > 0 && k > 0 && alpha && A && B && beta && C &&                      \
+            transA >= 111 && transA <= 113 && transB >= 111 && transB <= 113 && rocblas_stream(handle, &s_) &&                           \
+            try_emulate(CODE, (hipblasHandle_t)handle, (hipblasOperation_t)transA, (hipblasOperation_t)transB, m, n, k, alpha, A, lda, B, \
+                        ldb, beta, C, ldc, &st_, &s_))                                                                                   \
+            return rocblas_status_of(st_);                                                                                               \
+        return real ? real(handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc) : 6;                                    \
+    }
+OZ2_ROCBLAS_GEMM_HOOK(rocblas_sgemm, float, GEMMUL8_S)
+OZ2_ROCBLAS_GEMM_HOOK(rocblas_dgemm, double, GEMMUL8_D)
+OZ2_ROCBLAS_GEMM_HOOK(rocblas_cgemm, hipComplex, GEMMUL8_C)
+OZ2_ROCBLAS_GEMM_HOOK(rocblas_zgemm, hipDoubleComplex, GEMMUL8_Z)
+#undef OZ2_ROCBLAS_GEMM_HOOK
+
+#define OZ2_ROCBLAS_SB_HOOK(NAME, T, CODE)                                                                                               \
+    int NAME(void* handle, int transA, int transB, int m, int n, int k, const T* alpha, const T* A, int lda, long long strideA,          \
+             const T* B, int ldb, long long strideB, const T* beta, T* C, int ldc, long long strideC, int batchCount) {                  \
+        using Fn = int (*)(void*, int, int, int, int, int, const T*, const T*, int, long long, const T*, int, long long, const T*, T*,   \
+                           int, long long, int);                                                                                         \
+        static Fn real = real_rocblas<Fn>(#NAME);                                                                                        \
+        hipStream_t s_;                                                                                                                  \
+        hipblasStatus_t st_;                                                                                                             \
+        if (env_one("GEMMUL8_HOOK_ROCBLAS") && handle && m > 0 && n > 0 && k > 0 && batchCount > 0 && alpha && A && B && beta && C &&    \
+            transA >= 111 && transA <= 113 && transB >= 111 && transB <= 113 && rocblas_stream(handle, &s_) &&                           \
+            emulate_batch(CODE, sizeof(T), (hipblasHandle_t)handle, (hipblasOperation_t)transA, (hipblasOperation_t)transB, m, n, k,     \
+                          alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batchCount, &st_, &s_))                        \
+            return rocblas_status_of(st_);                                                                                               \
+        return real ? real(handle, transA, transB, m, n, k, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batchCount) : 6; \
+    }
+OZ2_ROCBLAS_SB_HOOK(rocblas_sgemm_strided_batched, float, GEMMUL8_S)
+OZ2_ROCBLAS_SB_HOOK(rocblas_dgemm_strided_batched, double, GEMMUL8_D)
+OZ2_ROCBLAS_SB_HOOK(rocblas_cgemm_strided_batched, hipComplex, GEMMUL8_C)
+OZ2_ROCBLAS_SB_HOOK(rocblas_zgemm_strided_batched, hipDoubleComplex, GEMMUL8_Z)
+#undef OZ2_ROCBLAS_SB_HOOK
+
+// rocSOLVER / hipSOLVER factorizations (getrf, geqrf, potrf ...: what torch.linalg.lu_factor / solve / qr run on) do not call the C entry
+// points above: their trailing updates go through rocBLAS's exported C++ template rocblas_internal_gemm_template<T> (and its _64 form).
+// Those ARE dynamic symbols, so the same opt-in interposes them -- by their mangled names, which belong to THIS rocBLAS ABI (ROCm 7.2:
+// nm -D librocsolver.so | grep internal_gemm); if a later rocBLAS changes the signature the names no longer match, nothing is intercepted,
+// and tests/test_gpu_hook_reach.py says so.  Strided batch (batch_count > 1) and element offsets as rocBLAS defines them.
+}  // extern "C"
+template <typename T, typename I>
+static int rocblas_internal_gemm_hook(const char* mangled, int code, void* handle, int transA, int transB, I m, I n, I k, const T* alpha, const T* A,
+                                      long offA, I lda, long strideA, const T* B, long offB, I ldb, long strideB, const T* beta, T* C, long offC,
+                                      I ldc, long strideC, I batch) {
+    using Fn = int (*)(void*, int, int, I, I, I, const T*, const T*, long, I, long, const T*, long, I, long, const T*, T*, long, I, long, I);
+    Fn real = real_rocblas<Fn>(mangled);
+    hipStream_t s_;
+    hipblasStatus_t st_;
+    const bool fits = m > 0 && n > 0 && k > 0 && batch > 0 && (long long)m <= 2147483647 && (long long)n <= 2147483647 && (long long)k <= 2147483647 &&
+                      (long long)lda <= 2147483647 && (long long)ldb <= 2147483647 && (long long)ldc <= 2147483647 && (long long)batch <= 2147483647;
+    if (fits && env_one("GEMMUL8_HOOK_ROCBLAS") && handle && alpha && A && B && beta && C && transA >= 111 && transA <= 113 && transB >= 111 &&
+        transB <= 113 && rocblas_stream(handle, &s_)) {
+        const T *Ao = A + offA, *Bo = B + offB;
+        T* Co = C + offC;
+        const bool served = batch == 1 ? try_emulate(code, (hipblasHandle_t)handle, (hipblasOperation_t)transA, (hipblasOperation_t)transB, (int)m, (int)n,
+                                                     (int)k, alpha, Ao, (int)lda, Bo, (int)ldb, beta, Co, (int)ldc, &st_, &s_)
+                                       : emulate_batch(code, sizeof(T), (hipblasHandle_t)handle, (hipblasOperation_t)transA, (hipblasOperation_t)transB,
+                                                       (int)m, (int)n, (int)k, alpha, Ao, (int)lda, strideA, Bo, (int)ldb, strideB, beta, Co, (int)ldc,
+                                                       strideC, (int)batch, &st_, &s_);
+        if (served) return rocblas_status_of(st_);
+    }
+    return real ? real(handle, transA, transB, m, n, k, alpha, A, offA, lda, strideA, B, offB, ldb, strideB, beta, C, offC, ldc, strideC, batch) : 6;
+}
+extern "C" {
+#define OZ2_ROCBLAS_INTERNAL(FN, T, CODE, SYM32, SYM64)                                                                                   \
+    int FN##_32(void* h, int ta, int tb, int m, int n, int k, const T* al, const T* A, long oa, int lda, long sa, const T* B, long ob, int ldb, \
+                long sb, const T* be, T* C, long oc, int ldc, long sc, int bc) __asm__(SYM32);                                            \
+    int FN##_32(void* h, int ta, int tb, int m, int n, int k, const T* al, const T* A, long oa, int lda, long sa, const T* B, long ob, int ldb, \
+                long sb, const T* be, T* C, long oc, int ldc, long sc, int bc) {                                                          \
+        return rocblas_internal_gemm_hook<T, int>(SYM32, CODE, h, ta, tb, m, n, k, al, A, oa, lda, sa, B, ob, ldb, sb, be, C, oc, ldc, sc, bc); \
+    }                                                                                                                                     \
+    int FN##_64(void* h, int ta, int tb, long m, long n, long k, const T* al, const T* A, long oa, long lda, long sa, const T* B, long ob,  \
+                long ldb, long sb, const T* be, T* C, long oc, long ldc, long sc, long bc) __asm__(SYM64);                                \
+    int FN##_64(void* h, int ta, int tb, long m, long n, long k, const T* al, const T* A, long oa, long lda, long sa, const T* B, long ob,  \
+                long ldb, long sb, const T* be, T* C, long oc, long ldc, long sc, long bc) {                                              \
+        return rocblas_internal_gemm_hook<T, long>(SYM64, CODE, h, ta, tb, m, n, k, al, A, oa, lda, sa, B, ob, ldb, sb, be, C, oc, ldc, sc, bc); \
+    }
+OZ2_ROCBLAS_INTERNAL(oz2_rb_int_gemm_s, float, GEMMUL8_S,
+                     "_Z30rocblas_internal_gemm_templateIfE15rocblas_status_P15_rocblas_handle18rocblas_operation_S3_iiiPKT_S6_lilS6_lilS6_PS4_lili",
+                     "_Z33rocblas_internal_gemm_template_64IfE15rocblas_status_P15_rocblas_handle18rocblas_operation_S3_lllPKT_S6_lllS6_lllS6_PS4_llll")
+OZ2_ROCBLAS_INTERNAL(oz2_rb_int_gemm_d, double, GEMMUL8_D,
+                     "_Z30rocblas_internal_gemm_templateIdE15rocblas_status_P15_rocblas_handle18rocblas_operation_S3_iiiPKT_S6_lilS6_lilS6_PS4_lili",
+                     "_Z33rocblas_internal_gemm_template_64IdE15rocblas_status_P15_rocblas_handle18rocblas_operation_S3_lllPKT_S6_lllS6_lllS6_PS4_llll")
+OZ2_ROCBLAS_INTERNAL(oz2_rb_int_gemm_c, hipComplex, GEMMUL8_C,
+                     "_Z30rocblas_internal_gemm_templateI19rocblas_complex_numIfEE15rocblas_status_P15_rocblas_handle18rocblas_operation_S5_iiiPKT_S8_lilS8_lilS8_PS6_lili",
+                     "_Z33rocblas_internal_gemm_template_64I19rocblas_complex_numIfEE15rocblas_status_P15_rocblas_handle18rocblas_operation_S5_lllPKT_S8_lllS8_lllS8_PS6_llll")
+OZ2_ROCBLAS_INTERNAL(oz2_rb_int_gemm_z, hipDoubleComplex, GEMMUL8_Z,
+                     "_Z30rocblas_internal_gemm_templateI19rocblas_complex_numIdEE15rocblas_status_P15_rocblas_handle18rocblas_operation_S5_iiiPKT_S8_lilS8_lilS8_PS6_lili",
+                     "_Z33rocblas_internal_gemm_template_64I19rocblas_complex_numIdEE15rocblas_status_P15_rocblas_handle18rocblas_operation_S5_lllPKT_S8_lllS8_lllS8_PS6_llll")
+#undef OZ2_ROCBLAS_INTERNAL
+
+// rocblas_gemm_ex: D = alpha op(A) op(B) + beta C.  Emulated for the four plain types (all of a / b / c / d / compute the same type) when it
+// is the in-place form (c == d, ldc == ldd) -- what rocBLAS's own clients and hipBLAS's GemmEx issue; anything else goes to rocBLAS.
+int rocblas_gemm_ex(void* handle, int transA, int transB, int m, int n, int k, const void* alpha, const void* a, int a_type, int lda,
+                    const void* b, int b_type, int ldb, const void* beta, const void* c, int c_type, int ldc, void* d, int d_type, int ldd,
+                    int compute_type, int algo, int32_t solution_index, uint32_t flags) {
+    using Fn = int (*)(void*, int, int, int, int, int, const void*, const void*, int, int, const void*, int, int, const void*, const void*, int,
+                       int, void*, int, int, int, int, int32_t, uint32_t);
+    static Fn real = real_rocblas<Fn>("rocblas_gemm_ex");
+    const bool same = a_type == b_type && b_type == c_type && c_type == d_type && d_type == compute_type;
+    const int dtype = !same ? -1 : a_type == 151 ? GEMMUL8_S : a_type == 152 ? GEMMUL8_D : a_type == 154 ? GEMMUL8_C : a_type == 155 ? GEMMUL8_Z : -1;
+    hipStream_t s_;
+    hipblasStatus_t st_;
+    if (dtype >= 0 && env_one("GEMMUL8_HOOK_ROCBLAS") && handle && m > 0 && n > 0 && k > 0 && alpha && a && b && beta && d && c == d &&
+        ldc == ldd && transA >= 111 && transA <= 113 && transB >= 111 && transB <= 113 && rocblas_stream(handle, &s_) &&
+        try_emulate(dtype, (hipblasHandle_t)handle, (hipblasOperation_t)transA, (hipblasOperation_t)transB, m, n, k, alpha, a, lda, b, ldb, beta,
+                    d, ldd, &st_, &s_))
+        return rocblas_status_of(st_);
+    return real ? real(handle, transA, transB, m, n, k, alpha, a, a_type, lda, b, b_type, ldb, beta, c, c_type, ldc, d, d_type, ldd, compute_type,
+                       algo, solution_index, flags)
+                : 6;
+}
 }  // extern "C"
 
 // ---- hipblasLtMatmul (not hooked by the reference; PyTorch on ROCm routes most float32 matmuls through hipBLASLt, so without

@@ -244,6 +244,58 @@ class TorchTransport:
             return 1
 
 
+def selftest(comm, device, stream=None, expect_rccl=True):
+    """First-contact check of a transport (RcclComm or TorchTransport) before anything is timed on it: communicator size, one
+    all-reduce(MAX) on int32, one grouped send/recv ring, one reduce-scatter(sum) on FP64 -- each compared with host arithmetic.
+    Returns (ok, one-line diagnosis).  Every rank must call it (the three operations are collective)."""
+    import numpy as np
+    import torch
+    rank, world = comm.rank, comm.world
+    st = stream if stream is not None else torch.cuda.current_stream(device).cuda_stream
+    c = comm.ptr.contents
+    try:
+        if expect_rccl:
+            cnt = comm.rccl_ranks()
+            if cnt != world:
+                return False, f"rank {rank}: ncclCommCount says {cnt}, the launcher says WORLD_SIZE = {world} (a rank joined another communicator: check MASTER_PORT / the id hand-off)"
+        # all-reduce(MAX), int32, odd length
+        cnt = 1027
+        i = np.arange(cnt, dtype=np.int64)
+        mine = ((i * 7 + rank * 13) % 101 - 50).astype(np.int32)
+        want = np.max(np.stack([((i * 7 + r * 13) % 101 - 50) for r in range(world)]), axis=0).astype(np.int32)
+        buf = torch.from_numpy(mine).to(device)
+        rc = c.allreduce_max_i32(c.ctx, buf.data_ptr(), cnt, st)
+        torch.cuda.synchronize(device)
+        if rc != 0 or not np.array_equal(buf.cpu().numpy(), want):
+            return False, f"rank {rank}: all-reduce(MAX, int32, {cnt}) rc = {rc}, {int((buf.cpu().numpy() != want).sum())} wrong entries"
+        if world > 1:
+            # grouped send / recv ring: to rank + 1, from rank - 1
+            nb = 4096 + 8
+            nxt, prv = (rank + 1) % world, (rank + world - 1) % world
+            out = torch.from_numpy(((np.arange(nb) * 3 + rank * 17) % 251).astype(np.uint8)).to(device)
+            inn = torch.zeros(nb, dtype=torch.uint8, device=device)
+            ops = (P2POp * 2)(P2POp(out.data_ptr(), nb, nxt, 1), P2POp(inn.data_ptr(), nb, prv, 0))
+            rc = c.sendrecv(c.ctx, 2, ops, st)
+            torch.cuda.synchronize(device)
+            wantb = ((np.arange(nb) * 3 + prv * 17) % 251).astype(np.uint8)
+            if rc != 0 or not np.array_equal(inn.cpu().numpy(), wantb):
+                return False, f"rank {rank}: grouped send/recv ring ({nb} B to {nxt}, from {prv}) rc = {rc}, {int((inn.cpu().numpy() != wantb).sum())} wrong bytes"
+        # reduce-scatter(sum), FP64: exact in double (small dyadic values)
+        rcnt = 515
+        w = np.arange(world, dtype=np.float64)[:, None]
+        j = np.arange(rcnt, dtype=np.float64)[None, :]
+        send = torch.from_numpy((rank + w * 0.5 + j * 0.25).reshape(-1)).to(device)
+        recv = torch.zeros(rcnt, dtype=torch.float64, device=device)
+        rc = c.reduce_scatter_sum_f64(c.ctx, send.data_ptr(), recv.data_ptr(), rcnt, st)
+        torch.cuda.synchronize(device)
+        wantd = world * (world - 1) / 2.0 + world * (rank * 0.5 + np.arange(rcnt) * 0.25)
+        if rc != 0 or not np.array_equal(recv.cpu().numpy(), wantd):
+            return False, f"rank {rank}: reduce-scatter(sum, FP64, {rcnt} per rank) rc = {rc}, max abs deviation {float(np.abs(recv.cpu().numpy() - wantd).max())}"
+    except Exception as e:  # a transport that throws is a failed self-test, with the reason
+        return False, f"rank {rank}: transport self-test raised {type(e).__name__}: {e}"
+    return True, "ok"
+
+
 def _ld(t):
     """Leading dimension (elements between consecutive columns) of a column-major matrix held as a (cols, rows) tensor."""
     return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))

@@ -58,3 +58,23 @@ def test_ld_preload_hook_dist_opt_in_one_rank(kind):
               {"LD_PRELOAD": LIB, "GEMMUL8_NUM_MOD_D": "15", "GEMMUL8_NUM_MOD_S": "8", "GEMMUL8_DIST": kind, "RANK": "0", "WORLD_SIZE": "1",
                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     assert "bitwise" in out
+
+
+def test_ld_preload_hook_rocblas_entry_points():
+    """GEMMUL8_HOOK_ROCBLAS=1: rocblas_dgemm / rocblas_gemm_ex / rocblas_dgemm_strided_batched called directly by an application are emulated
+    (error ~1e-16 of sum |a||b|, below anything the native FP64 routine leaves at k = 1500; counted by GEMMUL8_HOOK_STATS); without the
+    variable the same program runs on rocBLAS untouched.  No counterpart in the reference (src/hook.cu:846-1055 hooks the BLAS-level names only)."""
+    exe = os.path.join(BIN, "test_hook_rocblas")
+    assert os.path.exists(exe), "tests/cpp not built (run __graft_entry__.build())"
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    env.update({"LD_PRELOAD": LIB, "GEMMUL8_NUM_MOD_D": "15", "GEMMUL8_HOOK_STATS": "1"})
+    env.pop("GEMMUL8_MIN_FLOPS", None)
+    on = subprocess.run([exe, "on"], env=dict(env, GEMMUL8_HOOK_ROCBLAS="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    print(on.stdout)
+    assert on.returncode == 0 and "rocblas hook test passed (emulated)" in on.stdout, on.stdout[-2000:]
+    assert "stats: emulated 3 GEMM calls" in on.stdout, on.stdout[-2000:]
+    off = subprocess.run([exe, "off"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    print(off.stdout)
+    assert off.returncode == 0 and "rocblas hook test passed (native)" in off.stdout, off.stdout[-2000:]
+    assert "stats: emulated" not in off.stdout or "stats: emulated 0 GEMM calls" in off.stdout, off.stdout[-2000:]   # no call ever reached try_emulate
