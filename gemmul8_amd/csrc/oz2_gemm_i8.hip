@@ -229,8 +229,10 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
         __builtin_amdgcn_s_setprio(1);                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                     \
+            const int j = (i & 1) ? 3 - jj : jj; /* serpentine: see the ping-pong branch */                                   \
             acc[((seg_) & 1) * 4 + i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[((seg_) & 1) * 4 + i][j], 0, 0, 0); \
+        }                                                                                                                    \
         __builtin_amdgcn_s_setprio(0);                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
     } while (0)
@@ -329,11 +331,15 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_setprio(1);
+                    // serpentine order over the 4 x 4 fragment pairs: consecutive MFMAs share an operand register also across the row change
+                    // (B fragment 3, 3, 0, 0 ...): +0.5 ... 0.65 % at k >= 8192, interleaved (profiles/r04_gemm_ab_serpentine_kbar.txt)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int j = (i & 1) ? 3 - jj : jj;
                             acc[ah * 4 + i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[ah * 4 + i][j], 0, 0, 0);
+                        }
                     __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
