@@ -575,8 +575,29 @@ def main():
     out["other_mode"] = {"mode": "fast" if other else "accurate", "value": flops / oms * 1e-9, "unit": "TFLOPS", "ms_per_step": oms,
                          "max_rel_err": sampled_error(A, B, Cmat, n)}
     if not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline_port(N, args.fast)
-        out["host_blas_dgemm"] = host_blas(n)
+        # The CPU legs take ~14 s of host time (oracle port on one core, OpenBLAS on 128 threads).  They run on a helper thread (both are
+        # foreign calls that release the GIL) while THIS thread keeps issuing the emulated GEMM: the device is busy for the whole life of the
+        # process instead of idling behind 0.14 s of timed work, and the loop doubles as a sustained-throughput figure
+        # (thermally settled, but with the host cores busy beside the launch thread: reported separately, never as `value`).
+        import threading
+        cpu = {}
+
+        def cpu_legs():
+            cpu["cpu_baseline"] = cpu_baseline_port(N, args.fast)
+            cpu["host_blas_dgemm"] = host_blas(n)
+        th = threading.Thread(target=cpu_legs)
+        th.start()
+        calls, t2 = 0, time.perf_counter()
+        while th.is_alive():
+            for _ in range(20):
+                step(False)
+            torch.cuda.synchronize()
+            calls += 20
+        sus = time.perf_counter() - t2
+        th.join()
+        out.update(cpu)
+        out["sustained_beside_cpu_legs"] = {"value": flops * calls / sus * 1e-12, "unit": "TFLOPS", "calls": calls, "seconds": sus,
+                                            "note": "the same step looped while the CPU baselines run on the host cores; not the headline"}
     print(json.dumps(out))
 
 

@@ -452,12 +452,15 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_setprio(1);
+                    // serpentine order over the 4 x 4 fragment pairs, as in oz2_gemm_i8.hip (consecutive MFMAs share an operand register across the row change)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int j = (i & 1) ? 3 - jj : jj;
                             acc[ah * 4 + i][j] =
                                 __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[i], bf[j], acc[ah * 4 + i][j], 0, 0, 0, UNIT, 0, UNIT);
+                        }
                     __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (ah == 1 && ISB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -22,6 +22,7 @@ ap.add_argument("--k", default="8192")
 ap.add_argument("--moduli", type=int, default=14)
 ap.add_argument("--dtype", default="d")
 ap.add_argument("--fast", action="store_true")
+ap.add_argument("--backend", default="int8", help="int8 | fp8")
 ap.add_argument("--rounds", type=int, default=9)
 a = ap.parse_args()
 tdt = {"d": torch.float64, "s": torch.float32, "z": torch.complex128, "c": torch.complex64}[a.dtype]
@@ -37,13 +38,14 @@ for i, pth in enumerate(a.libs):
     L.gemmul8_gemm.argtypes = ref.gemmul8_gemm.argtypes
     libs.append(L)
 n, N = a.size, a.moduli
+BACKEND = g.FP8 if a.backend.lower() == "fp8" else 0
 st = torch.cuda.current_stream().cuda_stream
 al, be = np.array([1.0], dtype=ndt), np.array([0.0], dtype=ndt)
 for k in [int(x) for x in a.k.split(",")]:
     A = torch.randn((k, n), dtype=tdt, device="cuda")   # column-major m x k as a (k, m) tensor
     B = torch.randn((n, k), dtype=tdt, device="cuda")   # column-major k x n as a (n, k) tensor
     Cout = torch.zeros((n, n), dtype=tdt, device="cuda")
-    tot, _, _ = g.work_size(tdt.is_complex, g.INT8, n, n, k, N)
+    tot, _, _ = g.work_size(tdt.is_complex, BACKEND, n, n, k, N)
     work = torch.empty(tot, dtype=torch.uint8, device="cuda")
     dcode = g._dtype_code(tdt)
     ts = [[] for _ in libs]
@@ -51,7 +53,7 @@ for k in [int(x) for x in a.k.split(",")]:
         for i, L in enumerate(libs):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            rc = L.gemmul8_gemm(st, dcode, g.INT8, g.OPS["N"], g.OPS["N"], n, n, k, al.ctypes.data, A.data_ptr(), n, B.data_ptr(), k,
+            rc = L.gemmul8_gemm(st, dcode, BACKEND, g.OPS["N"], g.OPS["N"], n, n, k, al.ctypes.data, A.data_ptr(), n, B.data_ptr(), k,
                                 be.ctypes.data, Cout.data_ptr(), n, N, int(a.fast), work.data_ptr(), None, None, 0, 0, 0, 0, None)
             e1.record()
             torch.cuda.synchronize()
