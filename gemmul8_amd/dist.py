@@ -251,7 +251,9 @@ def selftest(comm, device, stream=None, expect_rccl=True):
     import numpy as np
     import torch
     rank, world = comm.rank, comm.world
-    st = stream if stream is not None else torch.cuda.current_stream(device).cuda_stream
+    on_gpu = torch.device(device).type == "cuda"
+    st = stream if stream is not None else (torch.cuda.current_stream(device).cuda_stream if on_gpu else None)
+    sync = (lambda: torch.cuda.synchronize(device)) if on_gpu else (lambda: None)   # host buffers: the CPU test transport completes before returning
     c = comm.ptr.contents
     try:
         if expect_rccl:
@@ -265,7 +267,7 @@ def selftest(comm, device, stream=None, expect_rccl=True):
         want = np.max(np.stack([((i * 7 + r * 13) % 101 - 50) for r in range(world)]), axis=0).astype(np.int32)
         buf = torch.from_numpy(mine).to(device)
         rc = c.allreduce_max_i32(c.ctx, buf.data_ptr(), cnt, st)
-        torch.cuda.synchronize(device)
+        sync()
         if rc != 0 or not np.array_equal(buf.cpu().numpy(), want):
             return False, f"rank {rank}: all-reduce(MAX, int32, {cnt}) rc = {rc}, {int((buf.cpu().numpy() != want).sum())} wrong entries"
         if world > 1:
@@ -276,7 +278,7 @@ def selftest(comm, device, stream=None, expect_rccl=True):
             inn = torch.zeros(nb, dtype=torch.uint8, device=device)
             ops = (P2POp * 2)(P2POp(out.data_ptr(), nb, nxt, 1), P2POp(inn.data_ptr(), nb, prv, 0))
             rc = c.sendrecv(c.ctx, 2, ops, st)
-            torch.cuda.synchronize(device)
+            sync()
             wantb = ((np.arange(nb) * 3 + prv * 17) % 251).astype(np.uint8)
             if rc != 0 or not np.array_equal(inn.cpu().numpy(), wantb):
                 return False, f"rank {rank}: grouped send/recv ring ({nb} B to {nxt}, from {prv}) rc = {rc}, {int((inn.cpu().numpy() != wantb).sum())} wrong bytes"
@@ -287,7 +289,7 @@ def selftest(comm, device, stream=None, expect_rccl=True):
         send = torch.from_numpy((rank + w * 0.5 + j * 0.25).reshape(-1)).to(device)
         recv = torch.zeros(rcnt, dtype=torch.float64, device=device)
         rc = c.reduce_scatter_sum_f64(c.ctx, send.data_ptr(), recv.data_ptr(), rcnt, st)
-        torch.cuda.synchronize(device)
+        sync()
         wantd = world * (world - 1) / 2.0 + world * (rank * 0.5 + np.arange(rcnt) * 0.25)
         if rc != 0 or not np.array_equal(recv.cpu().numpy(), wantd):
             return False, f"rank {rank}: reduce-scatter(sum, FP64, {rcnt} per rank) rc = {rc}, max abs deviation {float(np.abs(recv.cpu().numpy() - wantd).max())}"

@@ -226,3 +226,47 @@ def test_unique_id_rendezvous_over_tcp():
     assert [g_[0] for g_ in got] == list(range(world))
     assert all(g_[1] == 0 and g_[2] == g_[0] and g_[3] == world for g_ in got), [(g_[0], g_[1]) for g_ in got]
     assert len({g_[4] for g_ in got}) == 1 and any(got[0][4]), "ranks disagree on the unique id"
+
+
+def _selftest_worker(rank, world, port, break_it, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gemmul8_amd import dist as gd
+        comm = gd.TorchTransport(device=False)
+        if break_it and rank == 1:
+            # a transport whose reduce-scatter returns garbage on one rank: the self-test must say so, with the operation's name
+            def bad(ctx, send, recv, cnt, stream):
+                rc = comm._redscat(ctx, send, recv, cnt, stream)
+                (C.c_double * 1).from_address(recv)[0] += 1.0
+                return rc
+            comm._keep.append(gd.REDSCAT_FN(bad))
+            comm.struct.reduce_scatter_sum_f64 = comm._keep[-1]
+        ok, msg = gd.selftest(comm, "cpu", None, expect_rccl=False)
+        q.put((rank, ok, msg))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("break_it", [False, True])
+def test_transport_selftest_over_gloo(world, break_it):
+    """gemmul8_amd.dist.selftest (what `bench.py --gpus N` runs before it times anything): all-reduce(MAX, int32), grouped send/recv ring and
+    reduce-scatter(sum, FP64) checked against host arithmetic on every rank; a transport that delivers one wrong value is reported with
+    the name of the operation and the rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_selftest_worker, args=(r, world, port, break_it, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok, msg in res:
+        if break_it and rank == 1:
+            assert not ok and "reduce-scatter" in msg and "rank 1" in msg, msg
+        else:
+            assert ok and msg == "ok", (rank, msg)
