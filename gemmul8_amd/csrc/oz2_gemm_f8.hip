@@ -89,11 +89,19 @@ __device__ __forceinline__ F8Plane f8_plane(const F8Args& args, int plane) {
 __device__ __forceinline__ unsigned pack16(int a, int b) { return ((unsigned)a & 0xFFFFu) | ((unsigned)b << 16); }
 
 constexpr int F8_THREADS = 512;
-#ifndef OZ2_F8_PROBE_NODMA
-#define OZ2_F8_PROBE_NODMA 0  // timing probe on real data (wrong results): the LDS-DMA is issued during a workgroup's first tile only
+// Laboratory hook points (neutral here; a probe build of tools/build_probes.sh defines them through tools/experiments/probes/lab_hooks.hpp; the
+// product build -- -DOZ2_PRODUCT_BUILD -- refuses OZ2_LAB_HOOKS): see oz2_gemm_i8_epi.hpp
+#if defined(OZ2_PRODUCT_BUILD) && defined(OZ2_LAB_HOOKS)
+#error "laboratory switches (OZ2_LAB_*) are not allowed in the product build of libgemmul8.so: use tools/experiments/"
 #endif
-#ifndef OZ2_F8_PROBE_L2
-#define OZ2_F8_PROBE_L2 0
+#ifdef OZ2_LAB_HOOKS
+#include OZ2_LAB_HOOKS
+#endif
+#ifndef OZ2_HOOK_DMA_ON
+#define OZ2_HOOK_DMA_ON(first_tile) true
+#endif
+#ifndef OZ2_HOOK_KSTEP
+#define OZ2_HOOK_KSTEP(kin) (kin)
 #endif
 
 // int16 residue epilogues (EPI_PART / EPI_FINAL) of a wave's 128 x 64 accumulator block.  ODD: odd modulus -- the accumulators are
@@ -356,7 +364,7 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
         // Measured on config 3 (18 GEMMs, interleaved builds, profiles/r02_f8_ab.txt): this kernel 54.9 ms, the round-1 32x32x64 kernel
         // (four segments of 4 MFMAs) 55.5 ms, a four-segment (row x column halves) form of this one 55.8 ms.  The matrix pipes stay
         // ~25 % idle, and the cost sits in the L2 -> LDS operand path itself: with the DMA issued in the first tile only (real data
-        // in LDS, -DOZ2_F8_PROBE_NODMA=1) the 18 GEMMs take 44.2 instead of 54.2 ms (-18.5 %; the INT8 kernel: -13 %), of which
+        // in LDS; probe build -DOZ2_PROBE=4) the 18 GEMMs take 44.2 instead of 54.2 ms (-18.5 %; the INT8 kernel: -13 %), of which
         // L2-miss latency explains 6 % (round 1, L2-resident operands).  WHERE the DMA is issued from does not matter: a 12-wave
         // variant with dedicated producer waves (the INT8 layout; 32x32x64 so that 128 accumulators + 32 operand registers fit 168
         // VGPRs, address set folded into one register by XOR variants) was built, is bit-exact and runs 58.9 ms, 46.5 without
@@ -388,7 +396,7 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
     } while (0)
 #define F8_FETCH_BEGIN()                                                                                                     \
     do {                                                                                                                     \
-        fsrc = gsrc + (size_t)(OZ2_F8_PROBE_L2 ? (kt_next & 7) : kt_next) * BK; /* probe: operands from the first 8 K-steps (L2 hits) */ \
+        fsrc = gsrc + (size_t)OZ2_HOOK_KSTEP(kt_next) * BK;                                                                  \
         fdst = smem + hs * TILE_BYTES;                                                                                       \
     } while (0)
         F8_FETCH_BEGIN();
@@ -429,7 +437,7 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
 #pragma unroll
                 for (int ah = 0; ah < 2; ++ah) {  // LOAD segment ah of this K-step
                     v8i af[4];
-                    if (!(OZ2_F8_PROBE_NODMA) || vb == (int)blockIdx.x) {  // timing probe (wrong results): LDS-DMA in the first tile only
+                    if (OZ2_HOOK_DMA_ON(vb == (int)blockIdx.x)) {  // (laboratory hook: always true in the product)
                         if constexpr (ISB) {
                             if (ah == 0) {
 #pragma unroll

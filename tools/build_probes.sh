@@ -10,7 +10,7 @@ FLAGS="-std=c++20 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -DOCML_BASIC
 for spec in "$@"; do
   tag="${spec%%=*}"; defs="${spec#*=}"
   src=${SRC:-oz2_gemm_i8}
-  if [ "$src" = "oz2_gemm_i8" ]; then
+  if [ "$src" = "oz2_gemm_i8" ] || [ "$src" = "oz2_gemm_f8" ]; then
     /opt/rocm/bin/hipcc $FLAGS '-DOZ2_LAB_HOOKS="../../tools/experiments/probes/lab_hooks.hpp"' $defs -c $src.hip -o build/${src}_$tag.o
   else
     /opt/rocm/bin/hipcc $FLAGS $defs -c $src.hip -o build/${src}_$tag.o

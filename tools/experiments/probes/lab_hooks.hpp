@@ -22,7 +22,7 @@
 #define OZ2_HOOK_SKIP_EPILOGUE 1
 #endif
 #if OZ2_PROBE & 16
-#define OZ2_HOOK_KSTEP(kin) ((kin) & 1)   /* (the short-K kernel has as few as two K-steps) */
+#define OZ2_HOOK_KSTEP(kin) ((kin) & 7)
 #elif OZ2_KSTAG
 #define OZ2_HOOK_KSTEP(kin)                                                                                                        \
     (((kin) + (OZ2_KSTAG == 1   ? (int)(((blockIdx.x & 7u) * (unsigned)KT1) >> 3)                                                  \
