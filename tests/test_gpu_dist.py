@@ -196,6 +196,11 @@ def _check_multi_line(d, ranks, rccl):
     assert d["config"]["headline_plan"] in ("blocks", "moduli") and d["value"] == d["plans"][d["config"]["headline_plan"]]["value"]
     assert d["rccl_ranks"] == (ranks if rccl else -1)
     assert d["roofline"]["traffic_measured_in_run"] is False
+    # round 4: transport self-test before timing, single-GPU phase times and the per-plan time model they feed
+    assert d["dist_selftest"].startswith("ok"), d["dist_selftest"]
+    assert set(d["single_gpu_phase_ms"]) == {"bounds", "quantise", "lowprec_gemm", "crt"} and d["single_gpu_phase_ms"]["lowprec_gemm"] > 0
+    for name, p in d["plans"].items():
+        assert p["model_ms"] > 0 and abs(sum(p["model_terms_ms"].values()) - p["model_ms"]) < 1e-9, name
 
 
 def _one_json_line(out):
@@ -256,5 +261,5 @@ def test_bench_plan_path_on_real_rccl_one_rank():
                           "--size", "2048"], env=env, capture_output=True, text=True, timeout=600)
     d = _one_json_line(out)
     assert d["n_gpus"] == 1 and d["value"] > 10 and d["max_rel_err"] < 1e-9 and d["roofline"]["achieved"] > 0
-    assert d["rccl_ranks"] == 1 and "RCCL" in d["transport"]
+    assert d["rccl_ranks"] == 1 and "RCCL" in d["transport"] and "ncclCommCount" in d["dist_selftest"]
     assert all(p["mismatches_vs_moduli"] == 0 for p in d["plans"].values())   # one rank: every plan groups all moduli together
