@@ -49,7 +49,7 @@ def test_one_step_fp64_reduction_is_exact(p):
 
 @pytest.mark.parametrize("p", [m for m in INT8_MODULI if m & 1])
 def test_biased_accumulator_byte_dot_reduction_is_exact(p):
-    """INT8 GEMM epilogue, odd moduli (oz2_gemm_i8.hip red() with OZ2_RED_DOT4, oz2_device.hpp mod_small_sym_u): the accumulator
+    """INT8 GEMM epilogue, odd moduli (oz2_gemm_i8_epi.hpp red(), RED_ODD; oz2_device.hpp mod_small_sym_u): the accumulator
     starts at -2^31, so its register read as unsigned is u = x + 2^31 for any int32 sum x; s = sum_j byte_j(u) (256^j mod p) +
     ((-2^31) mod p) (v_dot4_u32_u8), q from the low 24 bits of fma(float(s), RN(1/p), 2^23), r = s - q p (v_mad_i32_i24)."""
     rng = np.random.default_rng(1000 + p)
