@@ -1026,7 +1026,7 @@ static int rocblas_internal_gemm_hook(const char* mangled, int code, void* handl
                                       long offA, I lda, long strideA, const T* B, long offB, I ldb, long strideB, const T* beta, T* C, long offC,
                                       I ldc, long strideC, I batch) {
     using Fn = int (*)(void*, int, int, I, I, I, const T*, const T*, long, I, long, const T*, long, I, long, const T*, T*, long, I, long, I);
-    Fn real = real_rocblas<Fn>(mangled);
+    static Fn real = real_rocblas<Fn>(mangled);  // one symbol per <T, I> instantiation: resolved once
     hipStream_t s_;
     hipblasStatus_t st_;
     const bool fits = m > 0 && n > 0 && k > 0 && batch > 0 && (long long)m <= 2147483647 && (long long)n <= 2147483647 && (long long)k <= 2147483647 &&

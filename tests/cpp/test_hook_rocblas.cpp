@@ -7,6 +7,7 @@
 #include <rocblas/rocblas.h>
 
 #include <cmath>
+#include <complex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -85,6 +86,45 @@ int main(int argc, char** argv) {
     for (double e : errs) {
         if (on) CHECK(e < tol_emulated);
         else CHECK(e > tol_emulated && e < 1e-13);  // the native routine's rounding at k = 1500
+    }
+    // 4. other types + device-pointer scalars: rocblas_zgemm with alpha / beta in device memory (rocblas_pointer_mode_device), op C / T
+    {
+        const int mz = 96, nz = 80, kz = 200;
+        std::vector<rocblas_double_complex> Az((size_t)kz * mz), Bz((size_t)nz * kz), Cz((size_t)mz * nz);
+        for (auto& x : Az) x = rocblas_double_complex(rand() / (double)RAND_MAX - 0.5, rand() / (double)RAND_MAX - 0.5);
+        for (auto& x : Bz) x = rocblas_double_complex(rand() / (double)RAND_MAX - 0.5, rand() / (double)RAND_MAX - 0.5);
+        rocblas_double_complex *dAz, *dBz, *dCz, *dsc;
+        CHECK(hipMalloc(&dAz, Az.size() * 16) == hipSuccess && hipMalloc(&dBz, Bz.size() * 16) == hipSuccess && hipMalloc(&dCz, Cz.size() * 16) == hipSuccess &&
+              hipMalloc(&dsc, 32) == hipSuccess);
+        CHECK(hipMemcpy(dAz, Az.data(), Az.size() * 16, hipMemcpyHostToDevice) == hipSuccess);
+        CHECK(hipMemcpy(dBz, Bz.data(), Bz.size() * 16, hipMemcpyHostToDevice) == hipSuccess);
+        CHECK(hipMemset(dCz, 0, Cz.size() * 16) == hipSuccess);
+        const rocblas_double_complex sc[2] = {rocblas_double_complex(1.0, 0.0), rocblas_double_complex(0.0, 0.0)};
+        CHECK(hipMemcpy(dsc, sc, 32, hipMemcpyHostToDevice) == hipSuccess);
+        CHECK(rocblas_set_pointer_mode(h, rocblas_pointer_mode_device) == rocblas_status_success);
+        // C = A^H * B^T : A stored k x m (lda = kz), B stored n x k (ldb = nz)
+        CHECK(rocblas_zgemm(h, rocblas_operation_conjugate_transpose, rocblas_operation_transpose, mz, nz, kz, dsc, dAz, kz, dBz, nz, dsc + 1, dCz, mz) ==
+              rocblas_status_success);
+        CHECK(rocblas_set_pointer_mode(h, rocblas_pointer_mode_host) == rocblas_status_success);
+        CHECK(hipStreamSynchronize(stream) == hipSuccess);
+        CHECK(hipMemcpy(Cz.data(), dCz, Cz.size() * 16, hipMemcpyDeviceToHost) == hipSuccess);
+        double ez = 0;
+        for (int j = 0; j < nz; j += 3)
+            for (int i = 0; i < mz; i += 5) {
+                long double sr = 0, si = 0, sa = 0;
+                for (int l = 0; l < kz; ++l) {
+                    const long double ar = std::real(Az[(size_t)i * kz + l]), ai = -std::imag(Az[(size_t)i * kz + l]);  // conj(A(l, i))
+                    const long double br = std::real(Bz[(size_t)l * nz + j]), bi = std::imag(Bz[(size_t)l * nz + j]);   // B(j, l)
+                    sr += ar * br - ai * bi;
+                    si += ar * bi + ai * br;
+                    sa += fabsl(ar * br) + fabsl(ai * bi) + fabsl(ar * bi) + fabsl(ai * br);
+                }
+                ez = std::fmax(ez, (double)(std::fmax(fabsl(sr - std::real(Cz[(size_t)j * mz + i])), fabsl(si - std::imag(Cz[(size_t)j * mz + i]))) / sa));
+            }
+        std::printf("rocblas hook %s: zgemm (op C, op T, device scalars) max error relative to sum|a||b|: %.2e\n", on ? "ON" : "off", ez);
+        if (on) CHECK(ez < tol_emulated);      // GEMMUL8_NUM_MOD_Z set by the test: emulated
+        else CHECK(ez < 1e-13);
+        (void)hipFree(dAz), (void)hipFree(dBz), (void)hipFree(dCz), (void)hipFree(dsc);
     }
     CHECK(rocblas_destroy_handle(h) == rocblas_status_success);
     std::printf("rocblas hook test passed (%s)\n", on ? "emulated" : "native");

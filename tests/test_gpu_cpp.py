@@ -68,12 +68,12 @@ def test_ld_preload_hook_rocblas_entry_points():
     assert os.path.exists(exe), "tests/cpp not built (run __graft_entry__.build())"
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
-    env.update({"LD_PRELOAD": LIB, "GEMMUL8_NUM_MOD_D": "15", "GEMMUL8_HOOK_STATS": "1"})
+    env.update({"LD_PRELOAD": LIB, "GEMMUL8_NUM_MOD_D": "15", "GEMMUL8_NUM_MOD_Z": "16", "GEMMUL8_HOOK_STATS": "1"})
     env.pop("GEMMUL8_MIN_FLOPS", None)
     on = subprocess.run([exe, "on"], env=dict(env, GEMMUL8_HOOK_ROCBLAS="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     print(on.stdout)
     assert on.returncode == 0 and "rocblas hook test passed (emulated)" in on.stdout, on.stdout[-2000:]
-    assert "stats: emulated 3 GEMM calls" in on.stdout, on.stdout[-2000:]
+    assert "stats: emulated 4 GEMM calls" in on.stdout, on.stdout[-2000:]
     off = subprocess.run([exe, "off"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     print(off.stdout)
     assert off.returncode == 0 and "rocblas hook test passed (native)" in off.stdout, off.stdout[-2000:]
