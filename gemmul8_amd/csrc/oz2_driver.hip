@@ -43,6 +43,10 @@ inline size_t mid_size(int backend, bool cplx) { return (backend == kINT8 ? 1 : 
 // restatement returns inf there, tests/test_gpu_parity.py::test_float_types_reject_more_than_13_moduli)
 static inline bool moduli_ok(int dtype, unsigned N) { return N >= 2 && N <= (is_f32(dtype) ? 13u : 20u); }
 
+// FP8 backend: C0 + C1 of a square modulus may share one FP32 accumulator (K-concatenation) while every partial sum stays an exact
+// integer: 2 k products of magnitude <= 16 * 16 (src/mod.hpp:159-189) <= 2^24
+static inline bool f8_concat_ok(size_t k) { return k <= 32768; }
+
 #define OZ2_HIP(expr)                       \
     do {                                    \
         hipError_t e__ = (expr);            \
@@ -325,10 +329,21 @@ int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t
         for (unsigned t0 = t_begin; t0 < t_end; t0 += (unsigned)chunk) {
             const unsigned t1 = std::min<unsigned>(t_end, t0 + (unsigned)chunk);
             int16_t* r1 = r0 + (size_t)(t1 - t0) * L->sizeC;
-            OZ2_HIP(launch_gemm_f8(stream, 0, A_lo, B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1, r0, L->mp, L->sizeC, nullptr, nullptr, 0));
-            OZ2_HIP(launch_gemm_f8(stream, 1, A_lo, B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1, r1, L->mp, L->sizeC, nullptr, nullptr, 0));
-            OZ2_HIP(launch_gemm_f8(stream, 2, A_lo, B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1,
-                                   (int16_t*)L->C_mid + (size_t)t0 * L->sizeC, L->mp, L->sizeC, r0, r1, L->sizeC));
+            // Square moduli (t < 6: value = s (C0 + C1) + C2): C0 + C1 as ONE GEMM over the K-concatenation [Ahi | Alo] x [Blo ; Bhi] (round 4) --
+            // one residue plane and one epilogue less per modulus, same MACs, same bits; exact while 2 k * 16 * 16 <= 2^24
+            const unsigned tc = f8_concat_ok(k) ? std::min<unsigned>(t1, std::max<unsigned>(t0, 6u)) : t0;  // [t0, tc): concatenated form
+            if (tc > t0) {
+                OZ2_HIP(launch_gemm_f8(stream, 4, A_lo, B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)tc, r0, L->mp, L->sizeC, nullptr, nullptr, 0));
+                OZ2_HIP(launch_gemm_f8(stream, 5, A_lo, B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)tc,
+                                       (int16_t*)L->C_mid + (size_t)t0 * L->sizeC, L->mp, L->sizeC, r0, r0, L->sizeC));
+            }
+            if (tc < t1) {
+                int16_t *q0 = r0 + (size_t)(tc - t0) * L->sizeC, *q1 = r1 + (size_t)(tc - t0) * L->sizeC;
+                OZ2_HIP(launch_gemm_f8(stream, 0, A_lo, B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)tc, (int)t1, q0, L->mp, L->sizeC, nullptr, nullptr, 0));
+                OZ2_HIP(launch_gemm_f8(stream, 1, A_lo, B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)tc, (int)t1, q1, L->mp, L->sizeC, nullptr, nullptr, 0));
+                OZ2_HIP(launch_gemm_f8(stream, 2, A_lo, B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)tc, (int)t1,
+                                       (int16_t*)L->C_mid + (size_t)tc * L->sizeC, L->mp, L->sizeC, q0, q1, L->sizeC));
+            }
         }
         return GEMMUL8_OK;
     }
@@ -345,18 +360,31 @@ int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t
             const unsigned t1 = std::min<unsigned>(t_end, t0 + (unsigned)chunk);
             const size_t nt = t1 - t0;
             int16_t *r1 = r0 + nt * L->sizeC, *rx = r1 + nt * L->sizeC, *ry = rx + nt * L->sizeC;
+            const unsigned tc = f8_concat_ok(k) ? std::min<unsigned>(t1, std::max<unsigned>(t0, 6u)) : t0;  // [t0, tc): square moduli, concatenated form (real path above)
             for (int part = 0; part < 3; ++part) {
                 const int8_t* Ap = A_lo + part * L->part_strideA;
                 const int8_t* Bp = B_lo + part * L->part_strideB;
-                OZ2_HIP(launch_gemm_f8(stream, 0, Ap, Bp, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1, r0, L->mp, L->sizeC, nullptr, nullptr, 0));
-                OZ2_HIP(launch_gemm_f8(stream, 1, Ap, Bp, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1, r1, L->mp, L->sizeC, nullptr, nullptr, 0));
-                if (part < 2) {
-                    OZ2_HIP(launch_gemm_f8(stream, 2, Ap, Bp, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1, part == 0 ? rx : ry, L->mp, L->sizeC,
-                                           r0, r1, L->sizeC));
-                } else {
-                    OZ2_HIP(launch_gemm_f8(stream, 3, Ap, Bp, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1,
-                                           (int16_t*)L->C_mid + (size_t)t0 * 2 * L->sizeC, L->mp, 2 * L->sizeC, r0, r1, L->sizeC, rx, ry));
-                }
+                // moduli [a0, a1) with partial residues in planes po.. of the chunk's scratch; cc = concatenated C0 + C1
+                auto product = [&](unsigned a0, unsigned a1, bool cc) -> int {
+                    if (a0 >= a1) return 0;
+                    const size_t po = (size_t)(a0 - t0) * L->sizeC;
+                    if (cc) {
+                        OZ2_HIP(launch_gemm_f8(stream, 4, Ap, Bp, L->sizeA, L->sizeB, L->kp, m, n, (int)a0, (int)a1, r0 + po, L->mp, L->sizeC, nullptr, nullptr, 0));
+                    } else {
+                        OZ2_HIP(launch_gemm_f8(stream, 0, Ap, Bp, L->sizeA, L->sizeB, L->kp, m, n, (int)a0, (int)a1, r0 + po, L->mp, L->sizeC, nullptr, nullptr, 0));
+                        OZ2_HIP(launch_gemm_f8(stream, 1, Ap, Bp, L->sizeA, L->sizeB, L->kp, m, n, (int)a0, (int)a1, r1 + po, L->mp, L->sizeC, nullptr, nullptr, 0));
+                    }
+                    if (part < 2) {
+                        OZ2_HIP(launch_gemm_f8(stream, cc ? 5 : 2, Ap, Bp, L->sizeA, L->sizeB, L->kp, m, n, (int)a0, (int)a1, (part == 0 ? rx : ry) + po, L->mp,
+                                               L->sizeC, r0 + po, r1 + po, L->sizeC));
+                    } else {
+                        OZ2_HIP(launch_gemm_f8(stream, cc ? 6 : 3, Ap, Bp, L->sizeA, L->sizeB, L->kp, m, n, (int)a0, (int)a1,
+                                               (int16_t*)L->C_mid + (size_t)a0 * 2 * L->sizeC, L->mp, 2 * L->sizeC, r0 + po, r1 + po, L->sizeC, rx + po, ry + po));
+                    }
+                    return 0;
+                };
+                if (int rc = product(t0, tc, true)) return rc;
+                if (int rc = product(tc, t1, false)) return rc;
             }
         }
         return GEMMUL8_OK;

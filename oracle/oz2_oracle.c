@@ -349,6 +349,8 @@ void oz2_bound_maxima_f8(int cplx, size_t m, size_t n, size_t k, const uint8_t *
     const size_t pa = m * k, pb = n * k;
     f8_lut_init();
     const float ku = f8_bound_ku(k);
+    /* absolute part of the product's default inflation (oz2_gemm_f8.hip bound_kabs): 7 kp 2^-14, kp = k padded to 256 */
+    const float kabs = g_f8_bound_mode == 0 ? 7.0f * (float)((k + 255) / 256 * 256) * 0x1.0p-14f : 0.0f;
     for (size_t j = c0; j < c1; ++j)
         for (size_t i = 0; i < m; ++i) {
             float v;
@@ -356,7 +358,7 @@ void oz2_bound_maxima_f8(int cplx, size_t m, size_t n, size_t k, const uint8_t *
                 double s = 0;
                 for (size_t kk = 0; kk < k; ++kk) s += F8_DBL_LUT[Abar[i * k + kk]] * F8_DBL_LUT[Bbar[j * k + kk]];
                 float t = (float)s;
-                v = fmaf_dir(ku, t, t, FE_UPWARD);
+                v = addf_dir(fmaf_dir(ku, t, t, FE_UPWARD), kabs, FE_UPWARD);
             } else {
                 const uint8_t *ar = Abar + i * k, *ai = ar + pa, *ad = ai + pa;
                 const uint8_t *br = Bbar + j * k, *bi = br + pb, *bd = bi + pb;
@@ -367,11 +369,11 @@ void oz2_bound_maxima_f8(int cplx, size_t m, size_t n, size_t k, const uint8_t *
                     cc0 += F8_DBL_LUT[ad[kk]] * F8_DBL_LUT[bd[kk]];
                 }
                 float ArBi = (float)cc1, AiBr = (float)cc2, AriBri = (float)cc0;
-                float ArBi_up = fmaf_dir(ku, ArBi, ArBi, FE_UPWARD);
-                float AiBr_up = fmaf_dir(ku, AiBr, AiBr, FE_UPWARD);
+                float ArBi_up = addf_dir(fmaf_dir(ku, ArBi, ArBi, FE_UPWARD), kabs, FE_UPWARD);
+                float AiBr_up = addf_dir(fmaf_dir(ku, AiBr, AiBr, FE_UPWARD), kabs, FE_UPWARD);
                 float s12 = addf_dir(ArBi_up, AiBr_up, FE_UPWARD);
                 float AriBri_up = g_f8_bound_mode == 0
-                                      ? fmaf_dir(ku, addf_dir(fabsf(AriBri), addf_dir(s12, s12, FE_UPWARD), FE_UPWARD), AriBri, FE_UPWARD)
+                                      ? addf_dir(fmaf_dir(ku, addf_dir(fabsf(AriBri), addf_dir(s12, s12, FE_UPWARD), FE_UPWARD), AriBri, FE_UPWARD), kabs, FE_UPWARD)
                                       : fmaf_dir(ku, AriBri, AriBri, FE_UPWARD);
                 float s0 = addf_dir(AriBri_up, s12, FE_UPWARD);
                 v = s0 > s12 ? s0 : s12;

@@ -218,6 +218,90 @@ def test_fp8_bound_adversarial_complex(N, dtype):
     assert out[0]["wrong_elements"] == 0 and out[0]["max_rel_err"] < tol, f"default combination: {out[0]}"
 
 
+def _fuzz_case(seed):
+    """The operands tests/test_gpu_fuzz.py draws for `seed` (kept in step with it by test_fuzz_regressions_are_the_fuzz_cases)."""
+    from test_gpu_fuzz import DIMS_K, DIMS_MN, _rand
+    rng = np.random.default_rng(9000 + seed)
+    dtype = [np.float64, np.float32, np.complex128, np.complex64][seed % 4]
+    fp8 = (seed // 4) % 3 == 2
+    is_f32 = dtype in (np.float32, np.complex64)
+    N = int(rng.integers(2, 14 if is_f32 else 21))
+    rng.integers(0, 2)
+    m, n = (int(rng.choice(DIMS_MN)) for _ in range(2))
+    k = int(rng.choice(DIMS_K))
+    cplx = np.dtype(dtype).kind == "c"
+    if fp8 or cplx:
+        m, n = min(m, 257), min(n, 256)
+    for opts in (["", "dma", "reg"], ["", "128", "256"], ["", "0", "1"], ["", "1", "2", "3"]):
+        rng.choice(opts)
+    opA = str(rng.choice(["N", "T", "C"] if cplx else ["N", "T"]))
+    opB = str(rng.choice(["N", "T", "C"] if cplx else ["N", "T"]))
+    phi = float(rng.choice([0.0, 1.0, 3.0]))
+    A = _rand((m, k) if opA == "N" else (k, m), dtype, rng, phi)
+    B = _rand((k, n) if opB == "N" else (n, k), dtype, rng, phi)
+    if rng.integers(0, 3) == 0 and m > 2:
+        (A if opA == "N" else A.T)[m // 2, :] = 0
+    return A, B, N, opA, opB, fp8
+
+
+@pytest.mark.parametrize("seed", [7388, 10113])
+def test_fp8_bound_fuzz_regressions(seed):
+    """Round 4: a 12000-seed run of tests/test_gpu_fuzz.py found these two real-type FP8 cases (one row / one column, exponent range
+    phi = 3, k = 400) whose bound maxima came out 4.7e-5 / 2.2e-6 BELOW the exact sums with the relative inflation alone: the engine aligns a
+    group of 8 products to the largest sum of the operands' exponent FIELDS, and an e4m3 subnormal carries the field of 2^-6
+    (tools/ubench/f8_accum2.hip, profiles/r04_f8_accum2.txt).  The default inflation now has an absolute part (oz2_gemm_f8.hip bound_kabs);
+    bounds_case asserts exact un-inflated maximum <= device value."""
+    import gemmul8_amd as g
+    import gpu_util as gu
+    A, B, N, opA, opB, fp8 = _fuzz_case(seed)
+    assert fp8 and A.dtype.kind == "f"
+    gu.bounds_case(A, B, N, opA=opA, opB=opB, backend=g.FP8)
+    gu.parity_case(A, B, N, False, opA=opA, opB=opB, backend=g.FP8)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fp8_bound_subnormal_reference_product(dtype):
+    """The mechanism of the cases above, built to its worst: in every group of 8 the product with the largest exponent-field sum is
+    (subnormal 2^-9) x 2^7 -- field sum 1, true value 2^-2 -- and the seven others, 2^-6 x 1.75 * 2^-7 = 1.75 * 2^-13, lie just under the
+    alignment grid 2^-12 of that reference and vanish: the engine's sum is 0.6 % low, six times what the relative inflation covers.  With the
+    absolute part of the default inflation the device's maxima are >= the exact sums (bounds_case); with the round-3 inflation (mode 2)
+    they are not (recorded)."""
+    import gemmul8_amd as g
+    import gpu_util as gu
+    k, groups = 512, 63
+    a = np.zeros(k)
+    b = np.zeros(k)
+    for gi in range(groups):
+        a[8 * gi] = 2.0 ** -9
+        b[8 * gi] = 128.0
+        a[8 * gi + 1:8 * gi + 8] = 2.0 ** -6
+        b[8 * gi + 1:8 * gi + 8] = 1.75 * 2.0 ** -7
+    a[8 * groups] = 128.0                                  # the row's maximum (amax = 1.0 -> sft0 = 7 -> bound plane = a exactly); its partner is 0
+    m, n = 48, 40
+    A = np.tile(a / 128.0, (m, 1)).astype(dtype)
+    B = np.tile((b / 128.0)[:, None], (1, n)).astype(dtype)
+    exact = float(a @ b)
+    lib = g.lib()
+    try:
+        assert lib.gemmul8_set_fp8_bound_mode(2) >= 0
+        try:
+            gu.bounds_case(A, B, 8, backend=g.FP8)
+            below_with_round3 = False
+        except AssertionError as e:
+            below_with_round3 = "BELOW the exact sum" in str(e)
+    finally:
+        lib.gemmul8_set_fp8_bound_mode(0)
+    gu.bounds_case(A, B, 8, backend=g.FP8)               # default: the guarantee holds
+    gu.parity_case(A, B, 8, False, backend=g.FP8)
+    rec = {"case": "subnormal reference product", "dtype": np.dtype(dtype).name, "k": k, "exact_bound_sum": exact,
+           "engine_loss_expected": 7 * 1.75 * 2.0 ** -13 * groups / exact, "round3_inflation_below_exact": below_with_round3}
+    print("fp8 bound subnormal reference:", json.dumps(rec))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "fp8_bound_subnormal_reference.jsonl"), "a") as f:
+        f.write(json.dumps(rec) + "\n")
+    assert below_with_round3, "the round-3 inflation was expected to fall below the exact sum on this input"
+
+
 def test_fp8_bound_never_below_exact_on_wide_rows():
     """Rows spanning > 20 binades with the big products scattered over the groups: the device's inflated maxima must not fall below
     the exactly accumulated ones (bounds_case asserts exactly that for real types)."""
