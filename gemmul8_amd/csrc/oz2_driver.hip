@@ -45,7 +45,9 @@ static inline bool moduli_ok(int dtype, unsigned N) { return N >= 2 && N <= (is_
 
 // FP8 backend: C0 + C1 of a square modulus may share one FP32 accumulator (K-concatenation) while every partial sum stays an exact
 // integer: 2 k products of magnitude <= 16 * 16 (src/mod.hpp:159-189) <= 2^24
-static inline bool f8_concat_ok(size_t k) { return k <= 32768; }
+// -- and while the four operand planes of such a GEMM stay inside the Infinity Cache: interleaved (profiles/r04_f8_concat_ab.txt) SGEMM 8192^2 x 4096 /
+// 8192, 6 moduli: +4.5 / +2.3 % of the whole call, 16384^3 (1 GiB of planes per concatenated GEMM): -0.4 %
+static inline bool f8_concat_ok(size_t k, size_t m, size_t n, size_t kp) { return k <= 32768 && 2 * (m + n) * kp <= ((size_t)384 << 20); }
 
 #define OZ2_HIP(expr)                       \
     do {                                    \
@@ -331,7 +333,7 @@ int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t
             int16_t* r1 = r0 + (size_t)(t1 - t0) * L->sizeC;
             // Square moduli (t < 6: value = s (C0 + C1) + C2): C0 + C1 as ONE GEMM over the K-concatenation [Ahi | Alo] x [Blo ; Bhi] (round 4) --
             // one residue plane and one epilogue less per modulus, same MACs, same bits; exact while 2 k * 16 * 16 <= 2^24
-            const unsigned tc = f8_concat_ok(k) ? std::min<unsigned>(t1, std::max<unsigned>(t0, 6u)) : t0;  // [t0, tc): concatenated form
+            const unsigned tc = f8_concat_ok(k, m, n, L->kp) ? std::min<unsigned>(t1, std::max<unsigned>(t0, 6u)) : t0;  // [t0, tc): concatenated form
             if (tc > t0) {
                 OZ2_HIP(launch_gemm_f8(stream, 4, A_lo, B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)tc, r0, L->mp, L->sizeC, nullptr, nullptr, 0));
                 OZ2_HIP(launch_gemm_f8(stream, 5, A_lo, B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)tc,
@@ -360,7 +362,7 @@ int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t
             const unsigned t1 = std::min<unsigned>(t_end, t0 + (unsigned)chunk);
             const size_t nt = t1 - t0;
             int16_t *r1 = r0 + nt * L->sizeC, *rx = r1 + nt * L->sizeC, *ry = rx + nt * L->sizeC;
-            const unsigned tc = f8_concat_ok(k) ? std::min<unsigned>(t1, std::max<unsigned>(t0, 6u)) : t0;  // [t0, tc): square moduli, concatenated form (real path above)
+            const unsigned tc = f8_concat_ok(k, m, n, L->kp) ? std::min<unsigned>(t1, std::max<unsigned>(t0, 6u)) : t0;  // [t0, tc): square moduli, concatenated form (real path above)
             for (int part = 0; part < 3; ++part) {
                 const int8_t* Ap = A_lo + part * L->part_strideA;
                 const int8_t* Bp = B_lo + part * L->part_strideB;
