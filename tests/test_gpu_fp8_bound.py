@@ -318,3 +318,35 @@ def test_fp8_bound_never_below_exact_on_wide_rows():
     Bc = B * np.exp(2j * np.pi * rng.random((k, n)))
     gu.bounds_case(Ac, Bc, 10, backend=g.FP8)
     gu.bounds_case(Ac.astype(np.complex64), Bc.astype(np.complex64), 6, backend=g.FP8)
+
+
+N_STRESS = int(os.environ.get("GEMMUL8_FP8_BOUND_STRESS", "24"))   # one-off sweeps: GEMMUL8_FP8_BOUND_STRESS=3000
+
+
+@pytest.mark.parametrize("seed", range(N_STRESS))
+def test_fp8_bound_guarantee_stress(seed):
+    """Random operands aimed at the regime where the fuzz sweep found the bound below the exact sum: few rows / columns (the maximum cannot
+    hide behind a well-aligned partner), exponent ranges of up to ~40 binades, many zeros, so that most entries of the e4m3 bound planes
+    are subnormal or zero and the few large ones of A rarely meet the large ones of B.  Real and complex; bounds_case asserts
+    exact un-inflated maximum <= device value."""
+    import gemmul8_amd as g
+    import gpu_util as gu
+    rng = np.random.default_rng(424242 + seed)
+    cplx = seed % 3 == 2
+    f32 = (seed // 3) % 2 == 1
+    m = int(rng.choice([1, 2, 5, 17, 64]))
+    n = int(rng.choice([1, 2, 3, 9, 48]))
+    k = int(rng.choice([8, 64, 127, 400, 1024, 2300]))
+    phi = float(rng.choice([2.0, 4.0, 6.0]))
+    dens = float(rng.choice([0.1, 0.5, 1.0]))
+
+    def mat(shape):
+        x = (rng.random(shape) - 0.5) * np.exp(phi * rng.standard_normal(shape)) * (rng.random(shape) < dens)
+        if cplx:
+            x = x + 1j * (rng.random(shape) - 0.5) * np.exp(phi * rng.standard_normal(shape)) * (rng.random(shape) < dens)
+        return x
+    A, B = mat((m, k)), mat((k, n))
+    A[0, 0] = A[0, 0] or 1.0          # no all-zero operand
+    B[0, 0] = B[0, 0] or 1.0
+    dt = (np.complex64 if f32 else np.complex128) if cplx else (np.float32 if f32 else np.float64)
+    gu.bounds_case(A.astype(dt), B.astype(dt), 6 if f32 else 10, backend=g.FP8)
