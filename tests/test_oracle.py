@@ -191,7 +191,8 @@ def test_fp8_bound_maxima_against_numpy(mode):
     """oz2_bound_maxima_f8 (exported for the GPU bound-maxima parity test; the function oz2_bound_shifts runs) against an
     independent numpy statement of find_max.hpp:82-96: decode e4m3, exact products and sums, one rounding to float,
     inflate by ku rounding up -- mode 1: the reference's ku = (k+1)*2^-24; mode 0: the product's engine-safe
-    ku = 7*2^-13 + 4(k+1)*2^-24 (include/gemmul8_c.h, gemmul8_set_fp8_bound_mode)."""
+    ku = 7*2^-13 + 4(k+1)*2^-24 plus, round 4, the absolute term kabs = 7*pad256(k)*2^-14 added rounding up
+    (include/gemmul8_c.h, gemmul8_set_fp8_bound_mode)."""
     def e4m3(b):
         b = b.astype(np.int64)
         e, mnt = (b >> 3) & 15, b & 7
@@ -211,7 +212,11 @@ def test_fp8_bound_maxima_against_numpy(mode):
     ku = ol.fp8_bound_ku(k, mode)
     assert ku == ((k + 1) * 2.0 ** -24 if mode == 1 else 7 * 2.0 ** -13 + 4 * (k + 1) * 2.0 ** -24)   # exact in float32 at this k
     prod = (e4m3(oA[0]) @ e4m3(oB[0]).T).astype(np.float32).astype(np.float64)   # [m][n], exact in double
-    x = prod + prod * ku                                                         # exact in double (48-bit product)
-    up = x.astype(np.float32)
-    up = np.where(up.astype(np.float64) < x, np.nextafter(up, np.float32(np.inf)), up)
+    def ru32(x):
+        up = x.astype(np.float32)
+        return np.where(up.astype(np.float64) < x, np.nextafter(up, np.float32(np.inf)), up)
+    up = ru32(prod + prod * ku)                                                  # exact in double (48-bit product), one rounding up
+    if mode == 0:
+        kabs = 7.0 * ((k + 255) // 256 * 256) * 2.0 ** -14
+        up = ru32(up.astype(np.float64) + kabs)                                  # second rounding up, like the device's __fadd_ru
     assert np.array_equal(rmax, up.max(axis=1)) and np.array_equal(cmax, up.max(axis=0))
