@@ -23,6 +23,7 @@ ap.add_argument("--rounds", type=int, default=9)
 ap.add_argument("--check", action="store_true", help="compare the residue planes every build writes with the first build's (bit for bit)")
 ap.add_argument("--smi", action="store_true", help="sample sclk / socket power (rocm-smi) while each build loops for ~1.5 s")
 ap.add_argument("--fused", action="store_true", help="time gemmul8_lowprec_gemm_crt (GEMMs + CRT in one launch) of every build; the first build's two-launch path (lowprec_gemm + crt) is timed beside it")
+ap.add_argument("--range", type=int, default=0, help="operand bytes uniform in [-R, R] instead of all 256 int8 values (energy per MAC depends on the data)")
 a = ap.parse_args()
 n, N = a.size, a.moduli
 ref = g.lib()  # binds the HIP runtime, gives layout/work_size
@@ -53,8 +54,12 @@ for k in [int(x) for x in a.k.split(",")]:
     Lo = g.Layout()
     g.check(ref.gemmul8_get_layout(g.D, g.INT8, n, n, k, N, work.data_ptr(), None, None, 0, 0, C.byref(Lo)))
     offA, offB = Lo.A_lo - work.data_ptr(), Lo.B_lo - work.data_ptr()
-    work[offA:offA + N * Lo.sizeA] = torch.randint(0, 256, (N * Lo.sizeA,), dtype=torch.uint8, device="cuda")
-    work[offB:offB + N * Lo.sizeB] = torch.randint(0, 256, (N * Lo.sizeB,), dtype=torch.uint8, device="cuda")
+    def planes(nbytes):
+        if a.range:
+            return torch.randint(-a.range, a.range + 1, (nbytes,), dtype=torch.int8, device="cuda").view(torch.uint8)
+        return torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device="cuda")
+    work[offA:offA + N * Lo.sizeA] = planes(N * Lo.sizeA)
+    work[offB:offB + N * Lo.sizeB] = planes(N * Lo.sizeB)
     Cout = torch.zeros((n, n), dtype=torch.float64, device="cuda")
     offS = Lo.sftA - work.data_ptr()
     work[offS:offS + 2 * Lo.mp] = 0
