@@ -284,9 +284,11 @@ int gemmul8_scale_finish(void* stream_, int dtype, int backend, int op_A, int op
     const bool cplx = is_complex(dtype);
     const bool kmajA = op_A != 0, kmajB = op_B == 0;
     const bool conjA = cplx && op_A == 2, conjB = cplx && op_B == 2;
+    QuantOperand oa, ob;  // rows == 0: the operand is skipped
+    if (!skipA) oa = QuantOperand{kmajA, conjA, m, A, lda, L->sftA, (int8_t*)L->A_lo, L->sizeA, L->part_strideA, g_batch.sa};
+    if (!skipB) ob = QuantOperand{kmajB, conjB, n, B, ldb, L->sftB, (int8_t*)L->B_lo, L->sizeB, L->part_strideB, g_batch.sb};
     if (fastmode) {
-        if (!skipA) OZ2_HIP(launch_fast_shift(stream, dtype, backend, N, kmajA, m, k, A, lda, L->sftA, g_batch.sa));
-        if (!skipB) OZ2_HIP(launch_fast_shift(stream, dtype, backend, N, kmajB, n, k, B, ldb, L->sftB, g_batch.sb));
+        OZ2_HIP(launch_fast_shift_pair(stream, dtype, backend, N, k, oa, ob));
     } else {
         int *rowmax, *colmax;
         void* amax;
@@ -294,12 +296,7 @@ int gemmul8_scale_finish(void* stream_, int dtype, int backend, int op_A, int op
         if (rc) return rc;
         OZ2_HIP(launch_shift_finalize(stream, backend, N, skipA ? 0 : m, rowmax, L->sftA, skipB ? 0 : n, colmax, L->sftB));
     }
-    if (!skipA)
-        OZ2_HIP(launch_quantise(stream, dtype, backend, N, (int)t_begin, (int)t_end, kmajA, conjA, m, k, A, lda, L->sftA, (int8_t*)L->A_lo,
-                                L->sizeA, L->part_strideA, L->kp, g_batch.sa));
-    if (!skipB)
-        OZ2_HIP(launch_quantise(stream, dtype, backend, N, (int)t_begin, (int)t_end, kmajB, conjB, n, k, B, ldb, L->sftB, (int8_t*)L->B_lo,
-                                L->sizeB, L->part_strideB, L->kp, g_batch.sb));
+    OZ2_HIP(launch_quantise_pair(stream, dtype, backend, (int)t_begin, (int)t_end, k, L->kp, oa, ob));
     return GEMMUL8_OK;
 }
 

@@ -67,11 +67,21 @@ hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajo
                           size_t xstride = 0);
 hipError_t launch_shift_finalize(hipStream_t stream, int backend, unsigned N, size_t rowsA, const int* maxA, int16_t* sftA, size_t rowsB,
                                  const int* maxB, int16_t* sftB);
-hipError_t launch_fast_shift(hipStream_t stream, int dtype, int backend, unsigned N, bool kmajor, size_t rows, size_t k, const void* X,
-                             size_t ld, int16_t* sft, size_t xstride = 0);
-hipError_t launch_quantise(hipStream_t stream, int dtype, int backend, unsigned N, int t_begin, int t_end, bool kmajor, bool conj,
-                           size_t rows, size_t k, const void* X, size_t ld, const int16_t* sft, int8_t* lo, size_t plane_stride,
-                           size_t part_stride, size_t kp, size_t xstride = 0);
+// one operand of the quantise / fast-shift launches; rows == 0 = absent (skip-scaling: the cached planes and shifts are kept)
+struct QuantOperand {
+    bool kmajor = false, conj = false;
+    size_t rows = 0;
+    const void* X = nullptr;
+    size_t ld = 0;
+    int16_t* sft = nullptr;   // fast shift: written; quantise: read (negated final shifts)
+    int8_t* lo = nullptr;
+    size_t plane_stride = 0, part_stride = 0;
+    size_t xstride = 0;       // batched launch: bytes between the items' operands
+};
+// both operands in ONE launch each (the A and B halves are independent; at launch-bound sizes every dispatch costs 5-10 us)
+hipError_t launch_fast_shift_pair(hipStream_t stream, int dtype, int backend, unsigned N, size_t k, const QuantOperand& A, const QuantOperand& B);
+hipError_t launch_quantise_pair(hipStream_t stream, int dtype, int backend, int t_begin, int t_end, size_t k, size_t kp, const QuantOperand& A,
+                                const QuantOperand& B);
 
 // ---- CRT accumulation + inverse scaling (oz2_crt.hip)
 hipError_t launch_crt(hipStream_t stream, int dtype, int backend, unsigned N, size_t m, size_t n, const void* Cmid, size_t ld_mid,

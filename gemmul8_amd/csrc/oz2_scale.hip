@@ -554,15 +554,15 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
 
 // K-major operand: one 256-thread block per row; thread = 4 consecutive k per 1024-wide sweep
 template <typename T, int MODE>
-__global__ void __launch_bounds__(256) stage_kmajor_kernel(const StageArgs a) {
+__device__ __forceinline__ void stage_kmajor_body(const StageArgs& a, const unsigned bid) {
     using E = ET<T>;
     using U = typename E::U;
     if constexpr (MODE == MODE_MOD && OZ2_STAGE_KCHUNK && sizeof(T) <= 8) {  // (16-byte elements measured 4 % better with the row loop)
         // quantise: one workgroup per 1024-wide k chunk of a row, the chunk index fastest: the workgroups in flight walk through
         // memory together (one row after the other) instead of streaming ~2000 rows at once
         const unsigned nch = (unsigned)(a.kp / 1024 + (a.kp % 1024 != 0));
-        const size_t row = blockIdx.x / nch;
-        const size_t k0 = (size_t)(blockIdx.x - row * nch) * 1024 + (size_t)threadIdx.x * 4;
+        const size_t row = bid / nch;
+        const size_t k0 = (size_t)(bid - row * nch) * 1024 + (size_t)threadIdx.x * 4;
         if (k0 >= a.kp) return;
         const T* x = (const T*)((const char*)a.X + OZ2_ZX) + row * a.ld;
         const int s = -(int)((const int16_t*)((const char*)a.sft + OZ2_ZW))[row];
@@ -571,7 +571,7 @@ __global__ void __launch_bounds__(256) stage_kmajor_kernel(const StageArgs a) {
         emit4<T, MODE>(a, row, k0, v, s);
         return;
     }
-    const size_t row = blockIdx.x;
+    const size_t row = bid;
     const T* x = (const T*)((const char*)a.X + OZ2_ZX) + row * a.ld;
     int s;
     if constexpr (MODE == MODE_BOUND) {
@@ -662,7 +662,7 @@ template <typename T> struct StageTile {
     static constexpr int TK = (sizeof(T) == 16 && !OZ2_STAGE_Z_WIDE) ? 64 : 128;
 };
 template <typename T, int MODE>
-__global__ void __launch_bounds__(256) stage_strided_kernel(const StageArgs a) {
+__device__ __forceinline__ void stage_strided_body(const StageArgs& a, const unsigned bid) {
     using E = ET<T>;
     using U = typename E::U;
     constexpr int TR = StageTile<T>::TR, TK = StageTile<T>::TK;
@@ -672,10 +672,10 @@ __global__ void __launch_bounds__(256) stage_strided_kernel(const StageArgs a) {
     __shared__ __attribute__((aligned(16))) T tile[TR][PITCH];
 #if OZ2_STAGE_RTFAST
     const unsigned nrt = (unsigned)((a.rows + TR - 1) / TR);
-    const unsigned kt = blockIdx.x / nrt, rt = blockIdx.x - kt * nrt;
+    const unsigned kt = bid / nrt, rt = bid - kt * nrt;
 #else
     const unsigned nkt = (unsigned)(a.kp / TK);
-    const unsigned rt = blockIdx.x / nkt, kt = blockIdx.x - rt * nkt;
+    const unsigned rt = bid / nkt, kt = bid - rt * nkt;
 #endif
     const size_t r0 = (size_t)rt * TR;
     const size_t kb = (size_t)kt * TK;
@@ -753,6 +753,24 @@ __global__ void __launch_bounds__(256) stage_strided_kernel(const StageArgs a) {
     }
 }
 
+// accurate-mode extract (MODE_BOUND): one operand per launch (a row-strided operand needs its row maxima first)
+template <typename T> __global__ void __launch_bounds__(256) extract_kmajor_kernel(const StageArgs a) { stage_kmajor_body<T, MODE_BOUND>(a, blockIdx.x); }
+template <typename T> __global__ void __launch_bounds__(256) extract_strided_kernel(const StageArgs a) { stage_strided_body<T, MODE_BOUND>(a, blockIdx.x); }
+// quantise (MODE_MOD) of BOTH operands in one launch: workgroups [0, nA) work on a, the rest on b; either share may be empty (skip-scaling,
+// single-operand callers).  The two halves are independent and at launch-bound sizes each of them is a ~5-10 us dispatch (1024^3: 12.7 + 9.5 us,
+// together ... see DESIGN.md 3.2); the form of each operand (K-major / row-strided) is a uniform run-time branch, registers and LDS are the
+// maximum of the two forms (40 / 47 VGPRs, 0 / 16.6 KiB for double).
+template <typename T> __global__ void __launch_bounds__(256) quantise_pair_kernel(const StageArgs a, const StageArgs b, const unsigned nA, const int kmA, const int kmB) {
+    if (blockIdx.x < nA) {
+        if (kmA) stage_kmajor_body<T, MODE_MOD>(a, blockIdx.x);
+        else stage_strided_body<T, MODE_MOD>(a, blockIdx.x);
+    } else {
+        if (kmB) stage_kmajor_body<T, MODE_MOD>(b, blockIdx.x - nA);
+        else stage_strided_body<T, MODE_MOD>(b, blockIdx.x - nA);
+    }
+}
+static_assert(2 * sizeof(StageArgs) + 16 <= 4096, "two argument blocks must fit the 4 KiB kernel-argument segment");
+
 // per-row amax of a row-strided operand: grid (ceil(rows/64), ksplit), 256 threads = 64 rows x 4 k-lanes
 template <typename T> __global__ void __launch_bounds__(256) amax_strided_kernel(const T* X, size_t ld, size_t rows, size_t k, void* amax, size_t bx, size_t bw) {
     X = (const T*)((const char*)X + blockIdx.z * bx);  // batched launch: item blockIdx.z
@@ -824,30 +842,34 @@ template <typename T> __global__ void __launch_bounds__(256) amax_strided_kernel
     }
 }
 
-template <typename T, int MODE> static hipError_t launch_stage(hipStream_t stream, bool kmajor, const StageArgs& a) {
-    if (kmajor) {
-        size_t blocks = a.rows;
-        if (MODE == MODE_MOD && OZ2_STAGE_KCHUNK && sizeof(T) <= 8) blocks *= (a.kp + 1023) / 1024;
-        if (blocks > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
-        dim3 grid((unsigned)blocks, 1, g_batch.batch);
-        hipLaunchKernelGGL((stage_kmajor_kernel<T, MODE>), grid, dim3(256), 0, stream, a);
-    } else {
-        const size_t blocks = (a.kp / StageTile<T>::TK) * ((a.rows + StageTile<T>::TR - 1) / StageTile<T>::TR);
-        if (blocks > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
-        dim3 grid((unsigned)blocks, 1, g_batch.batch);
-        hipLaunchKernelGGL((stage_strided_kernel<T, MODE>), grid, dim3(256), 0, stream, a);
-    }
+template <typename T, int MODE> static size_t stage_blocks(bool kmajor, const StageArgs& a) {
+    if (a.rows == 0) return 0;
+    if (kmajor) return a.rows * ((MODE == MODE_MOD && OZ2_STAGE_KCHUNK && sizeof(T) <= 8) ? (a.kp + 1023) / 1024 : 1);
+    return (a.kp / StageTile<T>::TK) * ((a.rows + StageTile<T>::TR - 1) / StageTile<T>::TR);
+}
+template <typename T> static hipError_t launch_extract_stage(hipStream_t stream, bool kmajor, const StageArgs& a) {
+    const size_t blocks = stage_blocks<T, MODE_BOUND>(kmajor, a);
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
+    dim3 grid((unsigned)blocks, 1, g_batch.batch);
+    if (kmajor) hipLaunchKernelGGL(extract_kmajor_kernel<T>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(extract_strided_kernel<T>, grid, dim3(256), 0, stream, a);
     return hipGetLastError();
 }
-
-template <int MODE> static hipError_t dispatch_stage(hipStream_t stream, int dtype, bool kmajor, const StageArgs& a) {
+static hipError_t dispatch_extract_stage(hipStream_t stream, int dtype, bool kmajor, const StageArgs& a) {
     switch (dtype) {
-    case kF32: return launch_stage<float, MODE>(stream, kmajor, a);
-    case kF64: return launch_stage<double, MODE>(stream, kmajor, a);
-    case kC32: return launch_stage<float2, MODE>(stream, kmajor, a);
-    case kC64: return launch_stage<double2, MODE>(stream, kmajor, a);
+    case kF32: return launch_extract_stage<float>(stream, kmajor, a);
+    case kF64: return launch_extract_stage<double>(stream, kmajor, a);
+    case kC32: return launch_extract_stage<float2>(stream, kmajor, a);
+    case kC64: return launch_extract_stage<double2>(stream, kmajor, a);
     }
     return hipErrorInvalidValue;
+}
+template <typename T> static hipError_t launch_quantise_stage(hipStream_t stream, bool kmA, const StageArgs& a, bool kmB, const StageArgs& b) {
+    const size_t nA = stage_blocks<T, MODE_MOD>(kmA, a), nB = stage_blocks<T, MODE_MOD>(kmB, b);
+    if (nA + nB == 0) return hipSuccess;
+    if (nA + nB > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(quantise_pair_kernel<T>, dim3((unsigned)(nA + nB), 1, g_batch.batch), dim3(256), 0, stream, a, b, (unsigned)nA, (int)kmA, (int)kmB);
+    return hipGetLastError();
 }
 
 __global__ void __launch_bounds__(256) zero_words_kernel(unsigned* p, size_t nwords, size_t bw) {
@@ -885,7 +907,7 @@ hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajo
     a.amax = scratch_amax;
     a.backend = backend;
     a.conj = conj;
-    if (kmajor) return dispatch_stage<MODE_BOUND>(stream, dtype, kmajor, a);
+    if (kmajor) return dispatch_extract_stage(stream, dtype, kmajor, a);
 
     const size_t ub = is_f32(dtype) ? 4 : 8;                        // bytes of an amax slot
     const size_t esz = ub * (is_complex(dtype) ? 2 : 1);            // bytes of an element
@@ -927,30 +949,27 @@ hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajo
         b.lo = lo + r0 * kp;
         b.sft0 = sft0 + r0;
         b.amax = amax_b;
-        e = dispatch_stage<MODE_BOUND>(stream, dtype, kmajor, b);
+        e = dispatch_extract_stage(stream, dtype, kmajor, b);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }
 
-hipError_t launch_quantise(hipStream_t stream, int dtype, int backend, unsigned N, int t_begin, int t_end, bool kmajor, bool conj,
-                           size_t rows, size_t k, const void* X, size_t ld, const int16_t* sft, int8_t* lo, size_t plane_stride,
-                           size_t part_stride, size_t kp, size_t xstride) {
-    if (rows == 0 || t_end <= t_begin) return hipSuccess;
+static StageArgs quantise_args(int backend, int t_begin, int t_end, size_t k, size_t kp, const QuantOperand& o) {
     StageArgs a{};
-    a.bx = xstride;
+    a.bx = o.xstride;
     a.bw = g_batch.ws;
-    a.X = X;
-    a.ld = ld;
-    a.rows = rows;
+    a.X = o.X;
+    a.ld = o.ld;
+    a.rows = o.rows;
     a.k = k;
     a.kp = kp;
-    a.lo = lo;
-    a.plane_stride = plane_stride;
-    a.part_stride = part_stride;
-    a.sft = sft;
+    a.lo = o.lo;
+    a.plane_stride = o.plane_stride;
+    a.part_stride = o.part_stride;
+    a.sft = o.sft;
     a.backend = backend;
-    a.conj = conj;
+    a.conj = o.conj;
     a.t_begin = t_begin;
     a.t_end = t_end;
     a.mt = make_mod_table(backend);
@@ -960,8 +979,20 @@ hipError_t launch_quantise(hipStream_t stream, int dtype, int backend, unsigned 
         a.pairInvP[j] = 1.0 / P;
     }
     for (int t = 0; t < 6; ++t) a.sqrtp[t] = GEMMUL8_SQRT_MODULI_FP8[t];
-    (void)N;
-    return dispatch_stage<MODE_MOD>(stream, dtype, kmajor, a);
+    return a;
+}
+
+hipError_t launch_quantise_pair(hipStream_t stream, int dtype, int backend, int t_begin, int t_end, size_t k, size_t kp, const QuantOperand& A,
+                                const QuantOperand& B) {
+    if ((A.rows == 0 && B.rows == 0) || t_end <= t_begin) return hipSuccess;
+    const StageArgs a = quantise_args(backend, t_begin, t_end, k, kp, A), b = quantise_args(backend, t_begin, t_end, k, kp, B);
+    switch (dtype) {
+    case kF32: return launch_quantise_stage<float>(stream, A.kmajor, a, B.kmajor, b);
+    case kF64: return launch_quantise_stage<double>(stream, A.kmajor, a, B.kmajor, b);
+    case kC32: return launch_quantise_stage<float2>(stream, A.kmajor, a, B.kmajor, b);
+    case kC64: return launch_quantise_stage<double2>(stream, A.kmajor, a, B.kmajor, b);
+    }
+    return hipErrorInvalidValue;
 }
 
 // ------------------------------------------------------------------ accurate-mode shift from the bound maxima
@@ -1036,13 +1067,11 @@ __device__ __forceinline__ int fast_sft(float amax, float vecnrm, float log2P) {
 }
 
 // K-major: one 256-thread block per row (scaling_fast_real.hpp:142-164)
-template <typename T> __global__ void __launch_bounds__(256) fast_shift_kmajor_kernel(const T* X, size_t ld, size_t k, int16_t* sft, float log2P, size_t bx, size_t bw) {
-    X = (const T*)((const char*)X + blockIdx.z * bx);  // batched launch: item blockIdx.z
-    sft = (int16_t*)((char*)sft + blockIdx.z * bw);
+template <typename T> __device__ __forceinline__ void fast_shift_kmajor_body(const T* X, size_t ld, size_t k, int16_t* sft, float log2P, const unsigned bid) {
     using E = ET<T>;
     using U = typename E::U;
     __shared__ U samax[32], ssum[32];
-    const T* x = X + (size_t)blockIdx.x * ld;
+    const T* x = X + (size_t)bid * ld;
     U amax = 0, sum = 0;
     size_t i = threadIdx.x;
     for (; i + 3 * 256 < k; i += 4 * 256) {  // four loads ahead of their (sequential) round-up FMAs
@@ -1084,7 +1113,7 @@ template <typename T> __global__ void __launch_bounds__(256) fast_shift_kmajor_k
         sum = threadIdx.x < 8 ? ssum[threadIdx.x] : (U)0;
         amax = tree32_max(amax);
         sum = tree32_sum_ru(sum);
-        if (threadIdx.x == 0) sft[blockIdx.x] = (int16_t)(-fast_sft(amax, sum, log2P));
+        if (threadIdx.x == 0) sft[bid] = (int16_t)(-fast_sft(amax, sum, log2P));
     }
 }
 
@@ -1094,15 +1123,13 @@ template <typename T> __global__ void __launch_bounds__(256) fast_shift_kmajor_k
 // = one 128-byte line per column -- 512 workgroups for 8192 rows of doubles where the 32 x 32 form had 256 and 8-byte loads.  The loads of
 // eight chain steps are issued ahead of their round-up FMAs: the chain itself is sequential, and with one load per step it ran at one
 // memory latency per element (289 us for 1024 x 16384 doubles; 128 MiB).
-template <typename T> __global__ void __launch_bounds__(256) fast_shift_strided_kernel(const T* X, size_t ld, size_t rows, size_t k, int16_t* sft, float log2P, size_t bx, size_t bw) {
-    X = (const T*)((const char*)X + blockIdx.z * bx);  // batched launch: item blockIdx.z
-    sft = (int16_t*)((char*)sft + blockIdx.z * bw);
+template <typename T> __device__ __forceinline__ void fast_shift_strided_body(const T* X, size_t ld, size_t rows, size_t k, int16_t* sft, float log2P, const unsigned bid) {
     using E = ET<T>;
     using U = typename E::U;
     constexpr int RPL = 16 / (int)sizeof(T), RPB = 8 * RPL;
     __shared__ U samax[32][RPB + 1], ssum[32][RPB + 1];
     const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
-    const size_t row0 = (size_t)blockIdx.x * RPB + (size_t)tx * RPL;
+    const size_t row0 = (size_t)bid * RPB + (size_t)tx * RPL;
     U amax[RPL], sum[RPL];
 #pragma unroll
     for (int j = 0; j < RPL; ++j) amax[j] = 0, sum[j] = 0;
@@ -1178,32 +1205,46 @@ template <typename T> __global__ void __launch_bounds__(256) fast_shift_strided_
     for (int rr = threadIdx.x >> 5; rr < RPB; rr += 8) {
         const U s = tree32_sum_ru(ssum[ll][rr]);
         const U m = tree32_max(samax[ll][rr]);
-        const size_t row = (size_t)blockIdx.x * RPB + rr;
+        const size_t row = (size_t)bid * RPB + rr;
         if (row < rows && ll == 0) sft[row] = (int16_t)(-fast_sft(m, s, log2P));
     }
 }
 
-hipError_t launch_fast_shift(hipStream_t stream, int dtype, int backend, unsigned N, bool kmajor, size_t rows, size_t k, const void* X,
-                             size_t ld, int16_t* sft, size_t xstride) {
-    if (rows == 0) return hipSuccess;
+// both operands in one launch: workgroups [0, a.blocks) take the rows of A, the rest the columns of B; either share may be empty
+struct ShiftOperand {
+    const void* X;
+    size_t ld, rows, bx;
+    int16_t* sft;
+    unsigned blocks;
+    int kmajor;
+};
+template <typename T> __global__ void __launch_bounds__(256) fast_shift_pair_kernel(const ShiftOperand a, const ShiftOperand b, size_t k, float log2P, size_t bw) {
+    const bool isB = blockIdx.x >= a.blocks;
+    const ShiftOperand& o = isB ? b : a;  // (kernel arguments: a scalar select per field, no copy)
+    const unsigned bid = isB ? blockIdx.x - a.blocks : blockIdx.x;
+    const T* X = (const T*)((const char*)o.X + blockIdx.z * o.bx);  // batched launch: item blockIdx.z
+    int16_t* sft = (int16_t*)((char*)o.sft + blockIdx.z * bw);
+    if (o.kmajor) fast_shift_kmajor_body<T>(X, o.ld, k, sft, log2P, bid);
+    else fast_shift_strided_body<T>(X, o.ld, o.rows, k, sft, log2P, bid);
+}
+
+hipError_t launch_fast_shift_pair(hipStream_t stream, int dtype, int backend, unsigned N, size_t k, const QuantOperand& A, const QuantOperand& B) {
+    if (A.rows == 0 && B.rows == 0) return hipSuccess;
     const float log2P = backend == kINT8 ? GEMMUL8_LOG2P_INT8[N - 2] : GEMMUL8_LOG2P_FP8[N - 2];
-    if (kmajor) {
-        dim3 grid((unsigned)rows, 1, g_batch.batch);
-        switch (dtype) {
-        case kF32: hipLaunchKernelGGL(fast_shift_kmajor_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, ld, k, sft, log2P, xstride, g_batch.ws); break;
-        case kF64: hipLaunchKernelGGL(fast_shift_kmajor_kernel<double>, grid, dim3(256), 0, stream, (const double*)X, ld, k, sft, log2P, xstride, g_batch.ws); break;
-        case kC32: hipLaunchKernelGGL(fast_shift_kmajor_kernel<float2>, grid, dim3(256), 0, stream, (const float2*)X, ld, k, sft, log2P, xstride, g_batch.ws); break;
-        case kC64: hipLaunchKernelGGL(fast_shift_kmajor_kernel<double2>, grid, dim3(256), 0, stream, (const double2*)X, ld, k, sft, log2P, xstride, g_batch.ws); break;
-        }
-    } else {
-        const size_t rpb = 8 * (16 / (is_f32(dtype) ? 4 : 8) / (is_complex(dtype) ? 2 : 1));
-        dim3 grid((unsigned)((rows + rpb - 1) / rpb), 1, g_batch.batch);
-        switch (dtype) {
-        case kF32: hipLaunchKernelGGL(fast_shift_strided_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
-        case kF64: hipLaunchKernelGGL(fast_shift_strided_kernel<double>, grid, dim3(256), 0, stream, (const double*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
-        case kC32: hipLaunchKernelGGL(fast_shift_strided_kernel<float2>, grid, dim3(256), 0, stream, (const float2*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
-        case kC64: hipLaunchKernelGGL(fast_shift_strided_kernel<double2>, grid, dim3(256), 0, stream, (const double2*)X, ld, rows, k, sft, log2P, xstride, g_batch.ws); break;
-        }
+    const size_t rpb = 8 * (16 / (is_f32(dtype) ? 4 : 8) / (is_complex(dtype) ? 2 : 1));  // rows per workgroup of the row-strided form
+    auto operand = [&](const QuantOperand& o) {
+        const size_t blocks = o.kmajor ? o.rows : (o.rows + rpb - 1) / rpb;
+        return ShiftOperand{o.X, o.ld, o.rows, o.xstride, o.sft, (unsigned)blocks, o.kmajor ? 1 : 0};
+    };
+    if (A.rows + B.rows > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
+    const ShiftOperand a = operand(A), b = operand(B);
+    dim3 grid(a.blocks + b.blocks, 1, g_batch.batch);
+    switch (dtype) {
+    case kF32: hipLaunchKernelGGL(fast_shift_pair_kernel<float>, grid, dim3(256), 0, stream, a, b, k, log2P, g_batch.ws); break;
+    case kF64: hipLaunchKernelGGL(fast_shift_pair_kernel<double>, grid, dim3(256), 0, stream, a, b, k, log2P, g_batch.ws); break;
+    case kC32: hipLaunchKernelGGL(fast_shift_pair_kernel<float2>, grid, dim3(256), 0, stream, a, b, k, log2P, g_batch.ws); break;
+    case kC64: hipLaunchKernelGGL(fast_shift_pair_kernel<double2>, grid, dim3(256), 0, stream, a, b, k, log2P, g_batch.ws); break;
+    default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
