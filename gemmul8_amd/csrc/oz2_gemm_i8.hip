@@ -84,7 +84,8 @@ struct NoCrt {
 #ifdef OZ2_LAB_FUSED_CRT
 #include OZ2_LAB_FUSED_CRT  // i8_crt_tail, i8_producer_crt
 #endif
-template <int EPI, bool KBAR, int FUSE>
+// SMALLK: the launch has K <= 512 (accumulators start at 0, three-instruction residue); the epilogue form is a compile-time property of the kernel
+template <int EPI, bool KBAR, int FUSE, bool SMALLK = false>
 __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args, const std::conditional_t<FUSE != 0, CrtArgs, NoCrt> crt) {
 #ifndef OZ2_LAB_FUSED_CRT
     static_assert(FUSE == 0, "the in-kernel CRT forms are laboratory code: tools/experiments/fused_crt");
@@ -214,8 +215,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][j][r] = EPI == EPI_MAX ? 0 : args.acc0;
+                    acc[i][j] = v4i{EPI == EPI_MAX ? 0 : args.acc0, EPI == EPI_MAX ? 0 : args.acc0, EPI == EPI_MAX ? 0 : args.acc0, EPI == EPI_MAX ? 0 : args.acc0};
 #define OZ2_LOAD_SEG(seg_)                                                                                                   \
     do {                                                                                                                     \
         const int coff_ = (((((seg_) >> 1) << 2) | q) ^ sw) << 4;                                                            \
@@ -276,7 +276,8 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #pragma unroll
                 for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-            i8_epilogue<EPI>(acc, args, FUSE ? PlaneRef{0, pl} : plane_ref(args, tmap.plane), tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane);
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            i8_epilogue<EPI, NoHook, FUSE != 0 ? -1 : (int)SMALLK>(acc, args, FUSE ? PlaneRef{0, pl} : plane_ref(args, tmap.plane), tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane);
 #endif
             }  // phase
             }
@@ -300,8 +301,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = EPI == EPI_MAX ? 0 : args.acc0;
+                acc[i][j] = v4i{EPI == EPI_MAX ? 0 : args.acc0, EPI == EPI_MAX ? 0 : args.acc0, EPI == EPI_MAX ? 0 : args.acc0, EPI == EPI_MAX ? 0 : args.acc0};
 
         int kt = 0;  // phases: see the K-step-barrier branch
         const int nph = (EPI == EPI_MAX && args.kt_mid > 0) ? 2 : 1;
@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-        i8_epilogue<EPI>(acc, args, FUSE ? PlaneRef{0, pl} : plane_ref(args, tmap.plane), tmap.tm * BM + wm * 128, tmap.tn * BN + wn * 64, lane);
+        i8_epilogue<EPI, NoHook, FUSE != 0 ? -1 : (int)SMALLK>(acc, args, FUSE ? PlaneRef{0, pl} : plane_ref(args, tmap.plane), tmap.tm * BM + wm * 128, tmap.tn * BN + wn * 64, lane);
 #endif
         }  // phase
         }
@@ -392,7 +392,7 @@ static int num_cus() {
     return n;
 }
 
-template <int EPI, bool KBAR, int FUSE = 0>
+template <int EPI, bool KBAR, int FUSE = 0, bool SMALLK = false>
 static hipError_t launch_sched(hipStream_t stream, GemmArgs& a, const std::conditional_t<FUSE != 0, CrtArgs, NoCrt>& crt = {}) {
     // the attribute belongs to the function on ONE device; setting it is idempotent, so concurrent first calls from several host
     // threads only need the flag itself to be race-free
@@ -400,7 +400,7 @@ static hipError_t launch_sched(hipStream_t stream, GemmArgs& a, const std::condi
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 0;
     if (!attr_set_dev[dev_].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_kernel<EPI, KBAR, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_i8_kernel<EPI, KBAR, FUSE, SMALLK>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set_dev[dev_].store(true, std::memory_order_release);
     }
@@ -410,7 +410,7 @@ static hipError_t launch_sched(hipStream_t stream, GemmArgs& a, const std::condi
     int grid = num_cus() & ~7;
     if (grid <= 0) grid = 8;
     if (a.total_tiles < grid) grid = a.total_tiles;
-    hipLaunchKernelGGL((gemm_i8_kernel<EPI, KBAR, FUSE>), dim3(grid), dim3(WS_THREADS), RING_LDS_BYTES, stream, a, crt);
+    hipLaunchKernelGGL((gemm_i8_kernel<EPI, KBAR, FUSE, SMALLK>), dim3(grid), dim3(WS_THREADS), RING_LDS_BYTES, stream, a, crt);
     return hipGetLastError();
 }
 
@@ -436,7 +436,10 @@ template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int
         if (a.nseg == 1 && a.kp <= OZ2_LAB_SHORTK) return launch_gemm_i8_shortk(stream, a, EPI);
     }
 #endif
-    if (EPI != EPI_MAX && a.kp * a.nseg <= OZ2_KBAR_MAX_KP) return launch_sched<EPI, true>(stream, a);
+    if constexpr (EPI != EPI_MAX) {
+        if (a.acc0 == 0) return launch_sched<EPI, true, 0, true>(stream, a);  // K <= 512
+        if (a.kp * a.nseg <= OZ2_KBAR_MAX_KP) return launch_sched<EPI, true>(stream, a);
+    }
     return launch_sched<EPI, false>(stream, a);
 }
 

@@ -77,139 +77,203 @@ template <typename Args> __device__ __forceinline__ PlaneRef plane_ref(const Arg
     const int b = p / args.ppi;
     return {(size_t)b * args.bstride, p - b * args.ppi};
 }
-enum { RED_GENERIC = 0, RED_ODD = 1, RED_256 = 2, RED_ODD_SMALL = 3 };
-// RED selects how an accumulator is reduced (uniform per plane): RED_256: p = 256, the symmetric residue IS the low byte;
-// RED_ODD: odd p, ONE exact FP64 quotient step for any int32 accumulator (v_cvt_f64_i32, v_mul_f64, v_rndne_f64, v_fma_f64,
-// v_cvt_i32_f64: FP64 VALU runs at the FP32 rate on gfx950); the two-step fp32 form it replaced cost 10 instructions and 12 % of
-// the kernel time at k = 1024.  (Reading the quotient from the low dword of fma(a, 1/p, 1.5 * 2^52) and finishing with
-// v_mad_i32_i24 -- three instructions -- measured 10 % SLOWER at k = 1024: the dependent FP64 chains no longer overlap.)
-// RED_GENERIC: 32-bit multiply-high (even p other than 256: no INT8 modulus, kept for completeness).
+enum { RED_ODD = 1, RED_ODD_SMALL = 3 };
+// RED selects how an accumulator is reduced to its residue's low byte -- one form per kernel instantiation (i8_epilogue): RED_ODD for any int32
+// accumulator (byte dot product on the biased accumulator + one fp32 quotient, below), RED_ODD_SMALL for launches with K <= 512.  p = 256 runs through
+// the same forms: every quotient leaves the low byte of the accumulator in place.  History: an FP64 quotient step (5 instructions; the two-step fp32
+// form before it cost 10 and 12 % of the kernel time at k = 1024); reading the FP64 quotient from the low dword of fma(a, 1/p, 1.5 * 2^52) --
+// three instructions -- measured 10 % SLOWER at k = 1024 (the dependent FP64 chains no longer overlap); separate run-time forms for p = 256 (low
+// byte) and for even p (32-bit multiply-high, no INT8 modulus needs it) existed until round 4 and cost far more than they saved (i8_epilogue).
 // Hook: called as hook(s, 0) before and hook(s, 1) after the stores of sub-block s = 2 tj + tg (64 rows x 16 columns; 8 per wave tile); NoHook
 // (nothing) in every product kernel -- the laboratory short-K kernel places its workgroup barriers there (tools/experiments/shortk).
 struct NoHook {
     __device__ __forceinline__ void operator()(int, int) const {}
 };
+// 16-byte store of the lanes whose column exists (col < n), WITHOUT a branch: the execution mask is narrowed and restored inside one asm block.
+// A divergent `if (col < n)` around every store made the whole epilogue a non-uniform region, and the structurizer then LINEARISED the (uniform) chain
+// of reduction variants around it -- variant after variant in one straight line, each guarded by its predicate --, so that the accumulators stayed
+// live through the complete epilogue of every variant but the last: no accumulator register could be reused, the residues, the X / Y values and the
+// store addresses of the complex combine went to scratch (64-144 bytes), and every reload in between is a vector-memory wait that serialises the
+// epilogue's loads (see the EPI_CPLX branch below).  The waitcnt pass does not see the store; hidden stores only make its vmcnt waits conservative.
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ void store16_cols(void* ptr, v4u d, int col, int n) {
+    unsigned long long saved;
+    if constexpr (NT)
+        asm volatile("s_mov_b64 %0, exec\n\tv_cmp_gt_i32_e32 vcc, %1, %2\n\ts_and_b64 exec, exec, vcc\n\tglobal_store_dwordx4 %3, %4, off nt\n\ts_mov_b64 exec, %0"
+                     : "=&s"(saved) : "s"(n), "v"(col), "v"(ptr), "v"(d) : "vcc", "memory");
+    else
+        asm volatile("s_mov_b64 %0, exec\n\tv_cmp_gt_i32_e32 vcc, %1, %2\n\ts_and_b64 exec, exec, vcc\n\tglobal_store_dwordx4 %3, %4, off\n\ts_mov_b64 exec, %0"
+                     : "=&s"(saved) : "s"(n), "v"(col), "v"(ptr), "v"(d) : "vcc", "memory");
+}
 template <int EPI, int RED, typename Hook = NoHook>
 __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const GemmArgs& args, PlaneRef pl, int i0, int j0, int lane, Hook hook = {}) {
     const int c16 = lane & 15;
     const int q = lane >> 4;
     const int t = args.t_begin + pl.tt;
     const int p = args.moduli[t];
-    const int pinv = args.pinv32[t];
     const float invp = 1.0f / (float)p;
     [[maybe_unused]] const unsigned dotw = args.dotw[t], dotc = args.dotc[t];
-    auto red = [&](int x) {
-        if constexpr (RED == RED_256) return x;  // the accumulator bias 2^31 (GemmArgs.acc0) does not touch the low byte
-        else if constexpr (RED == RED_ODD) {
-            // the accumulators start at -2^31 (acc init in the kernel): read as unsigned the register holds u = x + 2^31 for ANY int32 sum
-            // x, and s = sum_j byte_j(u) (256^j mod p) + ((-2^31) mod p) == x (mod p), 0 <= s < 2^18: v_dot4_u32_u8.  One fp32 quotient
-            // and the 24-bit multiply-add give the canonical residue (mod_small_sym_u, oz2_device.hpp).
-            return mod_small_sym_u(__builtin_amdgcn_udot4((unsigned)x, dotw, dotc, false), p, invp);
-        } else if constexpr (RED == RED_ODD_SMALL) {
-            // short K (kp * nseg <= 512: |x| <= 512 * 127^2 < 2^23; the accumulators start at 0, GemmArgs.acc0): the quotient comes
-            // straight from the accumulator -- v_cvt_f32_i32, one fma against 1.5 * 2^23 (its low 24 bits are 2^22 + q for either sign
-            // of q), v_mad_i32_i24: the canonical residue minus p 2^22, i.e. the canonical LOW BYTE, which is all the epilogue stores.
-            // Three instructions instead of four.  The bound is 2^23, not the 2^24 of fp32 exactness: |x| |RN(1/p) - 1/p| must stay
-            // below the 1/(2p) that separates x / p from a rounding tie (exhaustive CPU model: first wrong byte at |x| = 8 454 907 for
-            // p = 255, tests/test_residue_math.py; tests/test_gpu_parity.py::test_epilogue_reduction_on_extreme_accumulators).
-            const float qf = fmaf((float)x, invp, 12582912.0f);
-            int r;
-            asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(__float_as_int(qf)), "s"(-p), "v"(x));
-            return r;
-        } else return mod_i32_sym((int)((unsigned)x ^ (args.acc0 ? 0x80000000u : 0u)), p, pinv);
+    static_assert(RED == RED_ODD || RED == RED_ODD_SMALL, "one of the two reduction forms");
+    // RED_ODD_SMALL, short K (kp * nseg <= 512: |x| <= 512 * 127^2 < 2^23; the accumulators start at 0, GemmArgs.acc0): the quotient comes
+    // straight from the accumulator -- v_cvt_f32_i32, one fma against 1.5 * 2^23 (its low 24 bits are 2^22 + q for either sign
+    // of q), v_mad_i32_i24: the canonical residue minus p 2^22, i.e. the canonical LOW BYTE, which is all the epilogue stores.
+    // Three instructions.  The bound is 2^23, not the 2^24 of fp32 exactness: |x| |RN(1/p) - 1/p| must stay
+    // below the 1/(2p) that separates x / p from a rounding tie (exhaustive CPU model: first wrong byte at |x| = 8 454 907 for
+    // p = 255, tests/test_residue_math.py; tests/test_gpu_parity.py::test_epilogue_reduction_on_extreme_accumulators).
+    [[maybe_unused]] auto red = [&](int x) {
+        const float qf = fmaf((float)x, invp, 12582912.0f);
+        int r;
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(__float_as_int(qf)), "s"(-p), "v"(x));
+        return r;
     };
-    auto red_small = [&](int x) {
-        if constexpr (RED == RED_256) return x;
-        else if constexpr (RED == RED_ODD || RED == RED_ODD_SMALL) return mod_small_sym_odd(x, p, invp);
-        else return mod_i32_sym(x, p, pinv);
+    // RED_ODD.  The accumulators start at -2^31 (GemmArgs.acc0): read as unsigned the register holds u = x + 2^31 for ANY int32 sum x, and
+    // s = sum_j byte_j(u) (256^j mod p) + ((-2^31) mod p) == x (mod p), 0 <= s < 2^18: v_dot4_u32_u8; one fp32 quotient RN(s RN(1/p)) and the 24-bit
+    // multiply-add s - q p give the canonical residue (mod_small_sym_u, oz2_device.hpp: CPU model over the whole int32 range in
+    // tests/test_residue_math.py).  Since round 4 on two accumulators at a time, three instructions per accumulator instead of four: the dot product's constant carries
+    // the bit pattern of 2^23 (dotc | 0x4B000000; s < 2^18), so its result READ AS A FLOAT is 2^23 + s: no v_cvt_f32_u32.  s as a float and the
+    // quotient q = RN(s RN(1/p)) + 2^23 (the very fma of mod_small_sym_u: same operands, same rounding) are packed-FP32 instructions on the pair
+    // (v_pk_add_f32, v_pk_fma_f32: two lanes' worth per issue); v_mad_i32_i24 finishes on the low 24 bits of q's pattern (= q) with the dot product's
+    // pattern as addend -- the 0x4B000000 above bit 23 does not reach the low byte, which is all the epilogue keeps.
+    [[maybe_unused]] const unsigned dotc_f = dotc + 0x4B000000u;
+    [[maybe_unused]] auto red_odd_pair = [&](int x0, int x1, int& r0, int& r1) {
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const unsigned u0 = __builtin_amdgcn_udot4((unsigned)x0, dotw, dotc_f, false), u1 = __builtin_amdgcn_udot4((unsigned)x1, dotw, dotc_f, false);
+        const v2f sm = {__uint_as_float(u0), __uint_as_float(u1)};
+        const v2f sf = sm - v2f{8388608.0f, 8388608.0f};
+        const v2f qm = __builtin_elementwise_fma(sf, v2f{invp, invp}, v2f{8388608.0f, 8388608.0f});
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r0) : "v"(__float_as_int(qm[0])), "s"(-p), "v"(u0));
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r1) : "v"(__float_as_int(qm[1])), "s"(-p), "v"(u1));
     };
+    [[maybe_unused]] auto red_small = [&](int x) { return mod_small_sym_odd(x, p, invp); };  // |x| < 2^16 (complex combine); p = 256: the low byte survives
     // After the 4 x 4 dword transpose below lane (q, c16) owns the 16 consecutive rows i0 + 64 tg + 16 q .. + 15 of column
     // j0 + 16 tj + c16: one 64-bit element offset per lane for the whole block, the (tg, tj) sub-blocks add 64 tg and 16 tj * ldo --
     // no per-store multiplies (v_mul_lo_u32 / v_mad_u64_u32 are quarter rate)
     const size_t e00 = (size_t)(j0 + c16) * args.ldo + i0 + q * 16;
     const size_t po = pl.boff + (size_t)pl.tt * args.strideO, pr = pl.boff + (size_t)pl.tt * args.strideR;  // wave-uniform: scalar multiplies
     const size_t ejs = (size_t)16 * args.ldo;
+    // residues of the 64 x 16 sub-block (tj, tg) of the wave tile: z[0..3] = this lane's 16 consecutive rows (first row i0 + 64 tg + 16 q) of column j0 + 16 tj + c16
+    auto reduce_block = [&](int tj, int tg, unsigned (&z)[4]) {
+        unsigned d[4];
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj) {
-        const int col = j0 + tj * 16 + c16;
-#pragma unroll
-        for (int tg = 0; tg < 2; ++tg) {
-            unsigned d[4];
-#pragma unroll
-            for (int ti = 0; ti < 4; ++ti) {
-                int r[4];
+        for (int ti = 0; ti < 4; ++ti) {
+            int r[4];
+            if constexpr (RED == RED_ODD) {
+                red_odd_pair(acc[tg * 4 + ti][tj][0], acc[tg * 4 + ti][tj][1], r[0], r[1]);
+                red_odd_pair(acc[tg * 4 + ti][tj][2], acc[tg * 4 + ti][tj][3], r[2], r[3]);
+            } else {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) r[b] = red(acc[tg * 4 + ti][tj][b]);
-                // low bytes of four residues -> one dword with two v_perm_b32 and an OR (selector bytes: 0-3 = second operand,
-                // 4-7 = first operand, 0x0c = zero)
-                d[ti] = __builtin_amdgcn_perm((unsigned)r[1], (unsigned)r[0], 0x0c0c0400u) |
-                        __builtin_amdgcn_perm((unsigned)r[3], (unsigned)r[2], 0x04000c0cu);
             }
-            // lane quad q holds rows 4 q .. 4 q + 3 of the four 16-row tiles ti.  4 x 4 transpose over the quads (lane bits 5, 4) so
-            // that quad q holds all 16 rows of tile ti = q: bit 5 with v_permlane32_swap, bit 4 with v_permlane16_swap.
-            const auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);  // [0]: tile 2 qh, rows of quad (0, ql); [1]: of quad (1, ql)
-            const auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);  // the same for tile 2 qh + 1
-            const auto w01 = __builtin_amdgcn_permlane16_swap(s0[0], s1[0], false, false);  // tile q: rows 0-3, rows 4-7
-            const auto w23 = __builtin_amdgcn_permlane16_swap(s0[1], s1[1], false, false);  //         rows 8-11, rows 12-15
-            const unsigned z[4] = {w01[0], w01[1], w23[0], w23[1]};
-            hook(2 * tj + tg, 0);
-            if (col < args.n) {
+            // low bytes of four residues -> one dword with two v_perm_b32 and an OR (selector bytes: 0-3 = second operand,
+            // 4-7 = first operand, 0x0c = zero)
+            d[ti] = __builtin_amdgcn_perm((unsigned)r[1], (unsigned)r[0], 0x0c0c0400u) |
+                    __builtin_amdgcn_perm((unsigned)r[3], (unsigned)r[2], 0x04000c0cu);
+        }
+        // lane quad q holds rows 4 q .. 4 q + 3 of the four 16-row tiles ti.  4 x 4 transpose over the quads (lane bits 5, 4) so
+        // that quad q holds all 16 rows of tile ti = q: bit 5 with v_permlane32_swap, bit 4 with v_permlane16_swap.
+        const auto s0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);  // [0]: tile 2 qh, rows of quad (0, ql); [1]: of quad (1, ql)
+        const auto s1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);  // the same for tile 2 qh + 1
+        const auto w01 = __builtin_amdgcn_permlane16_swap(s0[0], s1[0], false, false);  // tile q: rows 0-3, rows 4-7
+        const auto w23 = __builtin_amdgcn_permlane16_swap(s0[1], s1[1], false, false);  //         rows 8-11, rows 12-15
+        z[0] = w01[0], z[1] = w01[1], z[2] = w23[0], z[3] = w23[1];
+    };
+    if constexpr (EPI == EPI_MOD) {
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+            const int col = j0 + tj * 16 + c16;
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg) {
+                unsigned z[4];
+                reduce_block(tj, tg, z);
+                hook(2 * tj + tg, 0);
                 const size_t e = e00 + tj * ejs + tg * 64;  // first of 16 consecutive rows
-                if constexpr (EPI == EPI_MOD) {
-                    if (pl.tt < args.nt_planes) {  // wave-uniform
-                        typedef unsigned v4u __attribute__((ext_vector_type(4)));
-                        __builtin_nontemporal_store(v4u{z[0], z[1], z[2], z[3]}, (v4u*)(args.out + po + e));
-                    } else {
-                        *(uint4*)(args.out + po + e) = make_uint4(z[0], z[1], z[2], z[3]);
-                    }
-                } else {
-                    // eight rows at a time: 8 bytes of X and Y in, 16 bytes of (Cr, Ci) pairs out -- with all 16 rows in flight the epilogue
-                    // needed 16 more registers than the 168-VGPR budget leaves beside the accumulators (51-62 spilled registers)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const uint2 x2 = *(const uint2*)(args.rx + pr + e + 8 * h);
-                        const uint2 y2 = *(const uint2*)(args.ry + pr + e + 8 * h);
-                        const unsigned xs[2] = {x2.x, x2.y}, ys[2] = {y2.x, y2.y};
-                        unsigned o[4];
-#pragma unroll
-                        for (int w2 = 0; w2 < 2; ++w2) {
-                            unsigned lo = 0, hi = 0;
-#pragma unroll
-                            for (int b = 0; b < 4; ++b) {
-                                const int X = (int)(int8_t)(xs[w2] >> (8 * b)), Y = (int)(int8_t)(ys[w2] >> (8 * b)), Z = (int)(int8_t)(z[2 * h + w2] >> (8 * b));
-                                const int cr = red_small(X - Y), ci = red_small(Z - X - Y);
-                                const unsigned pair = ((unsigned)cr & 0xFFu) | (((unsigned)ci & 0xFFu) << 8);
-                                if (b < 2) lo |= pair << (16 * b);
-                                else hi |= pair << (16 * (b - 2));
-                            }
-                            o[2 * w2] = lo;
-                            o[2 * w2 + 1] = hi;
-                        }
-                        if (pl.tt < args.nt_planes) {  // wave-uniform
-                            typedef unsigned v4u __attribute__((ext_vector_type(4)));
-                            __builtin_nontemporal_store(v4u{o[0], o[1], o[2], o[3]}, (v4u*)(args.out + po + 2 * e) + h);
-                        } else {
-                            *((uint4*)(args.out + po + 2 * e) + h) = make_uint4(o[0], o[1], o[2], o[3]);
-                        }
-                    }
-                }
+                if (pl.tt < args.nt_planes) store16_cols<true>(args.out + po + e, v4u{z[0], z[1], z[2], z[3]}, col, args.n);  // wave-uniform
+                else store16_cols<false>(args.out + po + e, v4u{z[0], z[1], z[2], z[3]}, col, args.n);
+                hook(2 * tj + tg, 1);
             }
-            hook(2 * tj + tg, 1);
+        }
+    } else {
+        // Complex combine in TWO passes (round 4).  Vector-memory operations of a wave complete in issue order (one vmcnt for loads and stores on
+        // gfx9), and a reload of a spilled register is a vector-memory load too: the sub-block-by-sub-block form of rounds 1-3 (load X / Y, combine,
+        // store; its store addresses reloaded from scratch) waited for a full memory round trip per 8 rows -- sixteen serialised latencies per tile,
+        // the 40 % by which the combine launch ran longer than a plain residue launch (profiles/r04_pmc_cplx_combine.txt: waves parked at s_waitcnt).
+        // Pass 1 reduces the accumulators sub-block by sub-block to packed residues and issues the two 16-byte X / Y loads of a sub-block as soon as
+        // its accumulators are dead (the loads land in those registers): sixteen loads in flight behind the residue arithmetic, none behind a store.
+        // One wait, then pass 2 combines and stores (the stores are invisible to the compiler's vmcnt bookkeeping -- store16_cols -- so it must not be
+        // left to wait for the loads one by one: each of those waits would also drain the stores issued before it).
+        unsigned z[8][4];
+        v4u X[8], Y[8];
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+            // columns beyond n read the last existing column instead (their results are never stored): no branch
+            const int colc = min(j0 + tj * 16 + c16, args.n - 1);
+            const size_t ec = (size_t)colc * args.ldo + i0 + q * 16;
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg) {
+                const int sb = 2 * tj + tg;
+                reduce_block(tj, tg, z[sb]);
+                X[sb] = *(const v4u*)(args.rx + pr + ec + tg * 64);
+                Y[sb] = *(const v4u*)(args.ry + pr + ec + tg * 64);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+        // (the store offsets are recomputed from an opaque copy of e00: kept live from pass 1 they are sixteen more registers at its peak)
+        size_t e00s = e00;
+        asm volatile("" : "+v"(e00s));
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+            const int col = j0 + tj * 16 + c16;
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg) {
+                const int sb = 2 * tj + tg;
+                unsigned o[8];
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) {  // four rows per dword of X, Y, Z -> two dwords of (Cr, Ci) byte pairs
+                    unsigned lo = 0, hi = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int xv = (int)(int8_t)(X[sb][w4] >> (8 * b)), yv = (int)(int8_t)(Y[sb][w4] >> (8 * b)), zv = (int)(int8_t)(z[sb][w4] >> (8 * b));
+                        const int cr = red_small(xv - yv), ci = red_small(zv - xv - yv);
+                        const unsigned pair = ((unsigned)cr & 0xFFu) | (((unsigned)ci & 0xFFu) << 8);
+                        if (b < 2) lo |= pair << (16 * b);
+                        else hi |= pair << (16 * (b - 2));
+                    }
+                    o[2 * w4] = lo;
+                    o[2 * w4 + 1] = hi;
+                }
+                hook(sb, 0);
+                const size_t e = e00s + tj * ejs + tg * 64;
+                v4u* const dst = (v4u*)(args.out + po + 2 * e);
+                if (pl.tt < args.nt_planes) {  // wave-uniform
+                    store16_cols<true>(dst, v4u{o[0], o[1], o[2], o[3]}, col, args.n);
+                    store16_cols<true>(dst + 1, v4u{o[4], o[5], o[6], o[7]}, col, args.n);
+                } else {
+                    store16_cols<false>(dst, v4u{o[0], o[1], o[2], o[3]}, col, args.n);
+                    store16_cols<false>(dst + 1, v4u{o[4], o[5], o[6], o[7]}, col, args.n);
+                }
+                hook(sb, 1);
+            }
         }
     }
 }
 
-template <int EPI, typename Hook = NoHook>
+template <int EPI, typename Hook = NoHook, int SMALLK = -1>
 __device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmArgs& args, PlaneRef pl, int i0, int j0, int lane, Hook hook = {}) {
     const int c16 = lane & 15;
     const int q = lane >> 4;
 
     if constexpr (EPI == EPI_MOD || EPI == EPI_CPLX) {
-        const int p = args.moduli[args.t_begin + pl.tt];
-        if (p == 256) i8_epilogue_mod<EPI, RED_256, Hook>(acc, args, pl, i0, j0, lane, hook);
-        else if ((p & 1) && args.acc0 == 0) i8_epilogue_mod<EPI, RED_ODD_SMALL, Hook>(acc, args, pl, i0, j0, lane, hook);
-        else if (p & 1) i8_epilogue_mod<EPI, RED_ODD, Hook>(acc, args, pl, i0, j0, lane, hook);
-        else i8_epilogue_mod<EPI, RED_GENERIC, Hook>(acc, args, pl, i0, j0, lane, hook);
+        // ONE reduction form per kernel instantiation (SMALLK: the launch's accumulators start at 0, K <= 512).  p = 256 takes the odd-modulus forms too:
+        // the only thing the epilogue keeps of a residue is its low byte, and for p = 256 every quotient leaves the low byte of the accumulator
+        // in place (dotw = 1, dotc = 0).  Until round 4 the epilogue was a run-time chain of four forms (256 / small / odd / generic); the
+        // structurizer lays such a chain out as a straight line of predicated blocks, which keeps the accumulators live through the whole
+        // epilogue of every form but the last -- no accumulator register could be reused inside an epilogue.
+        // SMALLK < 0: the form is chosen at run time from GemmArgs.acc0 (laboratory kernels).
+        if constexpr (SMALLK > 0) i8_epilogue_mod<EPI, RED_ODD_SMALL, Hook>(acc, args, pl, i0, j0, lane, hook);
+        else if constexpr (SMALLK == 0) i8_epilogue_mod<EPI, RED_ODD, Hook>(acc, args, pl, i0, j0, lane, hook);
+        else if (args.acc0 == 0) i8_epilogue_mod<EPI, RED_ODD_SMALL, Hook>(acc, args, pl, i0, j0, lane, hook);
+        else i8_epilogue_mod<EPI, RED_ODD, Hook>(acc, args, pl, i0, j0, lane, hook);
     } else {
         int* const rowmax_ = (int*)((char*)args.rowmax + pl.boff);
         int* const colmax_ = (int*)((char*)args.colmax + pl.boff);

@@ -76,6 +76,43 @@ def test_biased_accumulator_byte_dot_reduction_is_exact(p):
     assert np.array_equal(r, sym_exact(x, p))
 
 
+@pytest.mark.parametrize("p", INT8_MODULI)
+def test_round4_pair_form_and_p256_low_byte(p):
+    """Round 4 (oz2_gemm_i8_epi.hpp red_odd_pair): the dot product's constant carries the bit pattern of 2^23 (dotc + 0x4B000000), so the
+    register READ AS A FLOAT is 2^23 + s; s = that - 2^23 (exact), q from fma(s, RN(1/p), 2^23), v_mad_i32_i24(q bits, -p, dot-product bits):
+    the LOW BYTE is the canonical residue's.  p = 256 runs through the same form since round 4 (one reduction form per kernel): its dot
+    product is the accumulator's low byte (weights 1, 0, 0, 0; constant 0) and every quotient leaves the low byte in place."""
+    rng = np.random.default_rng(2000 + p)
+    lim = 2 ** 31 - 1
+    x = np.concatenate([rng.integers(-lim - 1, lim + 1, size=1_000_000, dtype=np.int64), np.arange(-lim - 1, -lim + 70_000, dtype=np.int64),
+                        np.arange(lim - 70_000, lim + 1, dtype=np.int64), np.arange(-70_000, 70_000, dtype=np.int64)])
+    u = (x + 2 ** 31).astype(np.uint64)
+    w = [pow(256, j, p) for j in range(4)]                    # fill_common: 1 | (256 % p) << 8 | ...
+    c = (p - (2 ** 31) % p) % p
+    s = sum(((u >> np.uint64(8 * j)) & np.uint64(0xFF)).astype(np.int64) * w[j] for j in range(4)) + c
+    assert 0 <= s.min() and s.max() < 2 ** 18
+    reg = (s + 0x4B000000).astype(np.uint32)                  # v_dot4_u32_u8 with the constant dotc + 0x4B000000: no carry into the exponent
+    sm = reg.view(np.float32)
+    assert np.array_equal(sm.astype(np.float64), 8388608.0 + s)
+    sf = (sm.astype(np.float64) - 8388608.0).astype(np.float32)   # v_pk_add_f32: exact
+    assert np.array_equal(sf.astype(np.int64), s)
+    invp = np.float32(1.0) / np.float32(p)
+    qm = (sf.astype(np.float64) * np.float64(invp) + np.float64(8388608.0)).astype(np.float32)   # v_pk_fma_f32: one rounding at unit spacing
+    q24 = qm.view(np.uint32).astype(np.int64) & 0xFFFFFF      # v_mad_i32_i24 reads the low 24 bits of the pattern
+    r = q24 * (-p) + reg.astype(np.int64)                     # ... and adds the dot product's PATTERN (2^23's exponent bits included)
+    want = sym_exact(x, p) if p & 1 else x                    # p = 256: the residue's byte is the accumulator's low byte
+    assert np.array_equal(r & 0xFF, want & 0xFF)
+
+
+def test_short_k_form_p256_low_byte():
+    """RED_ODD_SMALL with p = 256 (round 4: no separate form): x - (2^22 + q) 256 keeps the low byte of x for ANY q."""
+    x = np.arange(-(1 << 23), (1 << 23) + 1, dtype=np.int64)
+    invp = np.float32(1.0) / np.float32(256)
+    qf = (x.astype(np.float32).astype(np.float64) * np.float64(invp) + np.float64(12582912.0)).astype(np.float32)
+    low24 = qf.view(np.uint32).astype(np.int64) & 0xFFFFFF
+    assert np.array_equal((x - low24 * 256) & 0xFF, x & 0xFF)
+
+
 @pytest.mark.parametrize("p", [m for m in INT8_MODULI if m & 1])
 def test_mod_small_sym_u_exhaustive(p):
     """oz2_device.hpp mod_small_sym_u over its whole documented domain 0 <= s < 2^22 (the epilogue's byte-dot sums stay below 2^18)."""
@@ -346,3 +383,51 @@ def test_level2_quotient_exhaustive(moduli):
         else:
             assert np.all(np.abs(r) <= p // 2), p
 
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# FP8 GEMM epilogue (oz2_gemm_f8.hip f8_epilogue_mod, round 4): ONE reduction form for every modulus, q = ceil(x / p - 1/2),
+# r = x - q p in (-p/2, p/2]: the symmetric residue for odd p (x / p - 1/2 is never an integer there), the reference's representative
+# +512 of the tie for p = 1024 (conv_hi2mid / mod.hpp keep (-512, 512]).
+def _sym_half_open(x, p):
+    r = np.mod(x, p)
+    return np.where(r > p // 2, r - p, r)          # (-p/2, p/2]: odd p -> [-(p-1)/2, (p-1)/2]; p = 1024 -> [-511, 512]
+
+
+@pytest.mark.parametrize("p", FP8_MODULI)
+def test_fp8_epilogue_small_reduction_exhaustive(p):
+    """red_small: q = ceilf(fmaf(float(v), RN32(1/p), -0.5f)), r = v - q p; exhaustive over |v| < 2^18 (the combined value k0 R0 + k1 R1 +
+    k2 R2 and the complex differences stay below that)."""
+    v = np.arange(-(1 << 18), (1 << 18) + 1, dtype=np.int64)
+    invp = np.float32(1.0) / np.float32(p)
+    y = (v.astype(np.float64) * np.float64(invp) - 0.5).astype(np.float32)      # the product is exact in float64 (19 x 24 bits), the sum too: ONE rounding, as in the fma
+    q = np.ceil(y.astype(np.float64)).astype(np.int64)
+    r = v - q * p
+    assert np.array_equal(r, _sym_half_open(v, p))
+    if p & 1:
+        assert np.array_equal(r, sym_exact(v, p))
+
+
+@pytest.mark.parametrize("p", FP8_MODULI)
+def test_fp8_epilogue_accumulator_reduction(p):
+    """red_acc: q = ceil(fma(double(c), RN64(1/p), -0.5)), r = c - q p for the exact integer accumulators |c| <= 2^24 (k <= 65536 with |a|, |b| <= 16):
+    every residue class next to many quotients including the half-way points, the range ends, and random values; the fma is modelled exactly
+    with rationals (its rounding to double, 2^-38 absolute here, cannot reach an integer: the distance is >= 1/(2p) for odd p, and for p = 1024
+    the arithmetic is exact)."""
+    from fractions import Fraction
+    import math
+    rng = np.random.default_rng(3000 + p)
+    lim = 1 << 24
+    qs = np.concatenate([rng.integers(-(lim // p), lim // p, size=300), [-(lim // p), lim // p - 1, 0, 1, -1]])
+    rs = np.arange(-(p // 2) - 1, p // 2 + 2)
+    xs = np.concatenate([np.clip((qs[:, None] * p + rs[None, :]).ravel(), -lim, lim), rng.integers(-lim, lim + 1, size=20000),
+                         np.arange(-lim, -lim + 2000), np.arange(lim - 2000, lim + 1)])
+    xs = np.unique(xs)[:: max(1, len(np.unique(xs)) // 60000)]
+    invpd = Fraction(float(1.0 / p))
+    got = np.empty(len(xs), dtype=np.int64)
+    for i, x in enumerate(xs.tolist()):
+        y = float(Fraction(x) * invpd - Fraction(1, 2))                       # fma: one rounding
+        got[i] = x - math.ceil(y) * p
+        exact = Fraction(x, p) - Fraction(1, 2)
+        assert math.ceil(y) == math.ceil(exact), (x, p)
+    assert np.array_equal(got, _sym_half_open(xs, p))
