@@ -108,10 +108,19 @@ constexpr int F8_THREADS = 512;
 #define OZ2_HOOK_KSTEP(kin) (kin)
 #endif
 
-// int16 residue epilogues (EPI_PART / EPI_FINAL) of a wave's 128 x 64 accumulator block.  ODD: odd modulus -- the accumulators are
-// exact integers (|c| <= 2^24): one exact FP64 quotient step (five full-rate instructions); the combined value (|v| < 2^18)
-// needs one fp32 step.  p = 1024 (the only even FP8 modulus; the tie +-512 keeps the reference's representative +512): ((a + 511) & 1023) - 511.
-template <int EPI, bool ODD>
+// int16 residue epilogues (EPI_PART / EPI_FINAL / EPI_FINAL_CPLX) of a wave's 128 x 64 accumulator block.  The accumulators are exact integers
+// (|c| <= 2^24): one exact FP64 quotient step (five full-rate instructions); the combined value (|v| < 2^18) needs one fp32 step.
+// ONE reduction form for every modulus (round 4): q = ceil(x / p - 1/2), r = x - q p, the representative in (-p/2, p/2].  For odd p that is the
+// symmetric residue (x / p - 1/2 is never an integer; its distance from one is >= 1/(2p) = 4.6e-4, the evaluation errors are 1e-12 in FP64 and
+// 4.5e-5 in fp32 for |v| < 2^18: CPU models in tests/test_residue_math.py), for p = 1024 -- the only even FP8 modulus, where the arithmetic is
+// exact -- it keeps the reference's representative +512 of the tie.  Rounds 1-3 chose between an odd and an even form per tile at run time; the
+// structurizer lays such a choice out as a straight line of predicated blocks, which keeps the accumulators live through the first form's
+// whole epilogue (oz2_gemm_i8_epi.hpp, i8_epilogue).
+// EPI_FINAL / EPI_FINAL_CPLX load the partial residues of earlier launches.  Vector-memory operations of a wave complete in issue order, so the
+// loads are issued per sub-block right behind its reduction -- all of them in flight behind the residue arithmetic, none behind a store -- and
+// waited for ONCE; then the combination and the stores.  (Sub-block by sub-block -- load, wait, combine, store -- every sub-block paid a full
+// memory round trip: eight to sixteen serialised latencies per tile.)
+template <int EPI>
 __device__ __forceinline__ void f8_epilogue_mod(const v4f (&acc)[8][4], const F8Args& args, F8Plane pl, int i0, int j0, int lane) {
     const int c16 = lane & 15;
     const int q = lane >> 4;
@@ -131,93 +140,144 @@ __device__ __forceinline__ void f8_epilogue_mod(const v4f (&acc)[8][4], const F8
     const float pf = (float)p, invp = 1.0f / pf;
     const double pd = (double)p, invpd = 1.0 / pd;
     auto red_acc = [&](float c) -> int {
-        if constexpr (ODD) {
-            const double x = (double)c;  // one exact FP64 quotient step (oz2_device.hpp, mod_i32_sym_odd_f64)
-            return (int)fma(-rint(x * invpd), pd, x);
-        } else {
-            return ((__float2int_rn(c) + 511) & 1023) - 511;  // p = 1024, representative in (-512, 512]
-        }
+        const double x = (double)c;
+        return (int)fma(-ceil(fma(x, invpd, -0.5)), pd, x);
     };
     auto red_small = [&](int v) -> int {
-        if constexpr (ODD) {
-            const float vf = (float)v;
-            return (int)fmaf(-rintf(vf * invp), pf, vf);
-        } else {
-            return ((v + 511) & 1023) - 511;
+        const float vf = (float)v;
+        return (int)fmaf(-ceilf(fmaf(vf, invp, -0.5f)), pf, vf);
+    };
+    // int16 residues of the 64 x 16 sub-block (tj, tg): z[0..7] = this lane's 16 consecutive rows (first row i0 + 64 tg + 16 q) of column j0 + 16 tj + c16
+    auto reduce_block = [&](int tj, int tg, unsigned (&z)[8]) {
+        unsigned d[4][2];  // tile ti of the group: this lane quad's rows 4 q .. 4 q + 3 as 4 x int16
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+            int r[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) r[b] = red_acc(acc[tg * 4 + ti][tj][b]);
+            d[ti][0] = pack16(r[0], r[1]);
+            d[ti][1] = pack16(r[2], r[3]);
+        }
+        // 4 x 4 transpose over the lane quads (bits 5, 4) as in oz2_gemm_i8.hip: afterwards quad q holds the 16 consecutive rows
+        // 64 tg + 16 q .. + 15 (tile ti = q): rows 4 s .. 4 s + 3 from source quad s in z[2 s], z[2 s + 1]
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const auto s0 = __builtin_amdgcn_permlane32_swap(d[0][w], d[2][w], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(d[1][w], d[3][w], false, false);
+            const auto w01 = __builtin_amdgcn_permlane16_swap(s0[0], s1[0], false, false);
+            const auto w23 = __builtin_amdgcn_permlane16_swap(s0[1], s1[1], false, false);
+            z[0 + w] = w01[0];  // rows 0-3
+            z[2 + w] = w01[1];  // rows 4-7
+            z[4 + w] = w23[0];  // rows 8-11
+            z[6 + w] = w23[1];  // rows 12-15
         }
     };
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const size_t po = (size_t)plane * args.strideO, pr = (size_t)plane * args.strideR;
+    if constexpr (EPI == EPI_PART || EPI == EPI_FINAL_CPLX) {
+        // EPI_FINAL_CPLX keeps the sub-block-by-sub-block form: five plane pointers and 64 more registers of X / Y residues beside the kernel's DMA
+        // state do not fit the two-pass form below (it was built: 290-750 bytes of scratch, reloads between the stores)
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj) {
-        const int col = j0 + tj * 16 + c16;
+        for (int tj = 0; tj < 4; ++tj) {
+            const int col = j0 + tj * 16 + c16;
 #pragma unroll
-        for (int tg = 0; tg < 2; ++tg) {
-            unsigned d[4][2];  // tile ti of the group: this lane quad's rows 4 q .. 4 q + 3 as 4 x int16
-#pragma unroll
-            for (int ti = 0; ti < 4; ++ti) {
-                int r[4];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) r[b] = red_acc(acc[tg * 4 + ti][tj][b]);
-                d[ti][0] = pack16(r[0], r[1]);
-                d[ti][1] = pack16(r[2], r[3]);
-            }
-            // 4 x 4 transpose over the lane quads (bits 5, 4) as in oz2_gemm_i8.hip: afterwards quad q holds the 16 consecutive rows
-            // 64 tg + 16 q .. + 15 (tile ti = q): rows 4 s .. 4 s + 3 from source quad s in z[2 s], z[2 s + 1]
-            unsigned z[8];
-#pragma unroll
-            for (int w = 0; w < 2; ++w) {
-                const auto s0 = __builtin_amdgcn_permlane32_swap(d[0][w], d[2][w], false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(d[1][w], d[3][w], false, false);
-                const auto w01 = __builtin_amdgcn_permlane16_swap(s0[0], s1[0], false, false);
-                const auto w23 = __builtin_amdgcn_permlane16_swap(s0[1], s1[1], false, false);
-                z[0 + w] = w01[0];  // rows 0-3
-                z[2 + w] = w01[1];  // rows 4-7
-                z[4 + w] = w23[0];  // rows 8-11
-                z[6 + w] = w23[1];  // rows 12-15
-            }
-            if (col < args.n) {
-                const size_t e = (size_t)col * args.ldo + i0 + tg * 64 + q * 16;
-                int16_t* dst = out_ + (size_t)plane * args.strideO + e;
-                if constexpr (EPI == EPI_FINAL || EPI == EPI_FINAL_CPLX) {
-                    const uint4* p0 = (const uint4*)(r0_ + (size_t)plane * args.strideR + e);
-                    const uint4* p1 = (const uint4*)(r1_ + (size_t)plane * args.strideR + e);
-                    const uint4 x0 = p0[0], x1 = p0[1];
-                    uint4 y0 = make_uint4(0, 0, 0, 0), y1 = y0;
-                    if (args.nres == 2) y0 = p1[0], y1 = p1[1];  // wave-uniform; nres == 1: r0 holds the residue of C0 + C1, R1 = 0
-                    const unsigned xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                    const unsigned ys[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) {
-                        int o[2];
-#pragma unroll
-                        for (int hlf = 0; hlf < 2; ++hlf) {
-                            const int R0 = (int)(int16_t)(xs[w] >> (16 * hlf)), R1 = (int)(int16_t)(ys[w] >> (16 * hlf)),
-                                      R2 = (int)(int16_t)(z[w] >> (16 * hlf));
-                            o[hlf] = red_small(k0 * R0 + k1 * R1 + k2 * R2);
+            for (int tg = 0; tg < 2; ++tg) {
+                unsigned z[8];
+                reduce_block(tj, tg, z);
+                if (col < args.n) {
+                    const size_t e = (size_t)col * args.ldo + i0 + tg * 64 + q * 16;
+                    if constexpr (EPI == EPI_PART) {
+                        v4u* dst = (v4u*)(out_ + po + e);
+                        dst[0] = v4u{z[0], z[1], z[2], z[3]};
+                        dst[1] = v4u{z[4], z[5], z[6], z[7]};
+                    } else {
+                        const v4u* p0 = (const v4u*)(r0_ + pr + e);
+                        const v4u x0 = p0[0], x1 = p0[1];
+                        v4u y0 = v4u{0, 0, 0, 0}, y1 = y0;
+                        if (args.nres == 2) {  // wave-uniform; nres == 1: r0 holds the residue of C0 + C1, R1 = 0
+                            const v4u* p1 = (const v4u*)(r1_ + pr + e);
+                            y0 = p1[0], y1 = p1[1];
                         }
-                        z[w] = pack16(o[0], o[1]);
+                        const unsigned xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                        const unsigned ys[8] = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) {
+                            int o[2];
+#pragma unroll
+                            for (int hlf = 0; hlf < 2; ++hlf) {
+                                const int a0 = (int)(int16_t)(xs[w] >> (16 * hlf)), a1 = (int)(int16_t)(ys[w] >> (16 * hlf)), a2 = (int)(int16_t)(z[w] >> (16 * hlf));
+                                o[hlf] = red_small(k0 * a0 + k1 * a1 + k2 * a2);
+                            }
+                            z[w] = pack16(o[0], o[1]);
+                        }
+                        const v4u* px = (const v4u*)(rx_ + pr + e);
+                        const v4u* py = (const v4u*)(ry_ + pr + e);
+                        const v4u cx0 = px[0], cx1 = px[1], cy0 = py[0], cy1 = py[1];
+                        const unsigned cxs[8] = {cx0[0], cx0[1], cx0[2], cx0[3], cx1[0], cx1[1], cx1[2], cx1[3]};
+                        const unsigned cys[8] = {cy0[0], cy0[1], cy0[2], cy0[3], cy1[0], cy1[1], cy1[2], cy1[3]};
+                        unsigned o[16];  // 16 rows x (Cr, Ci) int16 pairs
+#pragma unroll
+                        for (int w = 0; w < 8; ++w)
+#pragma unroll
+                            for (int hlf = 0; hlf < 2; ++hlf) {
+                                const int xv = (int)(int16_t)(cxs[w] >> (16 * hlf)), yv = (int)(int16_t)(cys[w] >> (16 * hlf)), zv = (int)(int16_t)(z[w] >> (16 * hlf));
+                                o[2 * w + hlf] = pack16(red_small(xv - yv), red_small(zv - xv - yv));
+                            }
+                        v4u* dc = (v4u*)(out_ + po + 2 * e);
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) dc[w] = v4u{o[4 * w], o[4 * w + 1], o[4 * w + 2], o[4 * w + 3]};
                     }
                 }
-                if constexpr (EPI == EPI_FINAL_CPLX) {
-                    const uint4* px = (const uint4*)(rx_ + (size_t)plane * args.strideR + e);
-                    const uint4* py = (const uint4*)(ry_ + (size_t)plane * args.strideR + e);
-                    const uint4 x0 = px[0], x1 = px[1], y0 = py[0], y1 = py[1];
-                    const unsigned xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                    const unsigned ys[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
-                    unsigned o[16];  // 16 rows x (Cr, Ci) int16 pairs
+            }
+        }
+    } else {
+        unsigned z[8][8];
+        v4u R0[8][2], R1[8][2];
+        // pass 1: reduce; the partial residues of a sub-block are requested as soon as its accumulators are dead.  Columns beyond n read the
+        // last existing column instead (their results are never stored): no branch around the loads.
+        auto request = [&](int tj, int tg, size_t ec) {
+            const int sb = 2 * tj + tg;
+            const v4u* p0 = (const v4u*)(r0_ + pr + ec + tg * 64);
+            R0[sb][0] = p0[0], R0[sb][1] = p0[1];
+            R1[sb][0] = R1[sb][1] = v4u{0, 0, 0, 0};
+            if (args.nres == 2) {  // wave-uniform; nres == 1: r0 holds the residue of C0 + C1, R1 = 0
+                const v4u* p1 = (const v4u*)(r1_ + pr + ec + tg * 64);
+                R1[sb][0] = p1[0], R1[sb][1] = p1[1];
+            }
+        };
 #pragma unroll
-                    for (int w = 0; w < 8; ++w)
+        for (int tj = 0; tj < 4; ++tj) {
+            const size_t ec = (size_t)min(j0 + tj * 16 + c16, args.n - 1) * args.ldo + i0 + q * 16;
 #pragma unroll
-                        for (int hlf = 0; hlf < 2; ++hlf) {
-                            const int X = (int)(int16_t)(xs[w] >> (16 * hlf)), Y = (int)(int16_t)(ys[w] >> (16 * hlf)),
-                                      Z = (int)(int16_t)(z[w] >> (16 * hlf));
-                            o[2 * w + hlf] = pack16(red_small(X - Y), red_small(Z - X - Y));
-                        }
-                    uint4* dc = (uint4*)(out_ + (size_t)plane * args.strideO + 2 * e);
+            for (int tg = 0; tg < 2; ++tg) {
+                reduce_block(tj, tg, z[2 * tj + tg]);
+                request(tj, tg, ec);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+        // pass 2: residue of k0 R0 + k1 R1 + k2 R2 in place
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) dc[w] = make_uint4(o[4 * w], o[4 * w + 1], o[4 * w + 2], o[4 * w + 3]);
-                } else {
-                    ((uint4*)dst)[0] = make_uint4(z[0], z[1], z[2], z[3]);
-                    ((uint4*)dst)[1] = make_uint4(z[4], z[5], z[6], z[7]);
+        for (int tj = 0; tj < 4; ++tj) {
+            const int col = j0 + tj * 16 + c16;
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg) {
+                const int sb = 2 * tj + tg;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    int o[2];
+#pragma unroll
+                    for (int hlf = 0; hlf < 2; ++hlf) {
+                        const int a0 = (int)(int16_t)(R0[sb][w >> 2][w & 3] >> (16 * hlf)), a1 = (int)(int16_t)(R1[sb][w >> 2][w & 3] >> (16 * hlf)),
+                                  a2 = (int)(int16_t)(z[sb][w] >> (16 * hlf));
+                        o[hlf] = red_small(k0 * a0 + k1 * a1 + k2 * a2);
+                    }
+                    z[sb][w] = pack16(o[0], o[1]);
+                }
+                if (col < args.n) {
+                    v4u* dst = (v4u*)(out_ + po + (size_t)col * args.ldo + i0 + tg * 64 + q * 16);
+                    dst[0] = v4u{z[sb][0], z[sb][1], z[sb][2], z[sb][3]};
+                    dst[1] = v4u{z[sb][4], z[sb][5], z[sb][6], z[sb][7]};
                 }
             }
         }
@@ -490,8 +550,7 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
             const int i0 = tmap.tm * BM + wm * 128, j0 = tmap.tn * BN + wn * 64;
             const F8Plane pl = f8_plane(args, tmap.plane);
             if constexpr (EPI == EPI_PART || EPI == EPI_FINAL || EPI == EPI_FINAL_CPLX) {
-                if (args.moduli[args.t_begin + pl.tt] & 1) f8_epilogue_mod<EPI, true>(acc, args, pl, i0, j0, lane);
-                else f8_epilogue_mod<EPI, false>(acc, args, pl, i0, j0, lane);
+                f8_epilogue_mod<EPI>(acc, args, pl, i0, j0, lane);
             } else {
                 f8_epilogue_bound<EPI>(acc, args, pl, i0, j0, lane);
             }
