@@ -100,10 +100,10 @@ template <bool NT> __device__ __forceinline__ void store16_cols(void* ptr, v4u d
     unsigned long long saved;
     if constexpr (NT)
         asm volatile("s_mov_b64 %0, exec\n\tv_cmp_gt_i32_e32 vcc, %1, %2\n\ts_and_b64 exec, exec, vcc\n\tglobal_store_dwordx4 %3, %4, off nt\n\ts_mov_b64 exec, %0"
-                     : "=&s"(saved) : "s"(n), "v"(col), "v"(ptr), "v"(d) : "vcc", "memory");
+                     : "=&s"(saved) : "s"(n), "v"(col), "v"(ptr), "v"(d) : "vcc", "scc", "memory");
     else
         asm volatile("s_mov_b64 %0, exec\n\tv_cmp_gt_i32_e32 vcc, %1, %2\n\ts_and_b64 exec, exec, vcc\n\tglobal_store_dwordx4 %3, %4, off\n\ts_mov_b64 exec, %0"
-                     : "=&s"(saved) : "s"(n), "v"(col), "v"(ptr), "v"(d) : "vcc", "memory");
+                     : "=&s"(saved) : "s"(n), "v"(col), "v"(ptr), "v"(d) : "vcc", "scc", "memory");
 }
 template <int EPI, int RED, typename Hook = NoHook>
 __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const GemmArgs& args, PlaneRef pl, int i0, int j0, int lane, Hook hook = {}) {
@@ -227,20 +227,27 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
 #pragma unroll
             for (int tg = 0; tg < 2; ++tg) {
                 const int sb = 2 * tj + tg;
+                // (Cr, Ci) = (X - Y, Z - X - Y) mod p on PAIRS of rows in packed FP32 (v_pk_add_f32 / v_pk_fma_f32: two values per issue): the differences are
+                // integers of magnitude <= 381, the quotient is RN(d RN(1/p)) read from an fma against 1.5 * 2^23 (no tie is reachable: p is odd, or 256
+                // where every representative has the same byte), d - q p is exact, and adding 1.5 * 2^23 once more leaves the residue's two's-complement
+                // byte in the low byte of the pattern.  Ten instructions per element where the scalar form (two fp32 quotient steps with conversions both
+                // ways and a quarter-rate v_mul_lo_u32 each) took eighteen: the combine pass is VALU-bound.
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                const v2f invp2 = {invp, invp}, mg = {12582912.0f, 12582912.0f}, np2 = {-(float)p, -(float)p};
                 unsigned o[8];
 #pragma unroll
                 for (int w4 = 0; w4 < 4; ++w4) {  // four rows per dword of X, Y, Z -> two dwords of (Cr, Ci) byte pairs
-                    unsigned lo = 0, hi = 0;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int xv = (int)(int8_t)(X[sb][w4] >> (8 * b)), yv = (int)(int8_t)(Y[sb][w4] >> (8 * b)), zv = (int)(int8_t)(z[sb][w4] >> (8 * b));
-                        const int cr = red_small(xv - yv), ci = red_small(zv - xv - yv);
-                        const unsigned pair = ((unsigned)cr & 0xFFu) | (((unsigned)ci & 0xFFu) << 8);
-                        if (b < 2) lo |= pair << (16 * b);
-                        else hi |= pair << (16 * (b - 2));
+                    for (int pr = 0; pr < 2; ++pr) {
+                        auto sx = [](unsigned v, int b) { return (float)(int)(int8_t)(v >> (8 * b)); };
+                        const v2f xf = {sx(X[sb][w4], 2 * pr), sx(X[sb][w4], 2 * pr + 1)}, yf = {sx(Y[sb][w4], 2 * pr), sx(Y[sb][w4], 2 * pr + 1)},
+                                  zf = {sx(z[sb][w4], 2 * pr), sx(z[sb][w4], 2 * pr + 1)};
+                        const v2f d1 = xf - yf, d2 = zf - (xf + yf);
+                        const v2f q1 = __builtin_elementwise_fma(d1, invp2, mg) - mg, q2 = __builtin_elementwise_fma(d2, invp2, mg) - mg;
+                        const v2f r1 = __builtin_elementwise_fma(q1, np2, d1) + mg, r2 = __builtin_elementwise_fma(q2, np2, d2) + mg;
+                        o[2 * w4 + pr] = __builtin_amdgcn_perm(__float_as_uint(r2[0]), __float_as_uint(r1[0]), 0x0c0c0400u) |
+                                         __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r1[1]), 0x04000c0cu);
                     }
-                    o[2 * w4] = lo;
-                    o[2 * w4 + 1] = hi;
                 }
                 hook(sb, 0);
                 const size_t e = e00s + tj * ejs + tg * 64;

@@ -1,0 +1,104 @@
+"""Compile-time properties of the MFMA kernels that their speed depends on and that a source change can silently lose ("the
+epilogue's scratch"): register budget, scratch size, no spill traffic in any block that holds the MFMA loop, no vector-memory wait inside the
+K loops of the consumer waves.  Compiles the two GEMM translation units with the product flags and -save-temps (about 40 s); no GPU needed."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "gemmul8_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+FLAGS = ["-std=c++20", "-O3", "-fPIC", "-Wno-invalid-offsetof", "--offload-arch=gfx950", "-ffp-contract=off", "-DOCML_BASIC_ROUNDED_OPERATIONS",
+         "-DOZ2_PRODUCT_BUILD", "-w", "-I" + CSRC]
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+
+
+def _asm(src):
+    d = tempfile.mkdtemp()
+    try:
+        subprocess.run([HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", os.path.join(d, "x.o"), "-save-temps=obj"], check=True, cwd=d)
+        name = [f for f in os.listdir(d) if f.endswith(".s") and "gfx950" in f][0]
+        return open(os.path.join(d, name)).read()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def _kernels(text):
+    """{demangled-ish name: (vgprs, scratch bytes, [basic blocks as lists of instruction lines])}"""
+    meta = {}
+    for b in text.split("  - .agpr_count:")[1:]:
+        g = lambda k: re.search(r"\." + k + r":\s+(\S+)", b).group(1)
+        meta[g("name")] = (int(g("vgpr_count")), int(g("private_segment_fixed_size")))
+    out = {}
+    lines = text.split("\n")
+    for name, (vg, sc) in meta.items():
+        start = next(i for i, l in enumerate(lines) if l.startswith(name + ":"))
+        end = next(i for i in range(start + 1, len(lines)) if lines[i].startswith(".Lfunc_end"))
+        blocks, cur = [], []
+        for l in lines[start:end]:
+            if re.match(r"^\.LBB\d+_\d+:", l):
+                blocks.append(cur)
+                cur = []
+            elif l.startswith("\t") and not l.startswith("\t.") and not l.lstrip().startswith(";"):
+                cur.append(l.strip())
+        blocks.append(cur)
+        out[name] = (vg, sc, blocks)
+    return out
+
+
+@pytest.fixture(scope="module")
+def i8():
+    return _kernels(_asm("oz2_gemm_i8.hip"))
+
+
+@pytest.fixture(scope="module")
+def f8():
+    return _kernels(_asm("oz2_gemm_f8.hip"))
+
+
+def _mfma_blocks(blocks):
+    return [b for b in blocks if sum("v_mfma" in l for l in b) >= 32]
+
+
+def test_int8_kernels_registers_and_scratch(i8):
+    ks = {n: v for n, v in i8.items() if "gemm_i8_kernel" in n}
+    assert len(ks) == 7, sorted(ks)   # MOD / CPLX x {K-step barrier small-K, K-step barrier, ping-pong} + the bound GEMM
+    for n, (vg, sc, blocks) in ks.items():
+        assert vg <= 168, (n, vg)     # 12 waves per CU = 3 per SIMD
+        residue = "ILi0E" in n or "ILi2E" in n
+        # the residue kernels keep a handful of kernel-lifetime values in scratch (entry / tile start); the epilogues spill nothing
+        assert sc <= (32 if residue else 256), (n, sc)
+        loops = _mfma_blocks(blocks)
+        assert loops, n
+        for b in loops:
+            assert not any("scratch_" in l for l in b), (n, "spill traffic in an MFMA block")
+            # consumer waves: no vector-memory wait in the K loop (the producers' waits sit in their own blocks, without MFMAs)
+            assert not any(re.match(r"s_waitcnt vmcnt", l) for l in b), (n, "vmcnt wait in an MFMA block")
+
+
+def test_int8_complex_combine_loads_are_not_serialised(i8):
+    """All sixteen X / Y loads of a tile are issued before the first of them is waited for, and no scratch reload sits between them and the stores."""
+    for n, (vg, sc, blocks) in i8.items():
+        if "gemm_i8_kernelILi2E" not in n:
+            continue
+        flat = [l for b in blocks for l in b]
+        loads = [i for i, l in enumerate(flat) if l.startswith("global_load_dwordx4")]
+        assert len(loads) % 16 == 0 and loads, (n, len(loads))   # one epilogue per consumer half
+        for g0 in range(0, len(loads), 16):
+            first, last = loads[g0], loads[g0 + 15]
+            between = flat[first:last + 1]
+            assert not any(l.startswith("s_waitcnt vmcnt") or "scratch_" in l or l.startswith("global_store") for l in between), n
+
+
+def test_fp8_kernels_registers_and_scratch(f8):
+    ks = {n: v for n, v in f8.items() if "gemm_f8_kernel" in n}
+    assert len(ks) == 7, sorted(ks)
+    for n, (vg, sc, blocks) in ks.items():
+        assert vg <= 256 and sc == 0, (n, vg, sc)   # 8 waves per CU = 2 per SIMD
+        for b in _mfma_blocks(blocks):
+            assert not any("scratch_" in l for l in b), n
