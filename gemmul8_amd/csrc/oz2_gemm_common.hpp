@@ -84,6 +84,75 @@ __device__ __forceinline__ TileMap map_tile(int bid, int nwg, int tiles_m, int t
     return t;
 }
 
+// The same map with its divisions on the SCALAR unit (round 4).  A division by a run-time value expands to a float-reciprocal sequence on the
+// vector ALU (v_cvt / v_rcp_iflag / v_mul / v_cvt, v_readfirstlane, a correction): five of them per tile, and -- the divisors being loop
+// invariant -- reciprocals hoisted out of the persistent tile loop that sat in VGPRs across every K loop, were spilled there and reloaded
+// (a vector-memory wait) at every epilogue.  The host supplies M = floor(2^32 / d) per divisor; q0 = mulhi(x, M) is q or q - 1 for any
+// x < 2^32 (x (2^32 / d - M) / 2^32 < 1), one compare-and-correct finishes: s_mul_hi_u32, s_mul_i32, s_sub, s_cmp, s_cselect.
+struct TileMapArgs {
+    int tiles_m, tiles_n, colblock;
+    unsigned tpp, m_tpp;          // tiles per plane
+    unsigned pb, m_pb;            // tiles per column block (colblock > 0)
+    unsigned m_gs_full, m_gs_tail;  // 8 * (block width): full blocks (or the whole width), the last (narrower) block
+};
+inline unsigned map_magic(unsigned d) { return d <= 1 ? 0xFFFFFFFFu : (unsigned)(0x100000000ull / d); }
+inline TileMapArgs make_tile_map(int tiles_m, int tiles_n, int colblock) {
+    TileMapArgs a{};
+    a.tiles_m = tiles_m, a.tiles_n = tiles_n;
+    a.colblock = (colblock > 0 && tiles_n > colblock) ? colblock : 0;
+    a.tpp = (unsigned)tiles_m * (unsigned)tiles_n;
+    a.m_tpp = map_magic(a.tpp);
+    const int wfull = a.colblock ? a.colblock : tiles_n, wtail = a.colblock ? tiles_n % a.colblock : 0;
+    a.pb = (unsigned)tiles_m * (unsigned)wfull;
+    a.m_pb = map_magic(a.pb);
+    a.m_gs_full = map_magic(8u * (unsigned)wfull);
+    a.m_gs_tail = map_magic(8u * (unsigned)(wtail ? wtail : wfull));
+    return a;
+}
+__device__ __forceinline__ void udivmod_magic(unsigned x, unsigned d, unsigned M, unsigned& q, unsigned& r) {
+    q = __umulhi(x, M);
+    r = x - q * d;
+    if (r >= d) ++q, r -= d;
+}
+__device__ __forceinline__ TileMap map_tile(int bid, int nwg, const TileMapArgs a) {  // by value: the laboratory kernels read it from the kernel-argument address space
+    {
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int fc = OZ2_MAP_CHUNKED ? ((nwg >> 3) >> 5) : 0;  // full chunks of 256
+        if (idx < fc * 32) {
+            bid = (idx >> 5) * 256 + xcd * 32 + (idx & 31);
+        } else {
+            const int rem = nwg - fc * 256, q = rem >> 3, r = rem & 7, i2 = idx - fc * 32;
+            bid = fc * 256 + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i2;
+        }
+    }
+    TileMap t;
+    unsigned plane, rem;
+    udivmod_magic((unsigned)bid, a.tpp, a.m_tpp, plane, rem);
+    t.plane = (int)plane;
+    int tn0 = 0, w = a.tiles_n;
+    unsigned m_gs = a.m_gs_full;
+    if (a.colblock > 0) {
+        unsigned b;
+        udivmod_magic(rem, a.pb, a.m_pb, b, rem);
+        tn0 = (int)b * a.colblock;
+        if (a.tiles_n - tn0 < a.colblock) w = a.tiles_n - tn0, m_gs = a.m_gs_tail;
+        else w = a.colblock;
+    }
+    constexpr int GM = 8;
+    unsigned g;
+    udivmod_magic(rem, (unsigned)(GM * w), m_gs, g, rem);
+    const int first_m = (int)g * GM;
+    if (a.tiles_m - first_m >= GM) {  // full row group
+        t.tm = first_m + (int)(rem & (GM - 1));
+        t.tn = tn0 + (int)(rem >> 3);
+    } else {                          // the last, shorter row group of a plane whose tile-row count is not a multiple of 8
+        const unsigned gm = (unsigned)(a.tiles_m - first_m);
+        t.tm = first_m + (int)(rem % gm);
+        t.tn = tn0 + (int)(rem / gm);
+    }
+    return t;
+}
+
 // Row maxima of ONE 16-row accumulator tile row of the 16x16 MFMA shapes for the bound-GEMM epilogues: v[r], r = 0..3, is this lane's
 // (column-masked, non-negative) maximum over the wave's column tiles for row i0 + 4 (lane >> 4) + r; the 16 lanes of a quad hold the
 // 16 columns.  Reduce-scatter over lane bits 3, 2 (4 -> 2 -> 1 values), butterfly over bits 1, 0: lane l then holds the finished

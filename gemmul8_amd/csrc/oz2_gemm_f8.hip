@@ -58,6 +58,7 @@ struct F8Args {
     int nres;                      // EPI_FINAL / EPI_FINAL_CPLX: residue planes combined with the accumulator: 2 (r0, r1), or 1 (r0 = residue of C0 + C1)
     int kp, m, n, tiles_m, tiles_n;
     int colblock;  // tile-columns per column block of the tile walk (map_colblock; 0 = full width)
+    TileMapArgs map;  // the same with the divisors' magic numbers (make_tile_map)
     int t_begin;          // block b <-> modulus t_begin + b
     int16_t* out;         // EPI_PART: scratch plane b at out + b*strideO; EPI_FINAL: C_mid plane (t_begin+b) likewise
     size_t ldo, strideO;
@@ -74,6 +75,7 @@ struct F8Args {
     int cplx_rule;        // EPI_FB3: 1 = inflate the mixed-sign product by ku (|c| + 2 s12) (default), 0 = by ku c as the reference does
     int total_tiles;      // planes * tiles_m * tiles_n
     int ppi;              // planes per batch item (plane p = item p / ppi, item-relative plane p % ppi); = all planes for one GEMM
+    unsigned m_ppi;       // floor(2^32 / ppi) (map_magic)
     size_t bstride;       // bytes between the workspaces of consecutive batch items (every pointer above lives in the workspace)
     int moduli[20];
     int sqrtp[6];
@@ -86,8 +88,9 @@ struct F8Plane {
 };
 __device__ __forceinline__ F8Plane f8_plane(const F8Args& args, int plane) {
     const int p = __builtin_amdgcn_readfirstlane(plane);
-    const int b = p / args.ppi;
-    return {(size_t)b * args.bstride, p - b * args.ppi};
+    unsigned b, tt;
+    udivmod_magic((unsigned)p, (unsigned)args.ppi, args.m_ppi, b, tt);
+    return {(size_t)b * args.bstride, (int)tt};
 }
 
 __device__ __forceinline__ unsigned pack16(int a, int b) { return ((unsigned)a & 0xFFFFu) | ((unsigned)b << 16); }
@@ -394,7 +397,7 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
     };
 #define F8_SET_TILE(vb_)                                                                                                     \
     do {                                                                                                                     \
-        const TileMap tmap_ = map_tile((vb_), total, args.tiles_m, args.tiles_n, args.colblock);                                            \
+        const TileMap tmap_ = map_tile((vb_), total, args.map);                                            \
         const F8Plane pl_ = f8_plane(args, tmap_.plane);                                                                     \
         gsrc = uniform(isB ? args.B + pl_.boff + (size_t)args.planeB[pl_.tt] * args.strideB + (size_t)tmap_.tn * BN * args.kp \
                            : args.A + pl_.boff + (size_t)args.planeA[pl_.tt] * args.strideA + (size_t)tmap_.tm * BM * args.kp); \
@@ -546,7 +549,7 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n, args.colblock);
+            const TileMap tmap = map_tile(vb, total, args.map);
             const int i0 = tmap.tm * BM + wm * 128, j0 = tmap.tn * BN + wn * 64;
             const F8Plane pl = f8_plane(args, tmap.plane);
             if constexpr (EPI == EPI_PART || EPI == EPI_FINAL || EPI == EPI_FINAL_CPLX) {
@@ -603,6 +606,7 @@ template <int EPI> static hipError_t launch(hipStream_t stream, F8Args& a, int p
     }
     // the items of a batched call fold into the plane sequence: plane p = item p / ppi (oz2_gemm_i8.hip does the same)
     a.ppi = planes;
+    a.m_ppi = map_magic((unsigned)planes);
     a.bstride = g_batch.ws;
     planes *= (int)g_batch.batch;
     a.total_tiles = planes * a.tiles_m * a.tiles_n;
@@ -610,6 +614,7 @@ template <int EPI> static hipError_t launch(hipStream_t stream, F8Args& a, int p
     if (a.nseg < 1) a.nseg = 1;
     if (a.nres < 1) a.nres = 2;
     a.colblock = map_colblock((size_t)a.tiles_n, (size_t)a.kp * (size_t)a.nseg);
+    a.map = make_tile_map(a.tiles_m, a.tiles_n, a.colblock);
     int grid = num_cus() & ~7;  // persistent: one workgroup per CU (see oz2_gemm_i8.hip)
     if (grid <= 0) grid = 8;
     if (a.total_tiles < grid) grid = a.total_tiles;

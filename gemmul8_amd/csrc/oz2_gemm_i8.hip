@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     auto run = [&]<bool WM1>() {
         int sA = 0;  // slot of A(g); B(g) sits in the next slot (mod 5)
         for (int vb = blockIdx.x; vb < total; vb += G) {
-            const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n, args.colblock);
+            const TileMap tmap = map_tile(vb, total, args.map);
             for (int pl = 0; pl < planes_per_tile; ++pl) {
             v4i acc[8][4];
             v4i af[4], bf[4];
@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     if (wm == 1) __builtin_amdgcn_s_barrier();  // trailing half: one segment behind
     int sA = 0;                                  // slot of A(g); B(g) sits in the next slot (mod 5)
     for (int vb = blockIdx.x; vb < total; vb += G) {
-        const TileMap tmap = map_tile(vb, total, args.tiles_m, args.tiles_n, args.colblock);
+        const TileMap tmap = map_tile(vb, total, args.map);
         for (int pl = 0; pl < planes_per_tile; ++pl) {
         v4i acc[8][4];
 #pragma unroll
@@ -422,11 +422,13 @@ static hipError_t launch_sched(hipStream_t stream, GemmArgs& a, const std::condi
 template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int planes) {
     // batched call: the items' planes are one long plane sequence (item-major), the persistent tile loop runs over all of them
     a.ppi = planes;
+    a.m_ppi = map_magic((unsigned)planes);
     a.bstride = g_batch.ws;
     planes *= (int)g_batch.batch;
     a.total_tiles = planes * a.tiles_m * a.tiles_n;
     if (a.total_tiles <= 0) return hipSuccess;
     a.colblock = map_colblock((size_t)a.tiles_n, (size_t)a.kp * (size_t)a.nseg);
+    a.map = make_tile_map(a.tiles_m, a.tiles_n, a.colblock);
     a.acc0 = (size_t)a.kp * (size_t)a.nseg <= 512 ? 0 : (int)0x80000000u;  // RED_ODD_SMALL needs |sum| < 2^23
     // (the bound GEMM keeps the ping-pong schedule at every k.  In round 2 its K-step-barrier instantiation spilled accumulators INSIDE
     // the MFMA loop; with the round-3 source it no longer does, but the single-plane launch still runs slower with it: bounds phase

@@ -43,6 +43,7 @@ struct GemmArgs {
     int m, n;              // valid rows / cols of C
     int tiles_m, tiles_n;
     int colblock;          // tile-columns per column block of the tile walk (map_colblock; 0 = full width)
+    TileMapArgs map;       // the same with the divisors' magic numbers (make_tile_map; filled by launch<EPI>)
     int t_begin;           // plane p <-> modulus t_begin + p
     int8_t* out;           // EPI_MOD: plane p at out + p*strideO, [n][ldo] int8; EPI_CPLX: [n][ldo] char2
     size_t ldo;
@@ -56,6 +57,7 @@ struct GemmArgs {
     int total_tiles;       // planes * tiles_m * tiles_n (tile-stationary order, FUSE != 0: tiles_m * tiles_n)
     int planes;            // FUSE != 0: residue planes every workgroup runs through per output tile
     int ppi;               // planes per batch item (plane p = item p / ppi, modulus-relative plane p % ppi); = all planes for one GEMM
+    unsigned m_ppi;        // floor(2^32 / ppi) (map_magic): plane_ref divides on the scalar unit
     size_t bstride;        // bytes between the workspaces of consecutive batch items (every pointer above lives in the workspace)
     int moduli[20];
     int pinv32[20];
@@ -74,8 +76,9 @@ struct PlaneRef {
 };
 template <typename Args> __device__ __forceinline__ PlaneRef plane_ref(const Args& args, int plane) {
     const int p = __builtin_amdgcn_readfirstlane(plane);
-    const int b = p / args.ppi;
-    return {(size_t)b * args.bstride, p - b * args.ppi};
+    unsigned b, tt;  // (a plain p / ppi leaves a hoisted float reciprocal in a VGPR across every K loop: oz2_gemm_common.hpp, udivmod_magic)
+    udivmod_magic((unsigned)p, (unsigned)args.ppi, args.m_ppi, b, tt);
+    return {(size_t)b * args.bstride, (int)tt};
 }
 enum { RED_ODD = 1, RED_ODD_SMALL = 3 };
 // RED selects how an accumulator is reduced to its residue's low byte -- one form per kernel instantiation (i8_epilogue): RED_ODD for any int32

@@ -37,9 +37,11 @@ hipError_t launch_gemm_i8_mod_crt(hipStream_t stream, int dtype, const int8_t* A
     fill_common(a, kp, m, n);
     a.planes = (int)N;
     a.ppi = (int)N;
+    a.m_ppi = map_magic((unsigned)N);
     a.total_tiles = a.tiles_m * a.tiles_n;
     if (a.total_tiles <= 0) return hipSuccess;
     a.colblock = map_colblock((size_t)a.tiles_n, (size_t)a.kp);
+    a.map = make_tile_map(a.tiles_m, a.tiles_n, a.colblock);
     a.acc0 = ((size_t)a.kp <= 512) ? 0 : (int)0x80000000u;
     CrtArgs c{};
     c.m = m;
