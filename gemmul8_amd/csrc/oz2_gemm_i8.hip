@@ -208,6 +208,8 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
         int sA = 0;  // slot of A(g); B(g) sits in the next slot (mod 5)
         for (int vb = blockIdx.x; vb < total; vb += G) {
             const TileMap tmap = map_tile(vb, total, args.map);
+            const PlaneRef pref = (FUSE || EPI == EPI_MAX) ? PlaneRef{0, 0} : plane_ref(args, tmap.plane);  // (the bound GEMM looks its plane up at the epilogue: one value less across its K loop)
+            const PlaneConsts pcon = (FUSE || EPI == EPI_MAX) ? PlaneConsts{} : plane_consts(args, pref);  // fetched here: the latency passes behind the K loop
             for (int pl = 0; pl < planes_per_tile; ++pl) {
             v4i acc[8][4];
             v4i af[4], bf[4];
@@ -277,7 +279,9 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
                 for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-            i8_epilogue<EPI, NoHook, FUSE != 0 ? -1 : (int)SMALLK>(acc, args, FUSE ? PlaneRef{0, pl} : plane_ref(args, tmap.plane), tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane);
+            if constexpr (FUSE != 0) i8_epilogue<EPI, NoHook, -1>(acc, args, PlaneRef{0, pl}, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane);
+            else if constexpr (EPI == EPI_MAX) i8_epilogue<EPI, NoHook, 0>(acc, args, plane_ref(args, tmap.plane), PlaneConsts{}, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane);
+            else i8_epilogue<EPI, NoHook, (int)SMALLK>(acc, args, pref, pcon, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane);
 #endif
             }  // phase
             }
@@ -295,6 +299,8 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     int sA = 0;                                  // slot of A(g); B(g) sits in the next slot (mod 5)
     for (int vb = blockIdx.x; vb < total; vb += G) {
         const TileMap tmap = map_tile(vb, total, args.map);
+        const PlaneRef pref = (FUSE || EPI == EPI_MAX) ? PlaneRef{0, 0} : plane_ref(args, tmap.plane);  // (the bound GEMM looks its plane up at the epilogue: one value less across its K loop)
+        const PlaneConsts pcon = (FUSE || EPI == EPI_MAX) ? PlaneConsts{} : plane_consts(args, pref);  // fetched here: the latency passes behind the K loop
         for (int pl = 0; pl < planes_per_tile; ++pl) {
         v4i acc[8][4];
 #pragma unroll
@@ -354,7 +360,13 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-        i8_epilogue<EPI, NoHook, FUSE != 0 ? -1 : (int)SMALLK>(acc, args, FUSE ? PlaneRef{0, pl} : plane_ref(args, tmap.plane), tmap.tm * BM + wm * 128, tmap.tn * BN + wn * 64, lane);
+        // every reload still pending on some path is waited for HERE (the previous tile's stores retired a whole K loop ago: free), so that the waitcnt
+        // pass has no reason to put a vmcnt wait into the K loop (it did, in the K-step-barrier kernels until round 4 and in the bound GEMM after a
+        // register-allocation change: tests/test_kernel_resources.py)
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        if constexpr (FUSE != 0) i8_epilogue<EPI, NoHook, -1>(acc, args, PlaneRef{0, pl}, tmap.tm * BM + wm * 128, tmap.tn * BN + wn * 64, lane);
+        else if constexpr (EPI == EPI_MAX) i8_epilogue<EPI, NoHook, 0>(acc, args, plane_ref(args, tmap.plane), PlaneConsts{}, tmap.tm * BM + wm * 128, tmap.tn * BN + wn * 64, lane);
+        else i8_epilogue<EPI, NoHook, (int)SMALLK>(acc, args, pref, pcon, tmap.tm * BM + wm * 128, tmap.tn * BN + wn * 64, lane);
 #endif
         }  // phase
         }

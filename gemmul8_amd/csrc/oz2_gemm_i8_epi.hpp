@@ -80,6 +80,16 @@ template <typename Args> __device__ __forceinline__ PlaneRef plane_ref(const Arg
     udivmod_magic((unsigned)p, (unsigned)args.ppi, args.m_ppi, b, tt);
     return {(size_t)b * args.bstride, (int)tt};
 }
+// the per-modulus constants of the residue epilogues (scalar loads from the argument block, indexed by the plane): the persistent kernels fetch them
+// at the START of a tile, so that their latency passes behind the K loop instead of in front of the epilogue
+struct PlaneConsts {
+    int p;
+    unsigned dotw, dotc;
+};
+__device__ __forceinline__ PlaneConsts plane_consts(const GemmArgs& args, PlaneRef pl) {
+    const int t = args.t_begin + pl.tt;
+    return {args.moduli[t], args.dotw[t], args.dotc[t]};
+}
 enum { RED_ODD = 1, RED_ODD_SMALL = 3 };
 // RED selects how an accumulator is reduced to its residue's low byte -- one form per kernel instantiation (i8_epilogue): RED_ODD for any int32
 // accumulator (byte dot product on the biased accumulator + one fp32 quotient, below), RED_ODD_SMALL for launches with K <= 512.  p = 256 runs through
@@ -109,13 +119,12 @@ template <bool NT> __device__ __forceinline__ void store16_cols(void* ptr, v4u d
                      : "=&s"(saved) : "s"(n), "v"(col), "v"(ptr), "v"(d) : "vcc", "scc", "memory");
 }
 template <int EPI, int RED, typename Hook = NoHook>
-__device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const GemmArgs& args, PlaneRef pl, int i0, int j0, int lane, Hook hook = {}) {
+__device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const GemmArgs& args, PlaneRef pl, PlaneConsts pc, int i0, int j0, int lane, Hook hook = {}) {
     const int c16 = lane & 15;
     const int q = lane >> 4;
-    const int t = args.t_begin + pl.tt;
-    const int p = args.moduli[t];
+    const int p = pc.p;
     const float invp = 1.0f / (float)p;
-    [[maybe_unused]] const unsigned dotw = args.dotw[t], dotc = args.dotc[t];
+    [[maybe_unused]] const unsigned dotw = pc.dotw, dotc = pc.dotc;
     static_assert(RED == RED_ODD || RED == RED_ODD_SMALL, "one of the two reduction forms");
     // RED_ODD_SMALL, short K (kp * nseg <= 512: |x| <= 512 * 127^2 < 2^23; the accumulators start at 0, GemmArgs.acc0): the quotient comes
     // straight from the accumulator -- v_cvt_f32_i32, one fma against 1.5 * 2^23 (its low 24 bits are 2^22 + q for either sign
@@ -269,7 +278,7 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
 }
 
 template <int EPI, typename Hook = NoHook, int SMALLK = -1>
-__device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmArgs& args, PlaneRef pl, int i0, int j0, int lane, Hook hook = {}) {
+__device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmArgs& args, PlaneRef pl, PlaneConsts pc, int i0, int j0, int lane, Hook hook = {}) {
     const int c16 = lane & 15;
     const int q = lane >> 4;
 
@@ -280,10 +289,10 @@ __device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmAr
         // structurizer lays such a chain out as a straight line of predicated blocks, which keeps the accumulators live through the whole
         // epilogue of every form but the last -- no accumulator register could be reused inside an epilogue.
         // SMALLK < 0: the form is chosen at run time from GemmArgs.acc0 (laboratory kernels).
-        if constexpr (SMALLK > 0) i8_epilogue_mod<EPI, RED_ODD_SMALL, Hook>(acc, args, pl, i0, j0, lane, hook);
-        else if constexpr (SMALLK == 0) i8_epilogue_mod<EPI, RED_ODD, Hook>(acc, args, pl, i0, j0, lane, hook);
-        else if (args.acc0 == 0) i8_epilogue_mod<EPI, RED_ODD_SMALL, Hook>(acc, args, pl, i0, j0, lane, hook);
-        else i8_epilogue_mod<EPI, RED_ODD, Hook>(acc, args, pl, i0, j0, lane, hook);
+        if constexpr (SMALLK > 0) i8_epilogue_mod<EPI, RED_ODD_SMALL, Hook>(acc, args, pl, pc, i0, j0, lane, hook);
+        else if constexpr (SMALLK == 0) i8_epilogue_mod<EPI, RED_ODD, Hook>(acc, args, pl, pc, i0, j0, lane, hook);
+        else if (args.acc0 == 0) i8_epilogue_mod<EPI, RED_ODD_SMALL, Hook>(acc, args, pl, pc, i0, j0, lane, hook);
+        else i8_epilogue_mod<EPI, RED_ODD, Hook>(acc, args, pl, pc, i0, j0, lane, hook);
     } else {
         int* const rowmax_ = (int*)((char*)args.rowmax + pl.boff);
         int* const colmax_ = (int*)((char*)args.colmax + pl.boff);
@@ -326,6 +335,11 @@ __device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmAr
     }
 }
 
+
+template <int EPI, typename Hook = NoHook, int SMALLK = -1>
+__device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmArgs& args, PlaneRef pl, int i0, int j0, int lane, Hook hook = {}) {
+    i8_epilogue<EPI, Hook, SMALLK>(acc, args, pl, EPI == EPI_MAX ? PlaneConsts{} : plane_consts(args, pl), i0, j0, lane, hook);
+}
 
 #ifdef OZ2_LAB_SHORTK  // laboratory kernel (tools/experiments/shortk/oz2_gemm_i8_shortk.hip); `a` complete as launch<EPI> of oz2_gemm_i8.hip leaves it
 hipError_t launch_gemm_i8_shortk(hipStream_t stream, const GemmArgs& a, int epi);
