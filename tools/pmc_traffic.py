@@ -35,11 +35,17 @@ N = int(sys.argv[5]) if len(sys.argv) > 5 else 14
 operand = n * n * 8.0  # one FP64 operand
 known_reads = {  # bytes a launch reads exactly once (config 2: DGEMM n^3, N moduli, op N/N)
     "oz2::amax_strided_kernel<double>": operand,
+    "oz2::extract_strided_kernel<double>": operand,
+    "oz2::extract_kmajor_kernel<double>": operand,
+    "oz2::quantise_pair_kernel<double>": 2 * operand,       # round 4: A and B in one launch
+    "oz2::fast_shift_pair_kernel<double>": 2 * operand,
+    "oz2::crt_dma_kernel<double, false>": N * n * n * 1.0,   # the residue planes (beta = 0: C is not read)
+    "oz2::crt_kernel<double, false, signed char>": N * n * n * 1.0,
+    # names of rounds 1-3 (one launch per operand)
     "oz2::stage_strided_kernel<double, 0>": operand,
     "oz2::stage_kmajor_kernel<double, 0>": operand,
     "oz2::stage_strided_kernel<double, 1>": operand,
     "oz2::stage_kmajor_kernel<double, 1>": operand,
-    "oz2::crt_kernel<double, false, signed char>": N * n * n * 1.0,
 }
 out = {}
 for k in sorted(set(fetch) | set(write)):
