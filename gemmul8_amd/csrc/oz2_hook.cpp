@@ -454,12 +454,12 @@ struct FloorModel {
     double e[6];  // ms: 1, (m+n)k, N(m+n)k, mn, N mn, N mnk
     double n[3];  // ms: 1, mn, mnk
 };
-// generated by tools/fit_floor.py
+// generated by tools/fit_floor.py from profiles/sweeps/r04b_floor_scan_*.csv (the final round-4 kernels: emulation is 3-8 % faster at k <= 2048 than at the round-3 fit)
 static const FloorModel kFloor[4][2] = {  // [S, D, C, Z][accurate, fast]
-    {{{0.0645, 2.285e-09, 4.147e-10, 1.694e-09, 4.08e-10, 5.589e-13}, {0.02053, 4.996e-10, 1.333e-11}}, {{0.04985, 1.623e-09, 4.27e-10, 9.139e-10, 4.164e-10, 5.381e-13}, {0.02053, 4.996e-10, 1.333e-11}}},
-    {{{0.0594, 3.454e-09, 4.262e-10, 1.137e-09, 5.264e-10, 5.443e-13}, {0.01041, 5.723e-10, 2.757e-11}}, {{0.04537, 2.218e-09, 4.341e-10, 4.592e-10, 5.204e-10, 5.395e-13}, {0.01041, 5.723e-10, 2.757e-11}}},
-    {{{0.09541, 7.142e-09, 1.221e-09, 2.907e-09, 2.514e-09, 1.793e-12}, {0.01247, 3.124e-10, 5.502e-11}}, {{0.06607, 3.724e-09, 1.237e-09, 1.175e-09, 2.57e-09, 1.612e-12}, {0.01247, 3.124e-10, 5.502e-11}}},
-    {{{0.1111, 1.222e-08, 1.376e-09, 7.487e-10, 2.956e-09, 1.689e-12}, {0.00809, 2.584e-10, 1.076e-10}}, {{0.07812, 7.692e-09, 1.346e-09, 4.235e-11, 3.05e-09, 1.503e-12}, {0.00809, 2.584e-10, 1.076e-10}}},
+    {{{0.05902, 1.84e-09, 4.091e-10, 1.833e-09, 3.493e-10, 6.125e-13}, {0.02192, 4.685e-10, 1.377e-11}}, {{0.04339, 9.451e-10, 4.161e-10, 1.02e-09, 3.69e-10, 5.764e-13}, {0.02192, 4.685e-10, 1.377e-11}}},
+    {{{0.05264, 3.467e-09, 4.163e-10, 1.434e-09, 4.826e-10, 5.827e-13}, {0.01186, 6.009e-10, 2.791e-11}}, {{0.03959, 1.777e-09, 4.192e-10, 6e-10, 4.747e-10, 5.815e-13}, {0.01186, 6.009e-10, 2.791e-11}}},
+    {{{0.07382, 6.651e-09, 1.168e-09, 3.558e-09, 1.815e-09, 1.753e-12}, {0.01502, 3.243e-10, 5.563e-11}}, {{0.05627, 3.32e-09, 1.161e-09, 2.038e-09, 1.791e-09, 1.716e-12}, {0.01502, 3.243e-10, 5.563e-11}}},
+    {{{0.08236, 1.225e-08, 1.263e-09, 2.257e-09, 2.11e-09, 1.717e-12}, {0.01278, 2.34e-10, 1.085e-10}}, {{0.06348, 7.741e-09, 1.238e-09, 1.24e-09, 2.148e-09, 1.635e-12}, {0.01278, 2.34e-10, 1.085e-10}}},
 };
 static bool floor_model_declines(int dtype, double m, double n, double k, unsigned N, bool fast, int backend, double batch) {
     const FloorModel& fm = kFloor[dtype][fast ? 1 : 0];
