@@ -56,7 +56,7 @@ namespace oz2 {
 #define OZ2_PB 4
 #endif
 #ifndef OZ2_KBAR_MAX_KP
-#define OZ2_KBAR_MAX_KP 4096  // padded k up to which the K-step-barrier schedule is used (see launch<EPI>); 0 = never, 1 << 30 = always
+#define OZ2_KBAR_MAX_KP 5120  // padded k up to which the K-step-barrier schedule is used (see launch<EPI>); 0 = never, 1 << 30 = always.  Round 4 (after the epilogue / tile-prologue work): +1.0 / +1.3 % at k = 4608 / 5120 on 8192^2 x 14 planes, +0.5 % at 5120 on 16384^2 x 6; at 6144 +0.9 % / -1.1 %, at 7168 0 / -1.3 %, at 8192 -1.3 % (profiles/r04_gemm_ab_kbar_threshold.txt)
 #endif
 #ifndef OZ2_SLEEP_A
 #define OZ2_SLEEP_A 4  // s_sleep units (64 clocks) between the A producers' 8 groups of 2 LDS-DMA instructions
