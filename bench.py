@@ -283,28 +283,62 @@ def run_plans(args, n, N, A, B, dev, stream, backend, rank, world):
     import torch.distributed as dist
     import gemmul8_amd as g
     from gemmul8_amd import dist as gd
-    comm = gd.RcclComm() if backend == "nccl" else gd.TorchTransport(device=True)
-    rccl_ranks = comm.rccl_ranks()
     peak = 5000.0
     # First contact with the transport, before anything is timed (GEMMUL8_DIST_SELFTEST=0 skips it): communicator size, all-reduce(MAX),
-    # grouped send/recv ring, reduce-scatter(sum) against host arithmetic -- a failure ends the run with ONE line that says which
-    selftest = "skipped"
-    if os.environ.get("GEMMUL8_DIST_SELFTEST", "1") != "0":
-        ok, msg = gd.selftest(comm, dev, stream.cuda_stream, expect_rccl=(backend == "nccl"))
-        flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=dev)
+    # grouped send/recv ring, reduce-scatter(sum) against host arithmetic.  Order of choice on the nccl backend: the library's own RCCL
+    # communicator (RcclComm, the product path); if it cannot be created or fails the self-test on ANY rank, every rank falls back to
+    # torch's nccl (= RCCL) process group on the same device buffers (TorchNcclTransport; GEMMUL8_DIST_BACKEND=torch-nccl forces it) and
+    # the JSON says so -- a first multi-GPU lease then still returns a measured line.  A transport that fails there too ends the run
+    # with ONE line that says which check failed.
+    want_test = os.environ.get("GEMMUL8_DIST_SELFTEST", "1") != "0"
+
+    def agree(bad):
+        flag = torch.tensor([1 if bad else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return int(flag.item()) != 0
+
+    def bring_up(make, expect_rccl):
+        comm, ok, msg = None, True, "skipped"
+        try:
+            comm = make()
+            if want_test:
+                ok, msg = gd.selftest(comm, dev, stream.cuda_stream, expect_rccl=expect_rccl)
+        except Exception as e:
+            ok, msg = False, f"rank {rank}: {type(e).__name__}: {e}"
         if not ok:
             print(f"[bench] DIST SELFTEST FAILED: {msg}", file=sys.stderr, flush=True)
-        if int(flag.item()) != 0:
+        if agree(not ok):
+            if comm is not None:
+                comm.close()
+            return None, msg if not ok else "failed on another rank (see stderr)"
+        return comm, msg
+
+    fallback_reason = None
+    comm, msg = (None, None)
+    if backend == "nccl":
+        def first_choice():
+            if os.environ.get("GEMMUL8_BENCH_FAIL_FIRST_TRANSPORT", "0") == "1":   # test knob: exercise the fall-back (tests/test_gpu_dist.py)
+                raise RuntimeError("GEMMUL8_BENCH_FAIL_FIRST_TRANSPORT=1")
+            return gd.RcclComm()
+        comm, msg = bring_up(first_choice, True)
+        if comm is None:
+            fallback_reason = msg
+            backend = "torch-nccl"
             if rank == 0:
-                print(json.dumps({"metric": f"emulated DGEMM TFLOPS (N={n}, moduli={N})", "value": None, "n_gpus": world, "error": "dist selftest failed",
-                                  "dist_selftest": msg if not ok else "failed on another rank (see stderr)"}))
-            comm.close()
-            dist.barrier()
-            dist.destroy_process_group()
-            sys.exit(3)
-        selftest = "ok: ncclCommCount, all-reduce(MAX,int32), grouped send/recv ring, reduce-scatter(sum,f64) checked against host arithmetic" if backend == "nccl" \
-            else "ok (gloo test transport): all-reduce(MAX,int32), grouped send/recv ring, reduce-scatter(sum,f64) checked against host arithmetic"
+                print("[bench] the library's own RCCL communicator is not usable here; falling back to torch's nccl process group", file=sys.stderr, flush=True)
+    if comm is None:
+        comm, msg = bring_up(gd.TorchNcclTransport if backend == "torch-nccl" else (lambda: gd.TorchTransport(device=True)), False)
+    if comm is None:
+        if rank == 0:
+            print(json.dumps({"metric": f"emulated DGEMM TFLOPS (N={n}, moduli={N})", "value": None, "n_gpus": world, "error": "dist selftest failed",
+                              "dist_selftest": msg, "first_choice_failure": fallback_reason}))
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(3)
+    rccl_ranks = comm.rccl_ranks()
+    checked = "all-reduce(MAX,int32), grouped send/recv ring, reduce-scatter(sum,f64) checked against host arithmetic"
+    selftest = "skipped" if not want_test else {"nccl": "ok: ncclCommCount, " + checked, "torch-nccl": "ok (torch's nccl process group): " + checked}.get(
+        backend, "ok (gloo test transport): " + checked)
     # single-GPU phase times on rank 0 (the other ranks wait): the inputs of the per-plan time model in the JSON
     phases = None
     if rank == 0:
@@ -374,7 +408,10 @@ def run_plans(args, n, N, A, B, dev, stream, backend, rank, world):
         results[name] = rec
         plan.close()
         barrier()
-    info = {"transport": "RCCL (ncclCommInitRank inside libgemmul8.so)" if backend == "nccl" else f"gloo TEST transport, host-staged ({world} ranks on {torch.cuda.device_count()} GPU(s))",
+    transport = {"nccl": "RCCL (ncclCommInitRank inside libgemmul8.so)",
+                 "torch-nccl": "RCCL through torch.distributed's nccl process group, device buffers (second choice: see first_choice_failure)"}.get(
+        backend, f"gloo TEST transport, host-staged ({world} ranks on {torch.cuda.device_count()} GPU(s))")
+    info = {"transport": transport, "first_choice_failure": fallback_reason,
             "rccl_ranks": rccl_ranks, "dist_selftest": selftest, "single_gpu_phase_ms": phases,
             "model_assumptions": "plans[*].model_ms = DESIGN.md 5's per-rank model from single_gpu_phase_ms: kernels scale with the rank's share; bounds = 30 % A side + 17 % B "
                                  "side + 53 % bound GEMM; quantise 52 % A / 48 % B; all-reduce(MAX) 0.05 ms; 45 GB/s per xGMI peer link and direction, all peers at once; "
@@ -408,7 +445,7 @@ def main():
     world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("GEMMUL8_DIST_BACKEND", "nccl") != "nccl":
+    if os.environ.get("GEMMUL8_DIST_BACKEND", "nccl") not in ("nccl", "torch-nccl"):
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -420,7 +457,9 @@ def main():
         import torch.distributed as dist
         # RCCL ("nccl") is the product path; GEMMUL8_DIST_BACKEND=gloo only exists to smoke-test this file with
         # several ranks sharing one GPU (host-staged exchange), where NCCL refuses duplicate devices.
-        if backend == "nccl":
+        # GEMMUL8_DIST_BACKEND=torch-nccl: the same nccl process group, the plans' exchanges through it instead of the library's
+        # own communicator (run_plans' second choice, forced).
+        if backend in ("nccl", "torch-nccl"):
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)

@@ -8,6 +8,8 @@ same code.  This module only
   * offers `TorchTransport`, a gemmul8_comm table implemented with torch.distributed calls through ctypes callbacks -- the
     TEST transport: gloo on CPU (tests/test_dist_cpu.py drives the C++ plans at world sizes 2..8 with host memory) and
     host-staged gloo for several ranks sharing the one GPU of a test box,
+  * offers `TorchNcclTransport`, the same table over torch's own nccl (= RCCL) process group on the device buffers -- bench.py's
+    second choice on a multi-GPU node when the library's own communicator cannot be brought up,
   * wraps a plan as `DistGemm` for bench.py and the tests.
 
 Placement: A and B replicated on every rank, C full-size on every rank, each rank updating the block it owns
@@ -241,6 +243,90 @@ class TorchTransport:
             return 0
         except Exception as e:
             print("TorchTransport.reduce_scatter failed:", e)
+            return 1
+
+
+class _DevView:
+    """A raw device pointer as a __cuda_array_interface__ object (version 2: no stream hand-shake), so that torch can wrap it."""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class TorchNcclTransport:
+    """gemmul8_comm over an EXISTING torch.distributed nccl (= RCCL) process group, on the device buffers themselves: no host
+    staging, the bytes travel over xGMI exactly as with RcclComm, but inside the communicator torch already brought up.
+    bench.py's SECOND choice on a multi-GPU node: taken only when the library's own communicator (RcclComm, ncclCommInitRank in
+    libgemmul8.so) cannot be created or fails its self-test, so that a first 8-GPU lease still returns a measured line; the JSON
+    says which transport ran.  The collectives are issued on the stream the plan passes (wrapped as an ExternalStream when it is
+    not torch's current one); torch's process group orders them after that stream's work and the stream after them."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        self._keep = [ALLREDUCE_FN(self._allreduce), SENDRECV_FN(self._sendrecv), REDSCAT_FN(self._redscat), DESTROY_FN(lambda ctx: None)]
+        self.struct = Comm(None, self.rank, self.world, *self._keep)
+        self.ptr = C.pointer(self.struct)
+
+    def rccl_ranks(self):
+        return self.world  # torch's communicator: its size is the group's
+
+    def close(self):
+        pass
+
+    def _peer(self, r):
+        return r if self.group is None else self.dist.get_global_rank(self.group, r)
+
+    def _view(self, ptr, count, typestr):
+        return self.torch.as_tensor(_DevView(ptr, count, typestr), device=self.dev)
+
+    def _on(self, stream):
+        """Context that makes `stream` (a raw hipStream_t, None / 0 = the null stream) torch's current stream."""
+        t = self.torch
+        raw = int(stream or 0)
+        if raw == t.cuda.current_stream(self.dev).cuda_stream:
+            import contextlib
+            return contextlib.nullcontext()
+        return t.cuda.stream(t.cuda.ExternalStream(raw, device=self.dev) if raw else t.cuda.default_stream(self.dev))
+
+    def _allreduce(self, ctx, buf, count, stream):
+        try:
+            with self._on(stream):
+                self.dist.all_reduce(self._view(buf, count, "<i4"), op=self.dist.ReduceOp.MAX, group=self.group)
+            return 0
+        except Exception as e:  # an exception must not unwind through the C++ caller
+            print("TorchNcclTransport.allreduce failed:", e)
+            return 1
+
+    def _sendrecv(self, ctx, nops, ops, stream):
+        try:
+            work = []
+            for i in range(nops):
+                op = ops[i]
+                if op.bytes == 0:
+                    continue
+                t = self._view(op.buf, op.bytes, "|u1")
+                work.append(self.dist.P2POp(self.dist.isend if op.is_send else self.dist.irecv, t, self._peer(op.peer), self.group))
+            if work:
+                with self._on(stream):
+                    for w in self.dist.batch_isend_irecv(work):
+                        w.wait()   # stream-level wait for nccl work: the host does not block
+            return 0
+        except Exception as e:
+            print("TorchNcclTransport.sendrecv failed:", e)
+            return 1
+
+    def _redscat(self, ctx, send, recv, recv_count, stream):
+        try:
+            with self._on(stream):
+                self.dist.reduce_scatter_tensor(self._view(recv, recv_count, "<f8"), self._view(send, recv_count * self.world, "<f8"),
+                                                op=self.dist.ReduceOp.SUM, group=self.group)
+            return 0
+        except Exception as e:
+            print("TorchNcclTransport.reduce_scatter failed:", e)
             return 1
 
 

@@ -263,3 +263,83 @@ def test_bench_plan_path_on_real_rccl_one_rank():
     assert d["n_gpus"] == 1 and d["value"] > 10 and d["max_rel_err"] < 1e-9 and d["roofline"]["achieved"] > 0
     assert d["rccl_ranks"] == 1 and "RCCL" in d["transport"] and "ncclCommCount" in d["dist_selftest"]
     assert all(p["mismatches_vs_moduli"] == 0 for p in d["plans"].values())   # one rank: every plan groups all moduli together
+
+
+@pytest.mark.parametrize("how", ["forced", "fallback"])
+def test_bench_plan_path_on_torch_nccl_transport_one_rank(how):
+    """bench.py's SECOND-choice transport (gemmul8_amd.dist.TorchNcclTransport: the plans' exchanges through torch's own nccl = RCCL
+    process group, on the device buffers) with the single rank this box allows: forced by GEMMUL8_DIST_BACKEND=torch-nccl, and reached
+    as the fall-back when the library's own communicator cannot be brought up (injected failure)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GEMMUL8_BENCH_FORCE_PLAN="1")
+    env.pop("GEMMUL8_DIST_BACKEND", None)
+    if how == "forced":
+        env["GEMMUL8_DIST_BACKEND"] = "torch-nccl"
+    else:
+        env["GEMMUL8_BENCH_FAIL_FIRST_TRANSPORT"] = "1"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--size", "2048"], env=env, capture_output=True, text=True, timeout=600)
+    d = _one_json_line(out)
+    assert d["n_gpus"] == 1 and d["value"] > 10 and d["max_rel_err"] < 1e-9
+    assert "torch.distributed" in d["transport"] and d["dist_selftest"].startswith("ok (torch's nccl")
+    assert (d["first_choice_failure"] is None) == (how == "forced")
+    if how == "fallback":
+        assert "FAIL_FIRST_TRANSPORT" in d["first_choice_failure"]
+    assert all(p["mismatches_vs_moduli"] == 0 for p in d["plans"].values())
+
+
+def _torch_nccl_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import ctypes as C
+    import gemmul8_amd as g
+    from gemmul8_amd import dist as gd
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    comm = gd.TorchNcclTransport()
+    ok, msg = gd.selftest(comm, "cuda:0", None, expect_rccl=True)   # rccl_ranks() = the group's size
+    c = comm.ptr.contents
+    side = torch.cuda.Stream()
+    for st in (torch.cuda.current_stream(), side):                  # the plan's stream need not be torch's current one
+        with torch.cuda.stream(st):
+            out = torch.arange(5000, dtype=torch.int32, device="cuda").to(torch.uint8)
+            inn = torch.zeros_like(out)
+        ops = (gd.P2POp * 2)(gd.P2POp(out.data_ptr(), out.numel(), 0, 1), gd.P2POp(inn.data_ptr(), inn.numel(), 0, 0))   # to / from myself
+        ok &= c.sendrecv(c.ctx, 2, ops, st.cuda_stream) == 0
+        part = torch.rand(4096, dtype=torch.float64, device="cuda")
+        st.wait_stream(torch.cuda.current_stream())
+        red = torch.empty_like(part)
+        ok &= c.reduce_scatter_sum_f64(c.ctx, part.data_ptr(), red.data_ptr(), part.numel(), st.cuda_stream) == 0
+        torch.cuda.synchronize()
+        ok &= bool(torch.equal(inn, out)) and bool(torch.equal(part, red))
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    m, n, k, N = 700, 515, 900, 14
+    A = torch.rand((k, m), generator=gen, dtype=torch.float64, device="cuda") - 0.5
+    B = torch.rand((n, k), generator=gen, dtype=torch.float64, device="cuda") - 0.5
+    refC, _, _ = g.gemm(A, B, N)
+    for plan in ("blocks", "moduli", "fp64sum"):
+        pl = gd.DistGemm(comm, plan, g.D, g.INT8, m, n, k, N)
+        Cm = torch.zeros((n, m), dtype=torch.float64, device="cuda")
+        pl.run(A, B, Cm)
+        pl.gather_result(Cm)
+        torch.cuda.synchronize()
+        ok &= bool(torch.equal(Cm, refC))
+        pl.close()
+    dist.destroy_process_group()
+    q.put((bool(ok), msg))
+
+
+def test_torch_nccl_transport_world1():
+    """gemmul8_amd.dist.TorchNcclTransport (bench.py's second-choice transport: the plans' exchanges through torch's nccl = RCCL process
+    group on the device buffers themselves): self-test, a send/recv pair to itself and a reduce-scatter on torch's current stream AND on a
+    side stream, and all three plans, with the one rank this box allows."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_torch_nccl_worker, args=(_port(), q))
+    assert _start_and_reap([p], 300) == [0]
+    ok, msg = q.get(timeout=10)
+    assert ok, msg
