@@ -5,6 +5,8 @@
 //   4   the LDS-DMA is issued during a workgroup's first tile only (what the L2 -> LDS operand path costs: DESIGN.md 3.1)
 //   8   no epilogue, the accumulators stay live
 //   16  operands come from the first 8 K-steps of a panel only (every fetch an L2 hit: what the L2 misses cost)
+//   32  dose-response of the operand path: after a workgroup's first tile the LDS-DMA of every OZ2_DMA_SKIP-th K-step is left out
+//       (OZ2_DMA_SKIP = 6: -16.7 % of the L2 -> LDS bytes per MAC, what a 384 x 256 CU tile would save; 2: -50 %)
 // OZ2_KSTAG=<1..4> staggers the K-step a workgroup starts from (1: XCD x starts at x KT1 / 8; 2: plus (CU & 3) K-steps; 3: (CU & 7)
 // K-steps only; 4: odd XCDs start at KT1 / 2) -- bit-identical results (INT32 sums are order-independent), measured neutral
 // (profiles/r04_gemm_ab_kstag_order_l2.txt).
@@ -15,8 +17,13 @@
 #ifndef OZ2_KSTAG
 #define OZ2_KSTAG 0
 #endif
+#ifndef OZ2_DMA_SKIP
+#define OZ2_DMA_SKIP 6
+#endif
 #if OZ2_PROBE & 4
 #define OZ2_HOOK_DMA_ON(first_tile) (first_tile)
+#elif OZ2_PROBE & 32
+#define OZ2_HOOK_DMA_ON(first_tile) ((first_tile) || (kt % OZ2_DMA_SKIP) != 0)
 #endif
 #if OZ2_PROBE & 8
 #define OZ2_HOOK_SKIP_EPILOGUE 1
