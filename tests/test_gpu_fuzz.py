@@ -66,6 +66,53 @@ def test_random_case_bit_exact(seed, monkeypatch):
     gu.parity_case(A, B, N, fast, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0, backend=backend)
 
 
+N_SEEDS_LARGE_K = int(os.environ.get("GEMMUL8_FUZZ_LARGEK_SEEDS", "32"))
+DIMS_K_LARGE = [513, 640, 1023, 1024, 1300, 2049, 4097, 5120, 5121, 5400, 8193]
+DIMS_MN_LARGE_K = [1, 31, 129, 255, 256, 257, 300]
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS_LARGE_K))
+def test_random_case_large_k_bit_exact(seed, monkeypatch):
+    """The sweep above keeps k <= 400 for the scalar oracle's sake, i.e. padded k <= 512: every INT8 case of it runs the short-K
+    instantiation of the GEMM (accumulators from 0, three-instruction residue).  This one draws k from 513 ... 8193 -- the
+    K-step-barrier kernels with the byte-dot-product reduction on biased accumulators (padded k <= 5120), the ping-pong kernels
+    beyond, the FP8 K-concatenation gate, the complex three-segment bound GEMMs -- on shapes cut down so that the oracle still
+    finishes in seconds (m n k N x GEMMs-per-modulus <= 2e9)."""
+    import gemmul8_amd as g
+    import gpu_util as gu
+    rng = np.random.default_rng(77000 + seed)
+    dtype = [np.float64, np.float32, np.complex128, np.complex64][seed % 4]
+    backend = g.FP8 if (seed // 4) % 3 == 2 else g.INT8
+    cplx = np.dtype(dtype).kind == "c"
+    is_f32 = dtype in (np.float32, np.complex64)
+    N = int(rng.integers(2, 14 if is_f32 else 21))
+    fast = bool(rng.integers(0, 2))
+    m, n = (int(rng.choice(DIMS_MN_LARGE_K)) for _ in range(2))
+    k = int(rng.choice(DIMS_K_LARGE))
+    if backend == g.FP8:
+        k = min(k, 5400)
+    weight = (3 if cplx else 1) * (3 if backend == g.FP8 else 1)
+    while m * n * k * N * weight > 2e9:       # shrink the larger side, keeping it off the tile boundary
+        if m >= n:
+            m = max(1, m // 2 + 1)
+        else:
+            n = max(1, n // 2 + 1)
+    nt_force = str(rng.choice(["", "0", "1"]))
+    if nt_force:
+        gu.setknob(monkeypatch, "GEMMUL8_EPI_NT", nt_force)
+    tile_force = str(rng.choice(["", "128", "256"]))
+    if tile_force:
+        gu.setknob(monkeypatch, "GEMMUL8_BOUND_TILE", tile_force)
+    opA = str(rng.choice(["N", "T", "C"] if cplx else ["N", "T"]))
+    opB = str(rng.choice(["N", "T", "C"] if cplx else ["N", "T"]))
+    phi = float(rng.choice([0.0, 1.0, 3.0]))
+    A = _rand((m, k) if opA == "N" else (k, m), dtype, rng, phi)
+    B = _rand((k, n) if opB == "N" else (n, k), dtype, rng, phi)
+    alpha, beta = [(1.0, 0.0), (1.0, 1.0), (-1.0, 0.0), (0.75, -0.5)][int(rng.integers(0, 4))]
+    C0 = _rand((m, n), dtype, rng, 0.0) if beta != 0 else None
+    gu.parity_case(A, B, N, fast, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0, backend=backend)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32, np.complex128])
 @pytest.mark.parametrize("fast", [False, True])
 def test_extreme_exponents_bit_exact(dtype, fast):
