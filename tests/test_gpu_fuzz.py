@@ -66,7 +66,7 @@ def test_random_case_bit_exact(seed, monkeypatch):
     gu.parity_case(A, B, N, fast, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0, backend=backend)
 
 
-N_SEEDS_LARGE_K = int(os.environ.get("GEMMUL8_FUZZ_LARGEK_SEEDS", "32"))
+N_SEEDS_LARGE_K = int(os.environ.get("GEMMUL8_FUZZ_LARGEK_SEEDS", "12"))
 DIMS_K_LARGE = [513, 640, 1023, 1024, 1300, 2049, 4097, 5120, 5121, 5400, 8193]
 DIMS_MN_LARGE_K = [1, 31, 129, 255, 256, 257, 300]
 
