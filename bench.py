@@ -545,6 +545,21 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
 
+    # the other mode alongside (report both; the headline above is the mode selected by --fast), timed HERE, on the device the
+    # headline left warm -- behind the host-side error checks below its first launches ran on a device back in its idle power state
+    # (6.7 / 6.2 / 5.7 ms for the same GEMM launch: profiles/r04b_config2_kernel_stats_note.txt) and the fast-mode line read 169 where the sweeps read 175
+    C_head = Cmat.clone()
+    other = not args.fast
+    for _ in range(2):
+        g.gemm(A, B, N, fastmode=other, C_out=Cmat, work=work)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        g.gemm(A, B, N, fastmode=other, C_out=Cmat, work=work)
+    torch.cuda.synchronize()
+    oms = (time.perf_counter() - t1) / 5 * 1e3
+    C_other = Cmat
+
     ms = dt / args.steps * 1e3
     value = flops / (ms * 1e-3) * 1e-12
     gemm_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in phase_events]))
@@ -597,22 +612,12 @@ def main():
              "ms": b_ms, "algorithmic_bytes": b_bytes, "lowprec_ops": flops})
     out["phase_ms"] = {"bounds": float(np.mean([e[4].elapsed_time(e[0]) for e in phase_events])) if not args.fast else 0.0,
                        "quantise": q_ms, "lowprec_gemm": gemm_ms, "crt": c_ms}
-    out["max_rel_err"] = sampled_error(A, B, Cmat, n)
+    out["max_rel_err"] = sampled_error(A, B, C_head, n)
     nat["max_rel_err"] = sampled_error(A, B, Cn, n)
-    del Cn
+    del Cn, C_head
     out["native_fp64_dgemm_same_gpu"] = nat
-    # the other mode alongside (report both; the headline above is the mode selected by --fast)
-    other = not args.fast
-    for _ in range(2):
-        g.gemm(A, B, N, fastmode=other, C_out=Cmat, work=work)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(5):
-        g.gemm(A, B, N, fastmode=other, C_out=Cmat, work=work)
-    torch.cuda.synchronize()
-    oms = (time.perf_counter() - t1) / 5 * 1e3
     out["other_mode"] = {"mode": "fast" if other else "accurate", "value": flops / oms * 1e-9, "unit": "TFLOPS", "ms_per_step": oms,
-                         "max_rel_err": sampled_error(A, B, Cmat, n)}
+                         "max_rel_err": sampled_error(A, B, C_other, n)}
     if not args.no_cpu:
         # The CPU legs take ~14 s of host time (oracle port on one core, OpenBLAS on 128 threads).  They run on a helper thread (both are
         # foreign calls that release the GIL) while THIS thread keeps issuing the emulated GEMM: the device is busy for the whole life of the
