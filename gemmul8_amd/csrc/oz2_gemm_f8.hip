@@ -527,10 +527,17 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) af[i] = frag(curA + (ah * 4 + i) * 16 * BK);
-                    if (ah == 1 && !ISB) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // As in oz2_gemm_i8.hip: only the K-step's LAST load segment completes its LDS reads (and, on the A waves, the DMA the next K-step
+                    // needs) before the barrier -- the one the ring's hazards count on; the first segment arrives at the barrier with its reads issued
+                    // and waits behind it (config 3 whole call +1.25 %, SGEMM 8192^2 x 2048 / 8192 +1.2 / +0.7 %: profiles/r04e_f8_late_wait_ab.txt)
+                    if (ah == 1) {
+                        if (!ISB) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ah == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_setprio(1);
                     // serpentine order over the 4 x 4 fragment pairs, as in oz2_gemm_i8.hip (consecutive MFMAs share an operand register across the row change)

@@ -332,9 +332,15 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         af[i] = *(const v4i*)(curA + (ah * 4 + i) * 16 * BK + coff);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // Only the K-step's LAST load segment completes its reads BEFORE the barrier: that is the barrier the ring's WAR rule counts on
+                    // (LDS operations of a wave complete in order, so its wait covers every read of the K-step).  The other three segments arrive at
+                    // the barrier as soon as their reads are ISSUED and wait behind it: a wave's LDS latency no longer delays the hand-over of all
+                    // twelve (+0.4 / +0.5 % at k = 6144 / 8192, planes bit-identical: profiles/r04e_late_wait_ab.txt)
+                    if (ks2 == 1 && ah == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(ks2 == 1 && ah == 1)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_setprio(1);
                     // serpentine order over the 4 x 4 fragment pairs: consecutive MFMAs share an operand register also across the row change
