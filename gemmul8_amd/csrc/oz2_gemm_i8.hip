@@ -218,17 +218,23 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = v4i{EPI == EPI_MAX ? 0 : args.acc0, EPI == EPI_MAX ? 0 : args.acc0, EPI == EPI_MAX ? 0 : args.acc0, EPI == EPI_MAX ? 0 : args.acc0};
+// The fragment reads of a segment are issued in the order the MFMAs use them (pinned: the scheduler otherwise issues the first-used fragment last) and the
+// waits in front of the MFMAs are the compiler's own per-fragment lgkmcnt(3..0): the first four MFMAs of a segment start when THEIR fragment has landed.  No
+// barrier covers the read latency in this schedule (in the ping-pong schedule one does: there the same change is neutral).  8192^2 x 14 planes, interleaved,
+// 25 rounds: k = 256 / 512 / 1024: +0.4 / +0.8 / +1.5 %, neutral from 2048 (profiles/r04f_kbar_partial_wait_ab.txt)
+#define OZ2_KBAR_PIN() __builtin_amdgcn_sched_barrier(0)
+#define OZ2_KBAR_WAIT() do {} while (0)
 #define OZ2_LOAD_SEG(seg_)                                                                                                   \
     do {                                                                                                                     \
         const int coff_ = (((((seg_) >> 1) << 2) | q) ^ sw) << 4;                                                            \
         if (((seg_) & 1) == 0) {                                                                                             \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) bf[j] = *(const v4i*)(curB + j * 16 * BK + coff_);                 \
         }                                                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) af[i] = *(const v4i*)(curA + (((seg_) & 1) * 4 + i) * 16 * BK + coff_); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) { af[i] = *(const v4i*)(curA + (((seg_) & 1) * 4 + i) * 16 * BK + coff_); OZ2_KBAR_PIN(); } \
     } while (0)
 #define OZ2_MMA_SEG(seg_)                                                                                                    \
     do {                                                                                                                     \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                   \
+        OZ2_KBAR_WAIT();                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
         __builtin_amdgcn_s_setprio(1);                                                                                       \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                     \
@@ -271,6 +277,8 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #undef OZ2_SET_PANELS
 #undef OZ2_LOAD_SEG
 #undef OZ2_MMA_SEG
+#undef OZ2_KBAR_PIN
+#undef OZ2_KBAR_WAIT
 #if OZ2_HOOK_SKIP_EPILOGUE
             (void)tmap;  // laboratory probe: no epilogue; the accumulators stay live
 #pragma unroll
