@@ -157,12 +157,13 @@ bool recv_all(int fd, void* p, size_t n) {
     return true;
 }
 
-// Rank 0 listens on all interfaces (as torch's TCPStore does: MASTER_ADDR may be a service / NAT address the host does not own, or
-// resolve to 127.0.1.1 on rank 0 itself; if that bind fails it falls back to the address MASTER_ADDR resolves to).  Every client
-// introduces itself with a 16-byte hello {magic, rank, world, nonce = MASTER_PORT} before it is handed the id, which filters stray
-// connections (port scanner, another job's retry); a rank that asks again is served again (handing out the id is idempotent: its
-// first reply may have been lost to its 5 s receive timeout), and every accept / recv has a deadline: a missing rank ends in an
-// error message after GEMMUL8_DIST_TIMEOUT seconds (default 120) instead of a silent hang inside ncclCommInitRank.
+// Rank 0 listens on the address MASTER_ADDR resolves to; only if that bind fails (MASTER_ADDR is a service / NAT address the host does
+// not own, or resolves to 127.0.1.1 on rank 0 itself) does it fall back to all interfaces, as torch's TCPStore does.  Every client
+// introduces itself with a 16-byte hello {magic, rank, world, nonce} before it is handed the id; the nonce is MASTER_PORT mixed with
+// GEMMUL8_DIST_SECRET (a job secret the launcher may export to every rank: without it any host that reaches the port and guesses the
+// world size could obtain the communicator id).  A rank is served once; a rank that asks AGAIN (its first reply may have been lost to its
+// 5 s receive timeout) is served one more time, no more.  Every accept / recv has a deadline: a missing rank ends in an error message
+// after GEMMUL8_DIST_TIMEOUT seconds (default 120) instead of a silent hang inside ncclCommInitRank.
 struct IdHello {
     uint32_t magic, rank, world, nonce;
 };
@@ -199,8 +200,8 @@ int exchange_id_tcp(const char* addr, int port, int rank, int world, uint32_t no
         any.sin_family = AF_INET;
         any.sin_addr.s_addr = htonl(INADDR_ANY);
         any.sin_port = htons((uint16_t)port);
-        const bool bound = ls >= 0 && (::bind(ls, reinterpret_cast<const sockaddr*>(&any), sizeof any) == 0 ||
-                                       ::bind(ls, res->ai_addr, res->ai_addrlen) == 0);
+        const bool bound = ls >= 0 && (::bind(ls, res->ai_addr, res->ai_addrlen) == 0 ||
+                                       ::bind(ls, reinterpret_cast<const sockaddr*>(&any), sizeof any) == 0);
         if (!bound || ::listen(ls, world) != 0) {
             std::fprintf(stderr, "[GEMMUL8 DIST] cannot listen on %s:%d\n", addr, port);
             if (ls >= 0) ::close(ls);
@@ -220,9 +221,8 @@ int exchange_id_tcp(const char* addr, int port, int rank, int world, uint32_t no
             set_io_timeout(fd, 5);
             IdHello h{};
             if (recv_all(fd, &h, sizeof h) && h.magic == kHelloMagic && h.world == (uint32_t)world && h.nonce == nonce && h.rank >= 1 &&
-                h.rank < (uint32_t)world && send_all(fd, id, sizeof *id) && !served[h.rank]) {
-                served[h.rank] = 1;
-                --left;
+                h.rank < (uint32_t)world && served[h.rank] < 2 && send_all(fd, id, sizeof *id)) {
+                if (served[h.rank]++ == 0) --left;
             }
             ::close(fd);
         }
@@ -388,7 +388,10 @@ int gemmul8_comm_rccl_id_from_env(void* id128, int* rank_out, int* world_out) {
             port = (mp0 ? std::atoi(mp0) : 29500) + 17;
         }
         const char* mp = std::getenv("MASTER_PORT");
-        OZ2_RC(exchange_id_tcp(addr ? addr : "127.0.0.1", port, rank, world, (uint32_t)(mp ? std::atoi(mp) : 29500), &id));
+        uint32_t nonce = (uint32_t)(mp ? std::atoi(mp) : 29500);
+        if (const char* sec = std::getenv("GEMMUL8_DIST_SECRET"))  // FNV-1a of the job secret, folded into the hello's nonce
+            for (uint32_t h = 2166136261u; *sec; ++sec) nonce ^= (h = (h ^ (unsigned char)*sec) * 16777619u);
+        OZ2_RC(exchange_id_tcp(addr ? addr : "127.0.0.1", port, rank, world, nonce, &id));
     }
     std::memcpy(id128, &id, sizeof id);
     if (rank_out) *rank_out = rank;

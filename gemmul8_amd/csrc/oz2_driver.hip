@@ -313,8 +313,10 @@ int gemmul8_scale(void* stream_, int dtype, int backend, int op_A, int op_B, siz
 int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t n, size_t k, unsigned N, unsigned t_begin,
                          unsigned t_end, const gemmul8_layout* L) {
     hipStream_t stream = (hipStream_t)stream_;
-    (void)k;
     if (!L) return GEMMUL8_E_ARG;
+    // the layout carries the padded inner dimension the planes were built with: a k that does not pad to it is a caller error (the FP8
+    // K-concatenation below is exact only while 2 k 16^2 <= 2^24, so a placeholder k must not pass)
+    if (padding256(k) != L->kp) return GEMMUL8_E_ARG;
     if (!moduli_ok(dtype, N) || t_end > N || t_begin > t_end) return GEMMUL8_E_NUM_MODULI;
     const int8_t* A_lo = (const int8_t*)L->A_lo;
     const int8_t* B_lo = (const int8_t*)L->B_lo;

@@ -425,6 +425,16 @@ bool try_dist(int kind, int dtype, int backend, hipblasOperation_t ta, hipblasOp
 // the INT8 one.
 // GEMMUL8_MIN_FLOPS unset / 0 = the reference's behaviour (emulate every call); any other number is a plain floor on 2*m*n*k per call.
 // GEMMUL8_HOOK_STATS=1: how much of an application's GEMM work the hook reaches (tests/test_gpu_hook_reach.py)
+// A call handed to the native routine comes back through the interposed layers below it (hipblasDgemm -> rocblas_dgemm ->
+// rocblas_internal_gemm_template with GEMMUL8_HOOK_ROCBLAS=1): it is the SAME call, already declined by the same rules.  Every
+// pass-through runs inside a NativeScope; a hooked entry reached inside one goes straight to its real routine, uncounted.
+thread_local int tl_native_depth = 0;
+struct NativeScope {
+    NativeScope() { ++tl_native_depth; }
+    ~NativeScope() { --tl_native_depth; }
+    NativeScope(const NativeScope&) = delete;
+    NativeScope& operator=(const NativeScope&) = delete;
+};
 struct HookStats {
     std::atomic<unsigned long long> emu_calls{0}, nat_calls{0};
     std::atomic<unsigned long long> emu_mflops{0}, nat_mflops{0};  // 2 m n k batch / 1e6 (x 4 for complex), rounded down
@@ -588,6 +598,7 @@ bool try_emulate_impl(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, 
 bool try_emulate(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, hipblasOperation_t tb, int m, int n, int k, const void* alpha,
                  const void* A, int lda, const void* B, int ldb, const void* beta, void* C, int ldc, hipblasStatus_t* status,
                  const hipStream_t* explicit_stream = nullptr) {
+    if (tl_native_depth > 0) return false;  // inside a native pass-through of an outer hooked entry: the same call, already declined and counted
     const bool served = try_emulate_impl(dtype, handle, ta, tb, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, status, explicit_stream);
     count_call(served, dtype, m, n, k);
     return served;
@@ -648,7 +659,7 @@ hipblasStatus_t hipblasDestroy(hipblasHandle_t handle) {
     release_state(handle);
     using Fn = hipblasStatus_t (*)(hipblasHandle_t);
     static Fn real = real_fn<Fn>("hipblasDestroy");
-    return real ? real(handle) : HIPBLAS_STATUS_NOT_INITIALIZED;
+    NativeScope ns_; return real ? real(handle) : HIPBLAS_STATUS_NOT_INITIALIZED;
 }
 
 #define OZ2_GEMM_HOOK(NAME, T, CODE)                                                                                                   \
@@ -660,7 +671,7 @@ hipblasStatus_t hipblasDestroy(hipblasHandle_t handle) {
         using Fn = hipblasStatus_t (*)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int, const T*, const T*, int, \
                                        const T*, int, const T*, T*, int);                                                               \
         static Fn real = real_fn<Fn>(#NAME);                                                                                            \
-        return real ? real(handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc) : HIPBLAS_STATUS_NOT_INITIALIZED;      \
+        NativeScope ns_; return real ? real(handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc) : HIPBLAS_STATUS_NOT_INITIALIZED;      \
     }
 OZ2_GEMM_HOOK(hipblasSgemm, float, GEMMUL8_S)
 OZ2_GEMM_HOOK(hipblasDgemm, double, GEMMUL8_D)
@@ -685,7 +696,7 @@ hipblasStatus_t hipblasGemmEx(hipblasHandle_t handle, hipblasOperation_t transA,
                                    hipDataType, int, const void*, hipDataType, int, const void*, void*, hipDataType, int,
                                    hipblasComputeType_t, hipblasGemmAlgo_t);
     static Fn real = real_fn<Fn>("hipblasGemmEx");
-    return real ? real(handle, transA, transB, m, n, k, alpha, A, aType, lda, B, bType, ldb, beta, C, cType, ldc, computeType, algo)
+    NativeScope ns_; return real ? real(handle, transA, transB, m, n, k, alpha, A, aType, lda, B, bType, ldb, beta, C, cType, ldc, computeType, algo)
                 : HIPBLAS_STATUS_NOT_INITIALIZED;
 }
 
@@ -706,7 +717,7 @@ static inline bool fits_int(int64_t a, int64_t b, int64_t c, int64_t d, int64_t 
         using Fn = hipblasStatus_t (*)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int64_t, int64_t, int64_t, const T*,      \
                                        const T*, int64_t, const T*, int64_t, const T*, T*, int64_t);                                      \
         static Fn real = real_fn<Fn>(#NAME);                                                                                              \
-        return real ? real(handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc) : HIPBLAS_STATUS_NOT_INITIALIZED;        \
+        NativeScope ns_; return real ? real(handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc) : HIPBLAS_STATUS_NOT_INITIALIZED;        \
     }
 OZ2_GEMM_HOOK_64(hipblasSgemm_64, float, GEMMUL8_S)
 OZ2_GEMM_HOOK_64(hipblasDgemm_64, double, GEMMUL8_D)
@@ -735,7 +746,7 @@ hipblasStatus_t hipblasGemmExWithFlags(hipblasHandle_t handle, hipblasOperation_
                                    hipDataType, int, const void*, hipDataType, int, const void*, void*, hipDataType, int,
                                    hipblasComputeType_t, hipblasGemmAlgo_t, hipblasGemmFlags_t);
     static Fn real = real_fn<Fn>("hipblasGemmExWithFlags");
-    return real ? real(handle, transA, transB, m, n, k, alpha, A, aType, lda, B, bType, ldb, beta, C, cType, ldc, computeType, algo, flags)
+    NativeScope ns_; return real ? real(handle, transA, transB, m, n, k, alpha, A, aType, lda, B, bType, ldb, beta, C, cType, ldc, computeType, algo, flags)
                 : HIPBLAS_STATUS_NOT_INITIALIZED;
 }
 
@@ -753,7 +764,7 @@ hipblasStatus_t hipblasGemmEx_64(hipblasHandle_t handle, hipblasOperation_t tran
                                    const void*, hipDataType, int64_t, const void*, hipDataType, int64_t, const void*, void*, hipDataType,
                                    int64_t, hipblasComputeType_t, hipblasGemmAlgo_t);
     static Fn real = real_fn<Fn>("hipblasGemmEx_64");
-    return real ? real(handle, transA, transB, m, n, k, alpha, A, aType, lda, B, bType, ldb, beta, C, cType, ldc, computeType, algo)
+    NativeScope ns_; return real ? real(handle, transA, transB, m, n, k, alpha, A, aType, lda, B, bType, ldb, beta, C, cType, ldc, computeType, algo)
                 : HIPBLAS_STATUS_NOT_INITIALIZED;
 }
 
@@ -771,7 +782,7 @@ hipblasStatus_t hipblasGemmExWithFlags_64(hipblasHandle_t handle, hipblasOperati
                                    const void*, hipDataType, int64_t, const void*, hipDataType, int64_t, const void*, void*, hipDataType,
                                    int64_t, hipblasComputeType_t, hipblasGemmAlgo_t, hipblasGemmFlags_t);
     static Fn real = real_fn<Fn>("hipblasGemmExWithFlags_64");
-    return real ? real(handle, transA, transB, m, n, k, alpha, A, aType, lda, B, bType, ldb, beta, C, cType, ldc, computeType, algo, flags)
+    NativeScope ns_; return real ? real(handle, transA, transB, m, n, k, alpha, A, aType, lda, B, bType, ldb, beta, C, cType, ldc, computeType, algo, flags)
                 : HIPBLAS_STATUS_NOT_INITIALIZED;
 }
 
@@ -786,6 +797,7 @@ static bool emulate_batch(int dtype, size_t elem, hipblasHandle_t handle, hipbla
                           const void* alpha, const void* A, int lda, long long sa, const void* B, int ldb, long long sb, const void* beta,
                           void* C, int ldc, long long sc, int batch, hipblasStatus_t* status, const hipStream_t* explicit_stream = nullptr) {
     *status = HIPBLAS_STATUS_SUCCESS;
+    if (tl_native_depth > 0) return false;  // see try_emulate
     // First choice (INT8 backend, GEMMUL8_BATCH_FUSED != 0): the whole batch as ONE set of launches (gemmul8_gemm_batched: the items in
     // gridDim.z of every kernel) -- a batch of small matrices then fills the chip and costs ten launches, not ten per item.
     if (batch > 1 && env_u64("GEMMUL8_BATCH_FUSED", 1) != 0 && dist_kind_from_env() < 0) {
@@ -902,7 +914,7 @@ static bool emulate_batch(int dtype, size_t elem, hipblasHandle_t handle, hipbla
         using Fn = hipblasStatus_t (*)(hipblasHandle_t, hipblasOperation_t, hipblasOperation_t, int, int, int, const T*, const T*, int,   \
                                        long long, const T*, int, long long, const T*, T*, int, long long, int);                          \
         static Fn real = real_fn<Fn>(#NAME);                                                                                              \
-        return real ? real(handle, transA, transB, m, n, k, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batchCount)   \
+        NativeScope ns_; return real ? real(handle, transA, transB, m, n, k, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batchCount)   \
                     : HIPBLAS_STATUS_NOT_INITIALIZED;                                                                                     \
     }
 OZ2_SB_HOOK(hipblasSgemmStridedBatched, float, GEMMUL8_S)
@@ -932,7 +944,7 @@ hipblasStatus_t hipblasGemmStridedBatchedEx(hipblasHandle_t handle, hipblasOpera
                                    hipDataType, int, hipblasStride, const void*, hipDataType, int, hipblasStride, const void*, void*,
                                    hipDataType, int, hipblasStride, int, hipblasComputeType_t, hipblasGemmAlgo_t);
     static Fn real = real_fn<Fn>("hipblasGemmStridedBatchedEx");
-    return real ? real(handle, transA, transB, m, n, k, alpha, A, aType, lda, strideA, B, bType, ldb, strideB, beta, C, cType, ldc, strideC,
+    NativeScope ns_; return real ? real(handle, transA, transB, m, n, k, alpha, A, aType, lda, strideA, B, bType, ldb, strideB, beta, C, cType, ldc, strideC,
                        batchCount, computeType, algo)
                 : HIPBLAS_STATUS_NOT_INITIALIZED;
 }
@@ -963,7 +975,40 @@ bool rocblas_stream(void* handle, hipStream_t* s) {
     return fn && fn(handle, s) == 0;
 }
 int rocblas_status_of(hipblasStatus_t st) { return st == HIPBLAS_STATUS_SUCCESS ? 0 : st == HIPBLAS_STATUS_ALLOC_FAILED ? 5 : 6; }
+
+// rocblas_internal_gemm_template is an INTERNAL, unversioned C++ symbol: the mangled name pins the parameter TYPES but not their meaning
+// (offsets in elements, strides, the batch count), and a ROCm point release may change those without changing the name -- silent argument
+// corruption instead of a clean pass-through.  The interposition is therefore limited to the rocBLAS releases it was run against
+// (tests/test_gpu_hook_reach.py on PyTorch's bundled 5.0.x, tests/cpp/test_hook_rocblas.cpp on ROCm 7.2's 5.2.x); any other version string
+// -- or a rocBLAS without rocblas_get_version_string -- takes the pass-through, with one log line.  GEMMUL8_ROCBLAS_ABI_UNCHECKED=1 overrides.
+constexpr const char* kTestedRocblas[] = {"5.0.", "5.2."};
+bool rocblas_version_tested(const char* v) {
+    if (!v) return false;
+    for (const char* pre : kTestedRocblas)
+        if (std::strncmp(v, pre, std::strlen(pre)) == 0) return true;
+    return false;
+}
+bool rocblas_internal_abi_ok() {
+    static const bool ok = [] {
+        if (env_one("GEMMUL8_ROCBLAS_ABI_UNCHECKED")) return true;
+        using SizeFn = int (*)(size_t*);
+        using StrFn = int (*)(char*, size_t);
+        SizeFn fsz = real_rocblas<SizeFn>("rocblas_get_version_string_size");
+        StrFn fstr = real_rocblas<StrFn>("rocblas_get_version_string");
+        char buf[128] = "";
+        size_t len = 0;
+        const bool have = fsz && fstr && fsz(&len) == 0 && len > 0 && len <= sizeof(buf) && fstr(buf, len) == 0;
+        const bool good = have && rocblas_version_tested(buf);
+        if (!good && env_one("GEMMUL8_HOOK_ROCBLAS"))
+            std::fprintf(stderr, "[GEMMUL8 HOOK] rocBLAS version '%s' is not one this build was tested with (5.0.x, 5.2.x): rocblas_internal_gemm_template "
+                                 "(rocSOLVER's trailing updates) is NOT intercepted; the exported rocblas_*gemm entry points still are "
+                                 "(GEMMUL8_ROCBLAS_ABI_UNCHECKED=1 overrides)\n", have ? buf : "unknown");
+        return good;
+    }();
+    return ok;
+}
 }  // namespace
+extern "C" GEMMUL8_API int gemmul8_hook_rocblas_version_tested(const char* version) { return rocblas_version_tested(version) ? 1 : 0; }
 #pragma GCC visibility push(default)
 extern "C" {
 
@@ -971,7 +1016,7 @@ int rocblas_destroy_handle(void* handle) {
     if (handle) release_state((hipblasHandle_t)handle, true);
     using Fn = int (*)(void*);
     static Fn real = real_rocblas<Fn>("rocblas_destroy_handle");
-    return real ? real(handle) : 6;
+    NativeScope ns_; return real ? real(handle) : 6;
 }
 
 #define OZ2_ROCBLAS_GEMM_HOOK(NAME, T, CODE)                                                                                             \
@@ -986,7 +1031,7 @@ int rocblas_destroy_handle(void* handle) {
             try_emulate(CODE, (hipblasHandle_t)handle, (hipblasOperation_t)transA, (hipblasOperation_t)transB, m, n, k, alpha, A, lda, B, \
                         ldb, beta, C, ldc, &st_, &s_))                                                                                   \
             return rocblas_status_of(st_);                                                                                               \
-        return real ? real(handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc) : 6;                                    \
+        NativeScope ns_; return real ? real(handle, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc) : 6;                                    \
     }
 OZ2_ROCBLAS_GEMM_HOOK(rocblas_sgemm, float, GEMMUL8_S)
 OZ2_ROCBLAS_GEMM_HOOK(rocblas_dgemm, double, GEMMUL8_D)
@@ -1007,7 +1052,7 @@ OZ2_ROCBLAS_GEMM_HOOK(rocblas_zgemm, hipDoubleComplex, GEMMUL8_Z)
             emulate_batch(CODE, sizeof(T), (hipblasHandle_t)handle, (hipblasOperation_t)transA, (hipblasOperation_t)transB, m, n, k,     \
                           alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batchCount, &st_, &s_))                        \
             return rocblas_status_of(st_);                                                                                               \
-        return real ? real(handle, transA, transB, m, n, k, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batchCount) : 6; \
+        NativeScope ns_; return real ? real(handle, transA, transB, m, n, k, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batchCount) : 6; \
     }
 OZ2_ROCBLAS_SB_HOOK(rocblas_sgemm_strided_batched, float, GEMMUL8_S)
 OZ2_ROCBLAS_SB_HOOK(rocblas_dgemm_strided_batched, double, GEMMUL8_D)
@@ -1031,8 +1076,8 @@ static int rocblas_internal_gemm_hook(const char* mangled, int code, void* handl
     hipblasStatus_t st_;
     const bool fits = m > 0 && n > 0 && k > 0 && batch > 0 && (long long)m <= 2147483647 && (long long)n <= 2147483647 && (long long)k <= 2147483647 &&
                       (long long)lda <= 2147483647 && (long long)ldb <= 2147483647 && (long long)ldc <= 2147483647 && (long long)batch <= 2147483647;
-    if (fits && env_one("GEMMUL8_HOOK_ROCBLAS") && handle && alpha && A && B && beta && C && transA >= 111 && transA <= 113 && transB >= 111 &&
-        transB <= 113 && rocblas_stream(handle, &s_)) {
+    if (fits && env_one("GEMMUL8_HOOK_ROCBLAS") && rocblas_internal_abi_ok() && handle && alpha && A && B && beta && C && transA >= 111 && transA <= 113 &&
+        transB >= 111 && transB <= 113 && rocblas_stream(handle, &s_)) {
         const T *Ao = A + offA, *Bo = B + offB;
         T* Co = C + offC;
         const bool served = batch == 1 ? try_emulate(code, (hipblasHandle_t)handle, (hipblasOperation_t)transA, (hipblasOperation_t)transB, (int)m, (int)n,
@@ -1042,7 +1087,7 @@ static int rocblas_internal_gemm_hook(const char* mangled, int code, void* handl
                                                        strideC, (int)batch, &st_, &s_);
         if (served) return rocblas_status_of(st_);
     }
-    return real ? real(handle, transA, transB, m, n, k, alpha, A, offA, lda, strideA, B, offB, ldb, strideB, beta, C, offC, ldc, strideC, batch) : 6;
+    NativeScope ns_; return real ? real(handle, transA, transB, m, n, k, alpha, A, offA, lda, strideA, B, offB, ldb, strideB, beta, C, offC, ldc, strideC, batch) : 6;
 }
 extern "C" {
 #define OZ2_ROCBLAS_INTERNAL(FN, T, CODE, SYM32, SYM64)                                                                                   \
@@ -1089,7 +1134,7 @@ int rocblas_gemm_ex(void* handle, int transA, int transB, int m, int n, int k, c
         try_emulate(dtype, (hipblasHandle_t)handle, (hipblasOperation_t)transA, (hipblasOperation_t)transB, m, n, k, alpha, a, lda, b, ldb, beta,
                     d, ldd, &st_, &s_))
         return rocblas_status_of(st_);
-    return real ? real(handle, transA, transB, m, n, k, alpha, a, a_type, lda, b, b_type, ldb, beta, c, c_type, ldc, d, d_type, ldd, compute_type,
+    NativeScope ns_; return real ? real(handle, transA, transB, m, n, k, alpha, a, a_type, lda, b, b_type, ldb, beta, c, c_type, ldc, d, d_type, ldd, compute_type,
                        algo, solution_index, flags)
                 : 6;
 }
@@ -1272,7 +1317,7 @@ extern "C" hipblasStatus_t hipblasLtMatrixLayoutDestroy(const hipblasLtMatrixLay
     }
     using Fn = hipblasStatus_t (*)(const hipblasLtMatrixLayout_t);
     static Fn real = real_fn<Fn>("hipblasLtMatrixLayoutDestroy");
-    return real ? real(matLayout) : HIPBLAS_STATUS_NOT_INITIALIZED;
+    NativeScope ns_; return real ? real(matLayout) : HIPBLAS_STATUS_NOT_INITIALIZED;
 }
 
 // the per-handle state of an hipblasLt handle is released with the handle, as for hipblasDestroy
@@ -1280,7 +1325,7 @@ extern "C" hipblasStatus_t hipblasLtDestroy(const hipblasLtHandle_t handle) {
     release_state((hipblasHandle_t)handle, true);
     using Fn = hipblasStatus_t (*)(const hipblasLtHandle_t);
     static Fn real = real_fn<Fn>("hipblasLtDestroy");
-    return real ? real(handle) : HIPBLAS_STATUS_NOT_INITIALIZED;
+    NativeScope ns_; return real ? real(handle) : HIPBLAS_STATUS_NOT_INITIALIZED;
 }
 
 extern "C" hipblasStatus_t hipblasLtMatmul(hipblasLtHandle_t handle, hipblasLtMatmulDesc_t matmulDesc, const void* alpha, const void* A,
@@ -1293,7 +1338,7 @@ extern "C" hipblasStatus_t hipblasLtMatmul(hipblasLtHandle_t handle, hipblasLtMa
                                    hipblasLtMatrixLayout_t, const void*, const void*, hipblasLtMatrixLayout_t, void*, hipblasLtMatrixLayout_t,
                                    const hipblasLtMatmulAlgo_t*, void*, size_t, hipStream_t);
     static Fn real = real_fn<Fn>("hipblasLtMatmul");
-    return real ? real(handle, matmulDesc, alpha, A, Adesc, B, Bdesc, beta, C, Cdesc, D, Ddesc, algo, workspace, workspaceSizeInBytes, stream)
+    NativeScope ns_; return real ? real(handle, matmulDesc, alpha, A, Adesc, B, Bdesc, beta, C, Cdesc, D, Ddesc, algo, workspace, workspaceSizeInBytes, stream)
                 : HIPBLAS_STATUS_NOT_INITIALIZED;
 }
 #pragma GCC visibility pop

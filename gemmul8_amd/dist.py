@@ -341,11 +341,14 @@ def selftest(comm, device, stream=None, expect_rccl=True):
     st = stream if stream is not None else (torch.cuda.current_stream(device).cuda_stream if on_gpu else None)
     sync = (lambda: torch.cuda.synchronize(device)) if on_gpu else (lambda: None)   # host buffers: the CPU test transport completes before returning
     c = comm.ptr.contents
+    # The three operations are collectives: a rank that returned after a failed check would leave the others blocked in the next one
+    # (and bench.py's agreement step would never be reached).  Every rank therefore runs ALL of them and reports the first failure.
+    fails = []
     try:
         if expect_rccl:
             cnt = comm.rccl_ranks()
             if cnt != world:
-                return False, f"rank {rank}: ncclCommCount says {cnt}, the launcher says WORLD_SIZE = {world} (a rank joined another communicator: check MASTER_PORT / the id hand-off)"
+                fails.append(f"rank {rank}: ncclCommCount says {cnt}, the launcher says WORLD_SIZE = {world} (a rank joined another communicator: check MASTER_PORT / the id hand-off)")
         # all-reduce(MAX), int32, odd length
         cnt = 1027
         i = np.arange(cnt, dtype=np.int64)
@@ -355,7 +358,7 @@ def selftest(comm, device, stream=None, expect_rccl=True):
         rc = c.allreduce_max_i32(c.ctx, buf.data_ptr(), cnt, st)
         sync()
         if rc != 0 or not np.array_equal(buf.cpu().numpy(), want):
-            return False, f"rank {rank}: all-reduce(MAX, int32, {cnt}) rc = {rc}, {int((buf.cpu().numpy() != want).sum())} wrong entries"
+            fails.append(f"rank {rank}: all-reduce(MAX, int32, {cnt}) rc = {rc}, {int((buf.cpu().numpy() != want).sum())} wrong entries")
         if world > 1:
             # grouped send / recv ring: to rank + 1, from rank - 1
             nb = 4096 + 8
@@ -367,7 +370,7 @@ def selftest(comm, device, stream=None, expect_rccl=True):
             sync()
             wantb = ((np.arange(nb) * 3 + prv * 17) % 251).astype(np.uint8)
             if rc != 0 or not np.array_equal(inn.cpu().numpy(), wantb):
-                return False, f"rank {rank}: grouped send/recv ring ({nb} B to {nxt}, from {prv}) rc = {rc}, {int((inn.cpu().numpy() != wantb).sum())} wrong bytes"
+                fails.append(f"rank {rank}: grouped send/recv ring ({nb} B to {nxt}, from {prv}) rc = {rc}, {int((inn.cpu().numpy() != wantb).sum())} wrong bytes")
         # reduce-scatter(sum), FP64: exact in double (small dyadic values)
         rcnt = 515
         w = np.arange(world, dtype=np.float64)[:, None]
@@ -378,9 +381,11 @@ def selftest(comm, device, stream=None, expect_rccl=True):
         sync()
         wantd = world * (world - 1) / 2.0 + world * (rank * 0.5 + np.arange(rcnt) * 0.25)
         if rc != 0 or not np.array_equal(recv.cpu().numpy(), wantd):
-            return False, f"rank {rank}: reduce-scatter(sum, FP64, {rcnt} per rank) rc = {rc}, max abs deviation {float(np.abs(recv.cpu().numpy() - wantd).max())}"
+            fails.append(f"rank {rank}: reduce-scatter(sum, FP64, {rcnt} per rank) rc = {rc}, max abs deviation {float(np.abs(recv.cpu().numpy() - wantd).max())}")
     except Exception as e:  # a transport that throws is a failed self-test, with the reason
         return False, f"rank {rank}: transport self-test raised {type(e).__name__}: {e}"
+    if fails:
+        return False, "; ".join(fails)
     return True, "ok"
 
 

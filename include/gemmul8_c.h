@@ -104,7 +104,8 @@ GEMMUL8_API int gemmul8_scale_finish(void *stream, int dtype, int backend, int o
 
 /* Low-precision GEMMs of moduli [t_begin, t_end) with the requantise epilogue: fills C_mid planes.
  * Replaces gemm_low_prec_* + conv_hi2mid (src/matmult.hpp:120-389, src/conv_hi2mid_real.hpp,
- * src/conv_hi2mid_complex.hpp; loop at src/gemmul8_real.hpp:144-191). */
+ * src/conv_hi2mid_complex.hpp; loop at src/gemmul8_real.hpp:144-191).  k is the inner dimension the layout was made for: a k whose
+ * padding differs from L->kp is GEMMUL8_E_ARG (the FP8 backend chooses its exact-accumulation form from it). */
 GEMMUL8_API int gemmul8_lowprec_gemm(void *stream, int dtype, int backend, size_t m, size_t n, size_t k, unsigned num_moduli,
                          unsigned t_begin, unsigned t_end, const gemmul8_layout *L);
 
@@ -157,13 +158,18 @@ GEMMUL8_API int gemmul8_crt_finish(void *stream, int dtype, int backend, unsigne
  * Process-wide; returns the previous mode (>= 0) or GEMMUL8_E_ARG.  The hook sets mode 1 when GEMMUL8_FP8_BOUND=reference. */
 GEMMUL8_API int gemmul8_set_fp8_bound_mode(int mode);
 
-/* The hook's automatic floor (GEMMUL8_MIN_FLOPS unset; oz2_hook.cpp below_floor): 1 if a hooked GEMM of this shape is emulated,
- * 0 if the hook hands it to the native routine because the fitted cost model (tools/fit_floor.py, profiles/sweeps/r03_floor_scan_*.csv)
- * predicts the emulation to lose; GEMMUL8_E_ARG on bad arguments.  With GEMMUL8_MIN_FLOPS set, that floor is applied instead
- * (0 = emulate everything, the reference's behaviour).  batch = items of a strided batch (1 for a plain call).  No counterpart in
- * the reference, whose hook emulates every call. */
+/* What the hook does with a GEMM of this shape under the CURRENT value of GEMMUL8_MIN_FLOPS (oz2_hook.cpp below_floor): 1 = emulated,
+ * 0 = handed to the native routine, GEMMUL8_E_ARG on bad arguments.  GEMMUL8_MIN_FLOPS unset, empty or 0: every selected call is emulated
+ * (the reference's behaviour: its hook has no floor) -- always 1; "auto": the fitted cost model (tools/fit_floor.py,
+ * profiles/sweeps/r04b_floor_scan_*.csv) decides per shape; a number: a plain floor on 2 m n k.  batch = items of a strided batch (1 for a
+ * plain call).  No counterpart in the reference. */
 GEMMUL8_API int gemmul8_hook_would_emulate(int dtype, int backend, size_t m, size_t n, size_t k, unsigned num_moduli, int fastmode,
                                            size_t batch);
+
+/* 1 if `version` (a rocblas_get_version_string result) is a rocBLAS release the opt-in interposition of rocblas_internal_gemm_template
+ * (GEMMUL8_HOOK_ROCBLAS=1; an internal, unversioned rocBLAS symbol) was tested with, else 0: with any other rocBLAS that symbol is passed
+ * through untouched.  No counterpart in the reference (it hooks the hipBLAS names only). */
+GEMMUL8_API int gemmul8_hook_rocblas_version_tested(const char *version);
 
 /* Testing / A-B knobs (GEMMUL8_EPI_NT, _BOUND_TILE, _CPLX_BOUND_LAUNCHES, _CPLX_CHUNK, _CRT_KERNEL, _MAP_COLBLOCK; INTEGRATION.md
  * "Testing switches"): every one selects between bit-identical code paths.  They are parsed from the environment ONCE, at the first
