@@ -44,3 +44,20 @@ def test_plain_call_with_gpus_gt_1_starts_that_many_ranks(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
     assert cmd[cmd.index(BENCH) + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
     assert seen["env"].get("GEMMUL8_DIST_BACKEND") == "gloo"   # no GPU in this container: shared-device test transport
+
+
+def test_roofline_traffic_comes_from_the_manifest():
+    """roofline.traffic is a committed PMC constant: bench.py takes it from the file profiles/MANIFEST.json NAMES for the workload (not from
+    whatever sorts last in profiles/), and yields None -- never a stale number -- for a workload the manifest does not list."""
+    import json
+    spec = importlib.util.spec_from_file_location("bench_under_test2", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    man = json.load(open(os.path.join(ROOT, "profiles", "MANIFEST.json")))
+    ent = man["workloads"]["dgemm_8192_moduli14_int8"]
+    for key in ("pmc_traffic", "kernel_stats", "pmc_mfma"):
+        assert os.path.exists(os.path.join(ROOT, "profiles", ent[key])), ent[key]
+    got = bench.traffic_manifest_entry(8192, 14)
+    assert got and got["source"] == "profiles/" + ent["pmc_traffic"] and got["kernel"] == ent["kernel"]
+    assert 2.82e9 < got["hbm_side_bytes_per_launch"] < 40e9      # above the algorithmic 2.82 GB, far below a re-read of everything per tile row
+    assert bench.traffic_manifest_entry(4096, 14) is None and bench.traffic_manifest_entry(8192, 15) is None
