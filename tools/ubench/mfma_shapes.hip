@@ -8,6 +8,7 @@
 //          16w = 16x16x64, 16 accumulator tiles (4x4: a 64x64 wave tile)
 //          f32 = FP8 v_mfma_scale_f32_32x32x64_f8f6f4 (8 tiles), f16 = FP8 v_mfma_scale_f32_16x16x128_f8f6f4 (32 tiles);
 //                data for these: rand = random finite e4m3 bytes, res = integers uniform in [-16, 16], zero
+//          s32 / s16 = the same two instructions on FP6 (e2m3) operands (cbsz = blgp = 2; 6 registers per operand): round 5
 //          data: rand = random bytes; res = symmetric residues mod 251 (uniform in [-125,125], what the GEMM really multiplies);
 //                small = |x| <= 7; zero; sparse = random bytes with 3 of 4 zeroed
 #include <hip/hip_runtime.h>
@@ -36,6 +37,63 @@ __device__ inline int gen8(unsigned& s, int mode) {
         }
     }
     return (int)w;
+}
+// FP6 (e2m3) operand: 32 codes of 6 bits in 6 dwords; an integer v in [-16, 16] scaled by 2^-3 is the code sign << 5 | |v| (subnormal /
+// normal e2m3 happen to be the plain binary magnitude up to 16); mode 0 = random codes, 1 = integers uniform in [-16, 16], 3 = zero
+// (the builtin takes 8-register operands for every format; with cbsz / blgp = 2 the instruction reads the low six)
+__device__ inline v8i gen6(unsigned& s, int mode) {
+    unsigned w[6] = {0, 0, 0, 0, 0, 0};
+    if (mode != 3)
+        for (int i = 0; i < 32; ++i) {
+            s ^= s << 13, s ^= s >> 17, s ^= s << 5;
+            unsigned c;
+            if (mode == 0) c = (s >> 9) & 63u;
+            else {
+                const int v = (int)((s >> 8) % 33u) - 16;
+                c = (v < 0 ? 32u : 0u) | (unsigned)(v < 0 ? -v : v);
+            }
+            const int bit = 6 * i;
+            w[bit >> 5] |= c << (bit & 31);
+            if ((bit & 31) > 26) w[(bit >> 5) + 1] |= c >> (32 - (bit & 31));
+        }
+    return v8i{(int)w[0], (int)w[1], (int)w[2], (int)w[3], (int)w[4], (int)w[5], 0, 0};
+}
+// FP6 x FP6 (cbsz = blgp = 2), unit scales: the same loop bodies as spin8
+template <int SHAPE> __global__ void __launch_bounds__(512) spin6(int iters, int mode, int* sink) {
+    unsigned s = (threadIdx.x * 2654435761u + blockIdx.x * 40503u) | 1u;
+    if constexpr (SHAPE == 32) {
+        v8i a[4], b[2];
+        for (auto& x : a) x = gen6(s, mode);
+        for (auto& x : b) x = gen6(s, mode);
+        v16f acc[4][2] = {};
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[i], b[j], acc[i][j], 2, 2, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        float t = 0;
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 2; ++j) t += acc[i][j][0];
+        if (t == 12345.678f) sink[0] = 1;
+    } else {
+        v8i a[4], b[4];
+        for (auto& x : a) x = gen6(s, mode);
+        for (auto& x : b) x = gen6(s, mode);
+        v4f acc[8][4] = {};
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i & 3], b[j], acc[i][j], 2, 2, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        float t = 0;
+        for (int i = 0; i < 8; ++i)
+            for (int j = 0; j < 4; ++j) t += acc[i][j][0];
+        if (t == 12345.678f) sink[0] = 1;
+    }
 }
 template <int SHAPE> __global__ void __launch_bounds__(512) spin8(int iters, int mode, int* sink) {
     unsigned s = (threadIdx.x * 2654435761u + blockIdx.x * 40503u) | 1u;
@@ -143,7 +201,9 @@ int main(int argc, char** argv) {
     // every variant issues 64 x (2 * 16384 ops) = 2^21 ops per wave and iteration: 32: 4*8 MFMAs of 65536; 16: 2*32 of 32768; 16w: 4*16
     const double ops_per_launch = (double)p.multiProcessorCount * 8 * iters * 32.0 * 65536.0;
     auto launch = [&]() {
-        if (!strcmp(shape, "f32")) hipLaunchKernelGGL(spin8<32>, dim3(p.multiProcessorCount), dim3(512), 0, 0, iters, mode, sink);
+        if (!strcmp(shape, "s32")) hipLaunchKernelGGL(spin6<32>, dim3(p.multiProcessorCount), dim3(512), 0, 0, iters, mode, sink);
+        else if (!strcmp(shape, "s16")) hipLaunchKernelGGL(spin6<16>, dim3(p.multiProcessorCount), dim3(512), 0, 0, iters, mode, sink);
+        else if (!strcmp(shape, "f32")) hipLaunchKernelGGL(spin8<32>, dim3(p.multiProcessorCount), dim3(512), 0, 0, iters, mode, sink);
         else if (!strcmp(shape, "f16")) hipLaunchKernelGGL(spin8<16>, dim3(p.multiProcessorCount), dim3(512), 0, 0, iters, mode, sink);
         else if (!strcmp(shape, "32")) hipLaunchKernelGGL(spin<32>, dim3(p.multiProcessorCount), dim3(512), 0, 0, iters, mode, sink);
         else if (!strcmp(shape, "16")) hipLaunchKernelGGL(spin<16>, dim3(p.multiProcessorCount), dim3(512), 0, 0, iters, mode, sink);
