@@ -27,6 +27,7 @@ class Layout(C.Structure):
         ("A_bound", C.c_void_p), ("B_bound", C.c_void_p),
         ("sftA", C.c_void_p), ("sftB", C.c_void_p),
         ("C_mid", C.c_void_p), ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
+        ("lo_format", C.c_size_t),
     ]
 
 

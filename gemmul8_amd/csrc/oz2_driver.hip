@@ -93,6 +93,7 @@ static Knobs parse_knobs() {
     if (num("GEMMUL8_CPLX_BOUND_LAUNCHES", 1) == 2) k.cplx_bound_launches = 2;
     if (const int c = num("GEMMUL8_CPLX_CHUNK", 0); c >= 1) k.cplx_chunk = c;
     if (const char* e = getenv("GEMMUL8_CRT_KERNEL")) k.crt_kernel = e[0] == 'd' ? 1 : e[0] == 'r' ? 2 : 0;
+    if (const char* e = getenv("GEMMUL8_FP8_PLANES")) k.fp8_planes = e[0] == 'e' ? 1 : 0;
     if (const char* e = getenv("GEMMUL8_MAP_COLBLOCK"); e && *e) k.map_colblock = atoi(e) > 0 ? atoi(e) : 0;
     return k;
 }
@@ -187,6 +188,7 @@ int gemmul8_get_layout(int dtype, int backend, size_t m, size_t n, size_t k, uns
     const size_t tail = (native_sz - midsz * L->sizeC) & ~size_t(255);
     L->scratch = C_hi - tail;
     L->scratch_bytes = tail + hi_bytes;
+    L->lo_format = (backend == kFP8 && f6_planes_ok(n)) ? 1 : 0;
     return GEMMUL8_OK;
 }
 
@@ -285,8 +287,9 @@ int gemmul8_scale_finish(void* stream_, int dtype, int backend, int op_A, int op
     const bool kmajA = op_A != 0, kmajB = op_B == 0;
     const bool conjA = cplx && op_A == 2, conjB = cplx && op_B == 2;
     QuantOperand oa, ob;  // rows == 0: the operand is skipped
-    if (!skipA) oa = QuantOperand{kmajA, conjA, m, A, lda, L->sftA, (int8_t*)L->A_lo, L->sizeA, L->part_strideA, g_batch.sa};
-    if (!skipB) ob = QuantOperand{kmajB, conjB, n, B, ldb, L->sftB, (int8_t*)L->B_lo, L->sizeB, L->part_strideB, g_batch.sb};
+    const bool f6 = backend == kFP8 && L->lo_format == 1;  // FP6 panel images (oz2_gemm_f6.hip): A's blocks are whole (mp rows), B's last one may be short
+    if (!skipA) oa = QuantOperand{kmajA, conjA, m, A, lda, L->sftA, (int8_t*)L->A_lo, L->sizeA, L->part_strideA, g_batch.sa, f6 ? L->mp : 0};
+    if (!skipB) ob = QuantOperand{kmajB, conjB, n, B, ldb, L->sftB, (int8_t*)L->B_lo, L->sizeB, L->part_strideB, g_batch.sb, f6 ? n : 0};
     if (fastmode) {
         OZ2_HIP(launch_fast_shift_pair(stream, dtype, backend, N, k, oa, ob));
     } else {
@@ -320,6 +323,15 @@ int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t
     if (!moduli_ok(dtype, N) || t_end > N || t_begin > t_end) return GEMMUL8_E_NUM_MODULI;
     const int8_t* A_lo = (const int8_t*)L->A_lo;
     const int8_t* B_lo = (const int8_t*)L->B_lo;
+    if (backend == kFP8 && L->lo_format == 1 && n < 64) return GEMMUL8_E_ARG;  // (an image layout for a shape it cannot hold: not from gemmul8_get_layout)
+    // FP8 backend: the residue GEMMs run on e4m3 byte planes or on FP6 panel images of the same integers (twice the matrix rate), as the layout says
+    const bool f6 = backend == kFP8 && L->lo_format == 1;
+    auto launch_gemm_f8 = [f6](hipStream_t st, int which, const int8_t* A, const int8_t* B, size_t sA, size_t sB, size_t kp, size_t mm, size_t nn, int tb, int te,
+                               int16_t* out, size_t ldo, size_t sO, const int16_t* r0, const int16_t* r1, size_t sR, const int16_t* rx = nullptr,
+                               const int16_t* ry = nullptr) {
+        return f6 ? oz2::launch_gemm_f6(st, which, A, B, sA, sB, kp, mm, nn, tb, te, out, ldo, sO, r0, r1, sR, rx, ry)
+                  : oz2::launch_gemm_f8(st, which, A, B, sA, sB, kp, mm, nn, tb, te, out, ldo, sO, r0, r1, sR, rx, ry);
+    };
     if (backend == kFP8 && !is_complex(dtype)) {
         // three e4m3 GEMMs per modulus (gemmul8_real.hpp:159-181); the residues of the first two wait in int16 scratch planes
         // (the reference's C_hi region) for the third one's epilogue.  Moduli are chunked to the scratch size.

@@ -1,0 +1,274 @@
+// FP6 (e2m3) x FP6 -> FP32 "TN" GEMM on gfx950 MFMA for the residue GEMMs of the FP8 backend (round 5).
+//
+// The FP8 backend of the reference multiplies integers of magnitude <= 16 held as e4m3 (GEMMul8/src/mod.hpp:159-189; call sites
+// src/matmult.hpp:307-389, loop src/gemmul8_real.hpp:159-181).  Every such integer v is ALSO exact as an e2m3 number: v / 8 has the
+// 6-bit code sign << 5 | |v| (subnormal 0..7, normal 8..15, 16 = 2.0), and with E8M0 block scales 2^3 on both operands
+// v_mfma_scale_f32_16x16x128_f8f6f4 (cbsz = blgp = 2) returns the integer product sums themselves, exact in the FP32 accumulators up
+// to 2^24 like the e4m3 form (tools/ubench/f6_layout.hip checks field map, code map, scales and accumulation on the device:
+// profiles/r05_f6_layout.txt).  CDNA4 runs the FP6 formats at the FP4 rate -- 16 cycles per instruction where e4m3 takes 32 -- and at
+// the board's power cap a register-only loop of it sustains 6.8 POP/s on these integers against 4.5 for e4m3
+// (tools/ubench/mfma_shapes.hip s16 / f16, profiles/r05_mfma_shapes_fp6.txt).  Same numbers in, same bits out: the three GEMMs per modulus,
+// the epilogues (oz2_gemm_f8_epi.hpp) and every residue are those of oz2_gemm_f8.hip; only the operand planes' ENCODING differs, and it
+// never leaves the workspace.  The accurate-mode bound GEMM multiplies genuine e4m3 values and stays on the e4m3 kernel.
+//
+// Operand planes ("FP6 panel images", written by the quantise kernels: oz2_scale.hip put_f6_planes): a plane is cut into row blocks of
+// 256 rows (the CU tile; the last block of B has Rp = its rows rounded up to 16) and K-steps of 128 elements; panel (block tb, K-step kt)
+// is the byte image of what the kernel wants in LDS, Rp * 96 bytes at  plane + tb * 256 * (3 kp / 4) + kt * Rp * 96:
+//     X region: 16-byte slot q * Rp + r          = bytes  0..15 of the 24-byte fragment of (row r, K group q)   [ds_read_b128]
+//     Y region: at 64 Rp; 8-byte slot (q >> 1) * 2 Rp + 2 r + (q & 1) = bytes 16..23 of that fragment            [ds_read_b64]
+// where the fragment of (r, q) packs the codes of elements 32 q .. 32 q + 31 of the K-step, element e at bits 6 e .. 6 e + 5: exactly
+// the six operand registers of lane (r & 15, q).  The LDS-DMA is then LINEAR (instruction j moves bytes 1024 j .. 1024 j + 1023 of
+// the panel: eight full 128-byte lines, no address arithmetic), and both read patterns are bank-conflict free without a swizzle:
+// the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte slots mod 256 B (slot index = r mod 16 plus a multiple of 16), the
+// 32 lanes of a ds_read_b64 half-wave 32 distinct 8-byte slots (2 (r & 15) + (q & 1)).
+//
+// Tiling and schedule as oz2_gemm_f8.hip: persistent 256 x 256 tiles, 8 waves (2 x 4, wave tile 128 x 64, 128 accumulators), ping-pong
+// LOAD / MFMA segments with the two halves one slot apart, the waves issue the LDS-DMA themselves in their LOAD segments; five 24 KiB
+// panel slots (2.5 stages).  A K-step moves 48 KiB through the operand path for 2 x 32 MFMAs of 16 cycles.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <atomic>
+
+#include "oz2_gemm_f8_epi.hpp"
+
+namespace oz2 {
+
+constexpr int F6_BKE = 128;          // elements per K-step (one MFMA)
+constexpr int F6_ROWB = 96;          // bytes per row and K-step
+constexpr int F6_SLOT = BM * F6_ROWB;  // 24 KiB per panel slot
+constexpr int F6_NSLOT = 5;
+
+template <int EPI>
+__global__ void __launch_bounds__(F8_THREADS) gemm_f6_kernel(const F8Args args) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int KT1 = args.kp / F6_BKE;  // K-steps per segment
+    const int KT = KT1 * args.nseg;    // K-steps per tile
+    const int total = args.total_tiles;
+    const int G = gridDim.x;
+    const size_t blockbytes = (size_t)BM * (size_t)(args.kp / 4 * 3);  // one 256-row block of a plane
+
+    // LDS-DMA: a panel is 24 linear instructions of 1 KiB; the four waves fetching an operand issue six each (a shorter last block of B:
+    // lanes beyond the image re-read its last chunk).  Waves 0-3 fetch B (needed one K-step after issue), waves 4-7 A (two K-steps ahead).
+    const bool isB = wave < 4;
+    unsigned doff[6];
+    const int8_t* gsrc;
+    int gstep = 0;         // bytes between consecutive K-steps of the block: Rp * 96
+    long long gdelta = 0;  // nseg == 2: from the panel of K-step KT1 + j of segment 1's plane to K-step j of segment 2's plane
+    auto uniform = [](const int8_t* ptr) {
+        const unsigned long long v = (unsigned long long)ptr;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (const int8_t*)(((unsigned long long)hi << 32) | lo);
+    };
+    auto rows_pad = [&](int tn) {  // rows of B's block tn in its panel images
+        const int nr = args.n - tn * BN;
+        return nr >= BN ? BN : ((nr + 15) & ~15);
+    };
+#define F6_SET_TILE(vb_)                                                                                                     \
+    do {                                                                                                                     \
+        const TileMap tmap_ = map_tile((vb_), total, args.map);                                                              \
+        const F8Plane pl_ = f8_plane(args, tmap_.plane);                                                                     \
+        const int rp_ = isB ? rows_pad(tmap_.tn) : BM;                                                                       \
+        gstep = rp_ * F6_ROWB;                                                                                               \
+        gsrc = uniform(isB ? args.B + pl_.boff + (size_t)args.planeB[pl_.tt] * args.strideB + (size_t)tmap_.tn * blockbytes   \
+                           : args.A + pl_.boff + (size_t)args.planeA[pl_.tt] * args.strideA + (size_t)tmap_.tm * blockbytes); \
+        gdelta = isB ? ((long long)args.planeB2[pl_.tt] - args.planeB[pl_.tt]) * (long long)args.strideB - (long long)KT1 * gstep \
+                     : ((long long)args.planeA2[pl_.tt] - args.planeA[pl_.tt]) * (long long)args.strideA - (long long)KT1 * gstep; \
+        const int last_ = rp_ * 6 - 1;                                                                                       \
+        _Pragma("unroll") for (int q = 0; q < 6; ++q) {                                                                      \
+            const int c_ = ((wave & 3) * 6 + q) * 64 + lane;                                                                 \
+            doff[q] = (unsigned)(c_ < last_ ? c_ : last_) * 16u;                                                             \
+        }                                                                                                                    \
+    } while (0)
+#define F6_DMA(src_, q_, stage_)                                                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((src_) + doff[q_]),                     \
+                                     (__attribute__((address_space(3))) void*)((stage_) + ((wave & 3) * 6 + (q_)) * 1024), 16, 0, 0)
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r16 = lane & 15;
+    const int q = lane >> 4;
+    // this lane's fragment pieces inside a panel image (see the header): A blocks always have 256 rows
+    const int ax = (q * BM + wm * 128 + r16) * 16;
+    const int ay = 64 * BM + ((q >> 1) * 2 * BM + 2 * (wm * 128 + r16) + (q & 1)) * 8;
+
+    auto frag = [&](const char* px, const char* py) {  // 24 bytes: the six operand registers
+        const v4i lo = *(const v4i*)px;
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        const v2i hi = *(const v2i*)py;
+        return v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], 0, 0};
+    };
+    constexpr int SC3 = (int)0x82828282u;  // E8M0 scale 2^3 for every block: (v / 8 * 8) (w / 8 * 8)
+
+    auto run = [&]<bool ISB>() {
+        int vb_next = blockIdx.x, kt_next = 0;
+        bool more = true;
+        int hs = ISB ? 1 : 0;  // slot of the panel to fetch
+        const int8_t* fsrc;
+        char* fdst;
+        F6_SET_TILE(vb_next);
+#define F6_FETCH_ADVANCE()                                                                                                   \
+    do {                                                                                                                     \
+        hs = hs + 2 >= F6_NSLOT ? hs + 2 - F6_NSLOT : hs + 2;                                                                \
+        if (more && ++kt_next == KT) {                                                                                       \
+            kt_next = 0;                                                                                                     \
+            vb_next += G;                                                                                                    \
+            more = vb_next < total;                                                                                          \
+            if (more) F6_SET_TILE(vb_next);                                                                                  \
+            else kt_next = KT - 1;                                                                                           \
+        }                                                                                                                    \
+    } while (0)
+#define F6_FETCH_BEGIN()                                                                                                     \
+    do {                                                                                                                     \
+        fsrc = gsrc + (long long)OZ2_HOOK_KSTEP(kt_next) * gstep + (kt_next >= KT1 ? gdelta : 0);                            \
+        fdst = smem + hs * F6_SLOT;                                                                                          \
+    } while (0)
+        F6_FETCH_BEGIN();
+#pragma unroll
+        for (int i = 0; i < 6; ++i) F6_DMA(fsrc, i, fdst);
+        if constexpr (!ISB) {
+            F6_FETCH_ADVANCE();
+            F6_FETCH_BEGIN();
+#pragma unroll
+            for (int i = 0; i < 6; ++i) F6_DMA(fsrc, i, fdst);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();
+        // Hazards as in oz2_gemm_f8.hip: a slot was last read two (A) / one (B) K-steps before its refill is issued; every wave finishes a
+        // K-step's LOAD segments (lgkmcnt(0) + barrier) before the leading half enters the next one; each wave drains the DMA the NEXT
+        // K-step needs in its last LOAD segment (A waves: everything but the 6 instructions just issued).
+        int sA = 0;  // slot of A(g); B(g) sits in the next slot
+        for (int vb = blockIdx.x; vb < total; vb += G) {
+            const TileMap tmap = map_tile(vb, total, args.map);
+            const int rpB = rows_pad(tmap.tn);
+            const int bx = (q * rpB + wn * 64 + r16) * 16;
+            const int by = 64 * rpB + ((q >> 1) * 2 * rpB + 2 * (wn * 64 + r16) + (q & 1)) * 8;
+            v4f acc[8][4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
+
+            for (int kt = 0; kt < KT; ++kt) {
+                const char* curA = smem + sA * F6_SLOT;
+                const char* curB = smem + (sA == F6_NSLOT - 1 ? 0 : sA + 1) * F6_SLOT;
+                sA = sA + 2 >= F6_NSLOT ? sA + 2 - F6_NSLOT : sA + 2;
+                F6_FETCH_ADVANCE();
+                F6_FETCH_BEGIN();
+                v8i bf[4];
+#pragma unroll
+                for (int ah = 0; ah < 2; ++ah) {  // LOAD segment ah of this K-step
+                    v8i af[4];
+                    if (OZ2_HOOK_DMA_ON(vb == (int)blockIdx.x)) {  // (laboratory hook: always true in the product)
+                        if constexpr (ISB) {
+                            if (ah == 0) {
+#pragma unroll
+                                for (int i = 0; i < 6; ++i) F6_DMA(fsrc, i, fdst);
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) F6_DMA(fsrc, ah * 3 + i, fdst);
+                        }
+                    }
+                    if (ah == 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bf[j] = frag(curB + bx + j * 256, curB + by + j * 256);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i] = frag(curA + ax + (ah * 4 + i) * 256, curA + ay + (ah * 4 + i) * 256);
+                    if (ah == 1) {
+                        if (!ISB) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ah == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int j = (i & 1) ? 3 - jj : jj;  // serpentine, as in the INT8 / e4m3 kernels
+                            acc[ah * 4 + i][j] =
+                                __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[i], bf[j], acc[ah * 4 + i][j], 2, 2, 0, SC3, 0, SC3);
+                        }
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ah == 1 && ISB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const int i0 = tmap.tm * BM + wm * 128, j0 = tmap.tn * BN + wn * 64;
+            const F8Plane pl = f8_plane(args, tmap.plane);
+            f8_epilogue_mod<EPI>(acc, args, pl, i0, j0, lane);
+        }
+    };
+    if (isB) run.template operator()<true>();
+    else run.template operator()<false>();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+#undef F6_SET_TILE
+#undef F6_DMA
+#undef F6_FETCH_BEGIN
+#undef F6_FETCH_ADVANCE
+}
+
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) return 256;
+        n = prop.multiProcessorCount;
+    }
+    return n;
+}
+
+template <int EPI> static hipError_t launch(hipStream_t stream, F8Args& a, int planes) {
+    static std::atomic<bool> attr_set_dev[64];
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 0;
+    if (!attr_set_dev[dev_].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_f6_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, F6_NSLOT * F6_SLOT);
+        if (e != hipSuccess) return e;
+        attr_set_dev[dev_].store(true, std::memory_order_release);
+    }
+    a.ppi = planes;
+    a.m_ppi = map_magic((unsigned)planes);
+    a.bstride = g_batch.ws;
+    planes *= (int)g_batch.batch;
+    a.total_tiles = planes * a.tiles_m * a.tiles_n;
+    if (a.total_tiles <= 0) return hipSuccess;
+    if (a.nseg < 1) a.nseg = 1;
+    if (a.nres < 1) a.nres = 2;
+    a.colblock = map_colblock((size_t)a.tiles_n, (size_t)a.kp / 4 * 3 * (size_t)a.nseg);
+    a.map = make_tile_map(a.tiles_m, a.tiles_n, a.colblock);
+    int grid = num_cus() & ~7;  // persistent: one workgroup per CU (see oz2_gemm_i8.hip)
+    if (grid <= 0) grid = 8;
+    if (a.total_tiles < grid) grid = a.total_tiles;
+    hipLaunchKernelGGL(gemm_f6_kernel<EPI>, dim3(grid), dim3(F8_THREADS), F6_NSLOT * F6_SLOT, stream, a);
+    return hipGetLastError();
+}
+
+// The residue GEMMs of launch_gemm_f8 (same `which`, same plane algebra: see there) on FP6 panel images.
+hipError_t launch_gemm_f6(hipStream_t stream, int which, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp, size_t m,
+                          size_t n, int t_begin, int t_end, int16_t* out, size_t ldo, size_t strideO, const int16_t* r0, const int16_t* r1,
+                          size_t strideR, const int16_t* rx, const int16_t* ry) {
+    F8Args a{};
+    if (f8_fill_planes(a, which, A, B, strideA, strideB, kp, m, n, t_begin, t_end, out, ldo, strideO, r0, r1, strideR, rx, ry) != 0) return hipErrorInvalidValue;
+    const int planes = t_end - t_begin;
+    if (which == 3 || which == 6) return launch<EPI_FINAL_CPLX>(stream, a, planes);
+    return (which == 2 || which == 5) ? launch<EPI_FINAL>(stream, a, planes) : launch<EPI_PART>(stream, a, planes);
+}
+
+}  // namespace oz2

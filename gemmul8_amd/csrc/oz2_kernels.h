@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "oz2_device.hpp"
+#include "oz2_knobs.hpp"
 
 namespace oz2 {
 
@@ -49,6 +50,10 @@ hipError_t launch_gemm_i8_max_small(hipStream_t stream, int nseg, const int8_t* 
 hipError_t launch_gemm_f8(hipStream_t stream, int which, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp, size_t m,
                           size_t n, int t_begin, int t_end, int16_t* out, size_t ldo, size_t strideO, const int16_t* r0, const int16_t* r1,
                           size_t strideR, const int16_t* rx = nullptr, const int16_t* ry = nullptr);
+// the same residue GEMMs on FP6 (e2m3) panel images of the operand planes (oz2_gemm_f6.hip): same `which`, same outputs, twice the matrix rate
+hipError_t launch_gemm_f6(hipStream_t stream, int which, const int8_t* A, const int8_t* B, size_t strideA, size_t strideB, size_t kp, size_t m,
+                          size_t n, int t_begin, int t_end, int16_t* out, size_t ldo, size_t strideO, const int16_t* r0, const int16_t* r1,
+                          size_t strideR, const int16_t* rx = nullptr, const int16_t* ry = nullptr);
 void set_f8_bound_mode(int mode);  // 0 = engine-safe inflation (default), 1 = the reference's (k+1) * 2^-24
 int get_f8_bound_mode();
 hipError_t launch_gemm_f8_max(hipStream_t stream, const int8_t* A, const int8_t* B, size_t kp, size_t k, size_t m, size_t n, int* rowmax,
@@ -77,7 +82,11 @@ struct QuantOperand {
     int8_t* lo = nullptr;
     size_t plane_stride = 0, part_stride = 0;
     size_t xstride = 0;       // batched launch: bytes between the items' operands
+    size_t f6_rows = 0;       // FP8 backend: > 0 = write FP6 panel images (oz2_gemm_f6.hip) of a plane with this many image rows (A: mp, B: n)
 };
+// FP8 backend: the residue planes are FP6 panel images whenever B's last row block fits its share of the reference's plane size
+// (16-row granules at 3/4 byte per element: n >= 45; 64 keeps whole wave tiles); GEMMUL8_FP8_PLANES=e4m3 keeps the e4m3 byte planes
+inline bool f6_planes_ok(size_t n) { return n >= 64 && knobs().fp8_planes != 1; }
 // both operands in ONE launch each (the A and B halves are independent; at launch-bound sizes every dispatch costs 5-10 us)
 hipError_t launch_fast_shift_pair(hipStream_t stream, int dtype, int backend, unsigned N, size_t k, const QuantOperand& A, const QuantOperand& B);
 hipError_t launch_quantise_pair(hipStream_t stream, int dtype, int backend, int t_begin, int t_end, size_t k, size_t kp, const QuantOperand& A,

@@ -169,6 +169,9 @@ struct StageArgs {
     ModTable mt;
     double pairP[10], pairInvP[10];  // MODE_MOD, float-domain residues: product of the moduli pair (t_begin + 2j, t_begin + 2j + 1) and RN(1 / it)
     size_t bx, bw;        // batched launch (gridDim.z items): bytes between the items' operands X / between their workspaces
+    int f6;               // MODE_MOD, FP8 backend: 1 = the planes are FP6 panel images (oz2_gemm_f6.hip), 0 = e4m3 bytes, K-major rows
+    unsigned f6_last;     // index of the plane's last 256-row block ...
+    unsigned f6_rp_last;  // ... and its rows in the images (A: 256, B: its rows rounded up to 16)
 };
 // item blockIdx.z of a batched launch: every workspace pointer moves by bw, the operand by bx (both 0 for a single GEMM).  The offsets
 // are applied at the few points of use: a modified COPY of the argument block lands in scratch memory (the quantise kernels ran 6x
@@ -215,6 +218,51 @@ __device__ __forceinline__ void put_fp8_planes(const StageArgs& a, int8_t* o, in
         *(unsigned*)(o + 2 * a.plane_stride) =
             fp8x2_from_ints(hi[0] + lo[0], hi[1] + lo[1]) | (fp8x2_from_ints(hi[2] + lo[2], hi[3] + lo[3]) << 16);
     }
+}
+
+// FP6 panel images (oz2_gemm_f6.hip): the same integers as e2m3 codes, sign << 5 | |v|, four codes = 24 bits per lane.  A lane quad holds 16
+// consecutive k of a row = 96 bits = three dwords of the 24-byte fragment of (row, K group): lane j < 3 of the quad assembles dword j from its
+// own 24 bits and its right neighbour's (one quad-permute DPP move) and stores it at its own address o (f6_lane_addr below); lane 3 stores nothing.
+__device__ __forceinline__ unsigned f6_code(int v) { return (unsigned)(v < 0 ? 32 - v : v); }
+__device__ __forceinline__ void put_f6_word(int8_t* o, const int (&v)[4]) {
+    const unsigned w = f6_code(v[0]) | (f6_code(v[1]) << 6) | (f6_code(v[2]) << 12) | (f6_code(v[3]) << 18);
+    const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xF9, 0xF, 0xF, true);  // quad_perm [1, 2, 3, 3]
+    const unsigned j = threadIdx.x & 3u;
+    const unsigned d = (w >> (8u * j)) | (nb << (24u - 8u * j));
+    if (j < 3u) *(unsigned*)o = d;
+}
+__device__ __forceinline__ void put_f6_planes(const StageArgs& a, int8_t* o, int t, const int (&rr)[4]) {
+    int hi[4], lo[4];
+    if (t < 6) {
+        const int sq = a.sqrtp[t];
+        const float inv = 1.0f / (float)sq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float h, l;
+            fp8_split_sq(rr[e], sq, inv, h, l);
+            hi[e] = (int)h, lo[e] = (int)l;
+        }
+        put_f6_word(o, hi);
+        put_f6_word(o + a.plane_stride, lo);
+    } else {
+        int sm[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fp8_split_kara(rr[e], hi[e], lo[e]), sm[e] = hi[e] + lo[e];
+        put_f6_word(o, hi);
+        put_f6_word(o + a.plane_stride, lo);
+        put_f6_word(o + 2 * a.plane_stride, sm);
+    }
+}
+// byte offset, inside a plane, of the dword that THIS lane stores for the 16 k starting at k0 & ~15 of `row` (lane j = threadIdx.x & 3 holds
+// k0 = (k0 & ~15) + 4 j): dword 3 h + j of the fragment (h = the half of the K group), see the image layout in oz2_gemm_f6.hip
+__device__ __forceinline__ size_t f6_lane_offset(const StageArgs& a, size_t row, size_t k0) {
+    const unsigned tb = (unsigned)(row >> 8), r = (unsigned)row & 255u;
+    const unsigned kt = (unsigned)(k0 >> 7), qf = ((unsigned)k0 >> 5) & 3u, h = ((unsigned)k0 >> 4) & 1u;
+    const unsigned d = 3u * h + (threadIdx.x & 3u);
+    const unsigned rp = tb == a.f6_last ? a.f6_rp_last : 256u;
+    const size_t panel = (size_t)tb * 256u * (a.kp / 4 * 3) + (size_t)kt * rp * 96u;
+    const unsigned inner = d < 4u ? (qf * rp + r) * 16u + 4u * d : 64u * rp + ((qf >> 1) * 2u * rp + 2u * r + (qf & 1u)) * 8u + 4u * (d - 4u);
+    return panel + inner;
 }
 
 // Quantise + all residues of four consecutive k in the FLOATING-POINT domain.  The quantise kernels are bound by VALU issue, not by HBM
@@ -350,10 +398,18 @@ template <typename T> __device__ __forceinline__ void emit4_mod_float(const Stag
                 }
                 if constexpr (WIDE) {
                     int8_t* o = out + (size_t)(tt < 6 ? 2 * tt : 12 + 3 * (tt - 6)) * a.plane_stride;
-                    put_fp8_planes(a, o, tt, rr);
-                    if constexpr (E::cplx) {
-                        put_fp8_planes(a, o + a.part_stride, tt, ri);
-                        put_fp8_planes(a, o + 2 * a.part_stride, tt, rs);
+                    if (a.f6) {  // (uniform) FP6 panel images: `out` is this lane's dword address inside plane 0
+                        put_f6_planes(a, o, tt, rr);
+                        if constexpr (E::cplx) {
+                            put_f6_planes(a, o + a.part_stride, tt, ri);
+                            put_f6_planes(a, o + 2 * a.part_stride, tt, rs);
+                        }
+                    } else {
+                        put_fp8_planes(a, o, tt, rr);
+                        if constexpr (E::cplx) {
+                            put_fp8_planes(a, o + a.part_stride, tt, ri);
+                            put_fp8_planes(a, o + 2 * a.part_stride, tt, rs);
+                        }
                     }
                 } else {
                     auto pack = [](const int (&r)[4]) {
@@ -382,7 +438,7 @@ template <typename T> __device__ __forceinline__ void emit4_mod_float(const Stag
 template <typename T, int MODE>
 __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0, const T (&v)[4], int s) {
     using E = ET<T>;
-    int8_t* out = a.lo + OZ2_ZW + row * a.kp + k0;
+    int8_t* out = a.lo + OZ2_ZW + ((MODE == MODE_MOD && a.f6) ? f6_lane_offset(a, row, k0) : row * a.kp + k0);
     if constexpr (MODE == MODE_BOUND) {
         if (a.backend == kFP8) {
             // e4m3 round-up of |x|*2^s (< 2^8), computed in the input precision (scaling.hpp:77-82); complex: planes
@@ -474,7 +530,10 @@ __device__ __forceinline__ void emit4(const StageArgs& a, size_t row, size_t k0,
                 if constexpr (E::cplx) Xi[e] = shifted_bytes(Mi[e], Ei[e], ni[e]);
             }
         }
-        auto put_fp8 = [&](int8_t* o, int t, const int (&rr)[4]) { put_fp8_planes(a, o, t, rr); };
+        auto put_fp8 = [&](int8_t* o, int t, const int (&rr)[4]) {
+            if (a.f6) put_f6_planes(a, o, t, rr);
+            else put_fp8_planes(a, o, t, rr);
+        };
         // one pass over the moduli; FAST / WIDE are compile-time so the residue code is branch-free.  Complex: the residues of
         // Re, Im and wrapping(Re + Im) go to the three parts (INT8: the sum of the int8-cast values, mod.hpp:321-325).
         auto planes = [&]<bool FAST, bool WIDE>() {
@@ -979,6 +1038,11 @@ static StageArgs quantise_args(int backend, int t_begin, int t_end, size_t k, si
         a.pairInvP[j] = 1.0 / P;
     }
     for (int t = 0; t < 6; ++t) a.sqrtp[t] = GEMMUL8_SQRT_MODULI_FP8[t];
+    if (backend == kFP8 && o.f6_rows > 0) {
+        a.f6 = 1;
+        a.f6_last = (unsigned)((o.f6_rows - 1) / 256);
+        a.f6_rp_last = (unsigned)((o.f6_rows - 256 * (size_t)a.f6_last + 15) / 16 * 16);
+    }
     return a;
 }
 

@@ -31,6 +31,43 @@ def from_dev(T):
     return T.cpu().numpy().T
 
 
+def f6_plane_values(buf, rows, rows_img, kp):
+    """Integer values [rows, kp] of one FP6 panel-image plane of the FP8 backend (gemmul8_layout.lo_format == 1; layout in
+    csrc/oz2_gemm_f6.hip): row blocks of 256 (the last one holds rows_img - 256 * nb rows rounded up to 16), K-steps of 128 elements,
+    panel = X region (16-byte slot q * Rp + r) + Y region (8-byte slot (q >> 1) * 2 Rp + 2 r + (q & 1)); a fragment packs 32 codes
+    sign << 5 | |v| of 6 bits, little-endian."""
+    out = np.zeros((rows, kp), np.int8)
+    kt_n = kp // 128
+    nb = (rows_img + 255) // 256
+    blockbytes = 256 * (kp // 4 * 3)
+    for tb in range(nb):
+        nr = min(256, rows_img - 256 * tb)
+        rp = 256 if tb < nb - 1 else (nr + 15) // 16 * 16
+        for kt in range(kt_n):
+            off = tb * blockbytes + kt * rp * 96
+            panel = buf[off:off + rp * 96]
+            X = panel[:64 * rp].reshape(4, rp, 16)
+            Y = panel[64 * rp:].reshape(2, rp, 2, 8)
+            frag = np.concatenate([X, np.stack([Y[0, :, 0], Y[0, :, 1], Y[1, :, 0], Y[1, :, 1]])], axis=2)  # [q][r][24]
+            bits = np.unpackbits(frag, axis=2, bitorder="little").reshape(4, rp, 32, 6).astype(np.int16)
+            codes = (bits << np.arange(6, dtype=np.int16)).sum(axis=3)
+            vals = np.where(codes & 32, -(codes & 31), codes & 31).astype(np.int8)  # [q][r][32]
+            vals = vals.transpose(1, 0, 2).reshape(rp, 128)
+            r0, r1 = 256 * tb, min(rows, 256 * tb + rp)
+            if r1 > r0:
+                out[r0:r1, 128 * kt:128 * kt + 128] = vals[:r1 - r0]
+    return out
+
+
+def e4m3_of_ints(v):
+    """e4m3 byte (OCP, +0 for zero) of integers |v| <= 16: what the reference's planes hold (mod.hpp:159-189)."""
+    a = np.abs(v.astype(np.int32))
+    e = np.where(a > 0, np.floor(np.log2(np.maximum(a, 1))).astype(np.int32), 0)
+    mant = np.where(a > 0, (a * 8) // (1 << e) - 8, 0)
+    byte = np.where(a > 0, ((e + 7) << 3) | mant, 0) | np.where((v < 0) & (a > 0), 0x80, 0)
+    return byte.astype(np.uint8)
+
+
 def hip_gemm(A, B, N, fastmode=False, backend=g.INT8, opA="N", opB="N", alpha=1.0, beta=0.0, C0=None, want_intermediates=False,
              timers=False):
     """A, B: numpy arrays as stored (before op), like oracle_lib.gemm.  Returns C (numpy m x n) [, intermediates]."""
@@ -63,6 +100,13 @@ def hip_gemm(A, B, N, fastmode=False, backend=g.INT8, opA="N", opB="N", alpha=1.
     B_lo = np.zeros((parts, nm, n, k), np.uint8)
     for p in range(parts):
         for q in range(nm):
+            if L.lo_format == 1:  # FP6 panel images: decode to the integers and re-encode as the e4m3 bytes the oracle holds (zero as +0)
+                va = f6_plane_values(region(L.A_lo + p * L.part_strideA + q * L.sizeA, L.sizeA), m, L.mp, L.kp)
+                vb = f6_plane_values(region(L.B_lo + p * L.part_strideB + q * L.sizeB, L.sizeB), n, n, L.kp)
+                assert not va[:, k:].any() and not vb[:, k:].any(), "k-padding of the FP6 planes must be zero"
+                A_lo[p, q] = e4m3_of_ints(va[:, :k])
+                B_lo[p, q] = e4m3_of_ints(vb[:, :k])
+                continue
             pa = region(L.A_lo + p * L.part_strideA + q * L.sizeA, L.sizeA).reshape(L.mp, L.kp)
             A_lo[p, q] = pa[:m, :k]
             assert not pa[:m, k:].any(), "k-padding of A_lo must be zero"
@@ -78,7 +122,7 @@ def hip_gemm(A, B, N, fastmode=False, backend=g.INT8, opA="N", opB="N", alpha=1.
         Cm[t] = pc[:, :m, :]
     if not cplx:
         Cm = Cm[..., 0]
-    inter = dict(sftA=sftA, sftB=sftB, A_lo=A_lo, B_lo=B_lo, C_mid=Cm)
+    inter = dict(sftA=sftA, sftB=sftB, A_lo=A_lo, B_lo=B_lo, C_mid=Cm, lo_format=int(L.lo_format))
     return (Cn, inter, tm) if timers else (Cn, inter)
 
 
@@ -191,6 +235,9 @@ def parity_case(A, B, N, fastmode, opA="N", opB="N", alpha=1.0, beta=0.0, C0=Non
     # oracle fed with the device's shifts -> everything downstream is bit-exact
     Co, ito = ol.gemm(A, B, N, fastmode=fastmode, backend=backend, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0,
                       sftA_in=it["sftA"], sftB_in=it["sftB"], want_intermediates=True)
+    if it["lo_format"] == 1:  # FP6 codes carry no sign on a zero: the oracle's -0 (rint of a small negative quotient) compares as +0
+        for key in ("A_lo", "B_lo"):
+            ito[key] = np.where(ito[key] == 0x80, 0, ito[key]).astype(np.uint8)
     assert np.array_equal(it["A_lo"], ito["A_lo"]), "A_lo planes differ"
     assert np.array_equal(it["B_lo"], ito["B_lo"]), "B_lo planes differ"
     assert np.array_equal(it["C_mid"], ito["C_mid"]), "C_mid planes differ"

@@ -730,3 +730,23 @@ def test_tall_skinny_accurate_mode(n):
     Co = ol.gemm(An[rows], Bn, N, sftA_in=sftA[rows], sftB_in=sftB)
     got = Cd[:, torch.as_tensor(rows, device="cuda")].cpu().numpy().T
     assert gu.bits_equal(np.ascontiguousarray(got), np.ascontiguousarray(Co))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,N,fast", [(np.float32, 6, False), (np.float64, 13, True), (np.complex64, 8, False)])
+def test_fp8_backend_fp6_images_and_e4m3_planes_agree(dtype, N, fast, monkeypatch):
+    """FP8 backend, round 5: the residue planes are FP6 panel images of the same integers (gemmul8_layout.lo_format == 1, n >= 64;
+    csrc/oz2_gemm_f6.hip) unless GEMMUL8_FP8_PLANES=e4m3 keeps the reference's e4m3 bytes.  Both encodings must be bit-exact against the
+    oracle -- planes, C_mid and C -- including a last row block of B that is not a multiple of 16 rows and a second tile column."""
+    rng = np.random.default_rng(606)
+    m, n, k = 300, 333, 520
+    A, B = rand((m, k), dtype, rng), rand((k, n), dtype, rng)
+    for planes, want in (("fp6", 1), ("e4m3", 0)):
+        gu.setknob(monkeypatch, "GEMMUL8_FP8_PLANES", planes)
+        Cd, it = gu.hip_gemm(A, B, N, fastmode=fast, backend=g.FP8, want_intermediates=True)
+        assert it["lo_format"] == want
+        gu.parity_case(A, B, N, fast, backend=g.FP8)
+    # below 64 columns the images of B's only block would not fit its plane: the e4m3 planes are used
+    gu.setknob(monkeypatch, "GEMMUL8_FP8_PLANES", "fp6")
+    _, it = gu.hip_gemm(A, B[:, :48].copy(), N, fastmode=fast, backend=g.FP8, want_intermediates=True)
+    assert it["lo_format"] == 0

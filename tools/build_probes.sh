@@ -10,13 +10,13 @@ FLAGS="-std=c++20 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -DOCML_BASIC
 for spec in "$@"; do
   tag="${spec%%=*}"; defs="${spec#*=}"
   src=${SRC:-oz2_gemm_i8}
-  if [ "$src" = "oz2_gemm_i8" ] || [ "$src" = "oz2_gemm_f8" ]; then
+  if [ "$src" = "oz2_gemm_i8" ] || [ "$src" = "oz2_gemm_f8" ] || [ "$src" = "oz2_gemm_f6" ]; then
     /opt/rocm/bin/hipcc $FLAGS '-DOZ2_LAB_HOOKS="../../tools/experiments/probes/lab_hooks.hpp"' $defs -c $src.hip -o build/${src}_$tag.o
   else
     /opt/rocm/bin/hipcc $FLAGS $defs -c $src.hip -o build/${src}_$tag.o
   fi
   objs=""
-  for o in oz2_gemm_i8 oz2_gemm_i8_small oz2_gemm_f8 oz2_scale oz2_crt oz2_driver oz2_api oz2_hook oz2_dist; do
+  for o in oz2_gemm_i8 oz2_gemm_i8_small oz2_gemm_f8 oz2_gemm_f6 oz2_scale oz2_crt oz2_driver oz2_api oz2_hook oz2_dist; do
     [ "$o" = "$src" ] && objs="$objs build/${src}_$tag.o" || objs="$objs build/$o.o"
   done
   /opt/rocm/lib/llvm/bin/clang++ -shared -fPIC -o ../lib/lib_$tag.so $objs -ldl -lpthread
