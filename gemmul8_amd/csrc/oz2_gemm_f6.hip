@@ -37,10 +37,258 @@ namespace oz2 {
 constexpr int F6_BKE = 128;          // elements per K-step (one MFMA)
 constexpr int F6_ROWB = 96;          // bytes per row and K-step
 constexpr int F6_SLOT = BM * F6_ROWB;  // 24 KiB per panel slot
+typedef int v6i __attribute__((ext_vector_type(6)));
+#ifndef OZ2_F6_SGB
+#define OZ2_F6_SGB 1
+#endif
+#ifdef OZ2_F6_PINGPONG
 constexpr int F6_NSLOT = 5;
+#else
+constexpr int F6_NSLOT = 6;
+#endif
 
+// The product kernel (v2): every wave is SELF-PIPELINED -- fragment sets double-buffered in its 256 registers, the reads of the next half K-step
+// and its share of the LDS-DMA interleaved one by one with the MFMAs of the current half (sched_group_barrier) -- and ONE workgroup barrier per
+// K-step.  With 16-cycle MFMAs a ping-pong LOAD segment (16 ds_reads + 6 DMA issues, 600+ cycles) is far longer than the partner's MFMA
+// segment (256 cycles): the ping-pong form below ran the matrix pipes ~40 % busy (config 3: 3.47 POP/s).  Six 24 KiB panel slots = three full
+// stages: panel A(g) in slot 2 (g % 3), B(g) behind it.  Per K-step g and wave (K-steps counted ACROSS tiles: the panel stream is continuous):
+//   half 0: MFMAs of rows 0-63 (fragments aL, bcur: in registers) | reads of A rows 64-127 of panel g -> aH | DMA pieces 3-5 of panel g + 2
+//   wait vmcnt(6) lgkmcnt(0); barrier B_g                            (panel g + 1 has landed for everyone; every read of panel g is complete)
+//   half 1: MFMAs of rows 64-127 (aH, bcur) | reads of B(g + 1) -> bnext, A rows 0-63 of panel g + 1 -> aL | DMA pieces 0-2 of panel g + 3
+// Hazards: the slot of panel g + 3 is the slot of panel g, whose last reads are complete before B_g (RAW on the fragments: lgkmcnt(0));
+// pieces 0-2 / 3-5 of panel g + 2 are issued after B_{g-1} (slot of panel g - 1, free since then) and waited for before B_{g+1}
+// (vmcnt(6): only the six pieces of panel g + 3 may be outstanding) -- one to 1.5 K-steps of latency budget for every piece.
+// The last K-step of a tile prefetches nothing (the epilogue needs the registers): a tile's first fragments are read exposed.  The fetch stream
+// runs three panels ahead of the consumers and enters the tile `lead` tiles ahead exactly once per consumer tile: that tile's addresses are
+// computed at the consumer's tile start (scalar registers), so that the K loop itself contains no tile arithmetic.
 template <int EPI>
 __global__ void __launch_bounds__(F8_THREADS) gemm_f6_kernel(const F8Args args) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int KT1 = args.kp / F6_BKE;  // K-steps per segment
+    const int KT = KT1 * args.nseg;    // K-steps per tile (even: kp is a multiple of 256)
+    const int total = args.total_tiles;
+    const int G = gridDim.x;
+    const size_t blockbytes = (size_t)BM * (size_t)(args.kp / 4 * 3);  // one 256-row block of a plane
+
+    const bool isB = wave < 4;  // waves 0-3 fetch B panels, waves 4-7 A panels: six linear 1 KiB pieces each per panel
+    const unsigned dbase = (unsigned)((wave & 3) * 6 * 1024 + lane * 16);  // this lane's byte in piece 0 of the wave; piece i: + 1024 i, clamped to the image
+    unsigned dlast = 0;    // byte offset of the last 16-byte chunk of the panel being fetched
+    const int8_t* gsrc;
+    int gstep = 0;         // bytes between consecutive K-steps of the block: Rp * 96
+    long long gdelta = 0;  // nseg == 2: from the panel of K-step KT1 + j of segment 1's plane to K-step j of segment 2's plane
+    auto uniform = [](const int8_t* ptr) {
+        const unsigned long long v = (unsigned long long)ptr;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (const int8_t*)(((unsigned long long)hi << 32) | lo);
+    };
+    auto rows_pad = [&](int tn) {  // rows of B's block tn in its panel images
+        const int nr = args.n - tn * BN;
+        return nr >= BN ? BN : ((nr + 15) & ~15);
+    };
+#define F6_SET_TILE(vb_)                                                                                                     \
+    do {                                                                                                                     \
+        const TileMap tmap_ = map_tile((vb_), total, args.map);                                                              \
+        const F8Plane pl_ = f8_plane(args, tmap_.plane);                                                                     \
+        const int rp_ = isB ? rows_pad(tmap_.tn) : BM;                                                                       \
+        gstep = rp_ * F6_ROWB;                                                                                               \
+        dlast = (unsigned)(rp_ * F6_ROWB - 16);                                                                              \
+        gsrc = uniform(isB ? args.B + pl_.boff + (size_t)args.planeB[pl_.tt] * args.strideB + (size_t)tmap_.tn * blockbytes   \
+                           : args.A + pl_.boff + (size_t)args.planeA[pl_.tt] * args.strideA + (size_t)tmap_.tm * blockbytes); \
+        gdelta = isB ? ((long long)args.planeB2[pl_.tt] - args.planeB[pl_.tt]) * (long long)args.strideB - (long long)KT1 * gstep \
+                     : ((long long)args.planeA2[pl_.tt] - args.planeA[pl_.tt]) * (long long)args.strideA - (long long)KT1 * gstep; \
+    } while (0)
+#define F6_DMA(src_, q_, stage_)                                                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((src_) + min(dbase + (q_) * 1024u, dlast)), \
+                                     (__attribute__((address_space(3))) void*)((stage_) + ((wave & 3) * 6 + (q_)) * 1024), 16, 0, 0)
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r16 = lane & 15;
+    const int q = lane >> 4;
+    const int ax = (q * BM + wm * 128 + r16) * 16;
+    const int ay = 64 * BM + ((q >> 1) * 2 * BM + 2 * (wm * 128 + r16) + (q & 1)) * 8;
+    constexpr int SC3 = (int)0x82828282u;  // E8M0 scale 2^3 for every block
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    // a fragment = the six operand registers: 16 bytes of the X region (px_: a pointer) + 8 bytes of the Y region (LDS byte address yb_ + constant yo_).
+    // The 8-byte read is inline assembly: written as a load, two fragments' reads fuse into one ds_read2_b64 whose four registers then have to be
+    // waited for and COPIED into the two operand tuples, in the middle of the MFMA stream.  The compiler's waitcnt pass does not see these reads: the
+    // K-step waits for them itself (lgkmcnt(0) at its top and in front of its barrier; LDS operations of a wave return in order).
+#define F6_FRAG(dst_, px_, yb_, yo_)                                                                                         \
+    do {                                                                                                                     \
+        const v4i lo_ = *(const v4i*)(px_);                                                                                  \
+        v2i hi_;                                                                                                             \
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(hi_) : "v"(yb_), "n"(yo_));                                       \
+        dst_ = v6i{lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1]};                                                          \
+    } while (0)
+    const unsigned lds0 = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char*)smem;
+    // (the builtin takes 8-register operands for every format; with cbsz / blgp = 2 the instruction reads the low six -- the upper two are left
+    // undefined so that a fragment costs six registers also where it lives across loop iterations)
+#define F6_MFMA(a_, b_, c_)                                                                                                  \
+    c_ = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(a_, a_, 0, 1, 2, 3, 4, 5, -1, -1),         \
+                                                          __builtin_shufflevector(b_, b_, 0, 1, 2, 3, 4, 5, -1, -1), c_, 2, 2, 0, SC3, 0, SC3)
+
+    auto run = [&]<bool ISB>() {
+        int vb_next = blockIdx.x, kt_next = 0;
+        bool more = true;
+        int fs = 0;  // (panel being fetched) % 3
+        const int8_t* fsrc;
+        char* fdst;
+        F6_SET_TILE(vb_next);
+#define F6_FETCH_ADVANCE()                                                                                                   \
+    do {                                                                                                                     \
+        fs = fs == 2 ? 0 : fs + 1;                                                                                           \
+        if (more && ++kt_next == KT) {                                                                                       \
+            kt_next = 0;                                                                                                     \
+            vb_next += G;                                                                                                    \
+            more = vb_next < total;                                                                                          \
+            if (more) F6_SET_TILE(vb_next);                                                                                  \
+            else kt_next = KT - 1;                                                                                           \
+        }                                                                                                                    \
+    } while (0)
+        // the same step inside the K loop: the state of the tile the stream enters next was prepared at the consumer's tile start
+        const int8_t* gsrcN = nullptr;
+        int gstepN = 0;
+        long long gdeltaN = 0;
+        unsigned dlastN = 0;
+#define F6_FETCH_ADVANCE_LOOP()                                                                                              \
+    do {                                                                                                                     \
+        fs = fs == 2 ? 0 : fs + 1;                                                                                           \
+        if (++kt_next == KT) kt_next = 0, gsrc = gsrcN, gstep = gstepN, gdelta = gdeltaN, dlast = dlastN;                    \
+    } while (0)
+#define F6_FETCH_PTRS()                                                                                                      \
+    do {                                                                                                                     \
+        fsrc = gsrc + (long long)OZ2_HOOK_KSTEP(kt_next) * gstep + (kt_next >= KT1 ? gdelta : 0);                            \
+        fdst = smem + (2 * fs + (ISB ? 1 : 0)) * F6_SLOT;                                                                    \
+    } while (0)
+        // prologue: panels 0 and 1 whole, pieces 0-2 of panel 2
+        F6_FETCH_PTRS();
+#pragma unroll
+        for (int i = 0; i < 6; ++i) F6_DMA(fsrc, i, fdst);
+        F6_FETCH_ADVANCE();
+        F6_FETCH_PTRS();
+#pragma unroll
+        for (int i = 0; i < 6; ++i) F6_DMA(fsrc, i, fdst);
+        F6_FETCH_ADVANCE();
+        F6_FETCH_PTRS();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) F6_DMA(fsrc, i, fdst);
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        v6i bf[4], aL[4], aH[4];
+        int cs = 0;  // (current K-step) % 3
+        const int lead = (3 + KT - 1) / KT;  // tiles between the consumers' tile and the one the fetch stream enters during it (1 for KT >= 4)
+        // the prologue left the stream in tile vb_next; re-base it on (consumer tile, lead): from here on every wrap takes the prepared state
+        // One K-step.  PF_: prefetch the next K-step's first fragments.  Half 1 runs column-major over the B fragments: fragment j of the NEXT K-step is
+        // read into the registers of fragment j as soon as its last four MFMAs are issued (one B set: 128 + 72 fragment registers, room for the rest).
+#define F6_KSTEP(PF_)                                                                                                        \
+    do {                                                                                                                     \
+        const char* curA_ = smem + (2 * cs) * F6_SLOT;                                                                       \
+        const unsigned ycA_ = lds0 + (unsigned)((2 * cs) * F6_SLOT + ay);                                                    \
+        cs = cs == 2 ? 0 : cs + 1;                                                                                           \
+        const char* nxtA_ = smem + (2 * cs) * F6_SLOT;                                                                       \
+        const char* nxtB_ = nxtA_ + F6_SLOT;                                                                                 \
+        const unsigned ynA_ = lds0 + (unsigned)((2 * cs) * F6_SLOT + ay), ynB_ = lds0 + (unsigned)((2 * cs + 1) * F6_SLOT + by); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the fragments read in the previous half (or at the tile's start) */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        if (dma_on) {                                                                                                        \
+            _Pragma("unroll") for (int i = 3; i < 6; ++i) F6_DMA(fsrc, i, fdst);                                             \
+        }                                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) F6_FRAG(aH[i], curA_ + ax + (4 + i) * 256, ycA_, (4 + i) * 256); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                     \
+            const int j = (i & 1) ? 3 - jj : jj;                                                                             \
+            F6_MFMA(aL[i], bf[j], acc[i][j]);                                                                                \
+        }                                                                                                                    \
+        _Pragma("unroll") for (int kk = 0; kk < (OZ2_F6_SGB ? 16 : 0); ++kk) {                                               \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                               \
+            if (kk < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                   \
+            if (kk == 1 || kk == 6 || kk == 11) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                           \
+        }                                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        __builtin_amdgcn_s_barrier();                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        F6_FETCH_ADVANCE_LOOP();                                                                                             \
+        F6_FETCH_PTRS();                                                                                                     \
+        if (dma_on) {                                                                                                        \
+            _Pragma("unroll") for (int i = 0; i < 3; ++i) F6_DMA(fsrc, i, fdst);                                             \
+        }                                                                                                                    \
+        if (PF_) {                                                                                                           \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) F6_FRAG(aL[i], nxtA_ + ax + i * 256, ynA_, i * 256);        \
+        }                                                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \
+            _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) {                                                               \
+                const int i = (j & 1) ? 3 - ii : ii;                                                                         \
+                F6_MFMA(aH[i], bf[j], acc[4 + i][j]);                                                                        \
+            }                                                                                                                \
+            if (PF_) F6_FRAG(bf[j], nxtB_ + bx + j * 256, ynB_, j * 256);                                             \
+        }                                                                                                                    \
+        _Pragma("unroll") for (int kk = 0; kk < (OZ2_F6_SGB ? 16 : 0); ++kk) {                                               \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                               \
+            if (PF_ && kk < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               /* aL: 4 x b128 (+ the asm b64 reads) */ \
+            if (PF_ && (kk & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        /* bf[j]: behind its last MFMA */ \
+            if (kk == 1 || kk == 6 || kk == 11) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                           \
+        }                                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    } while (0)
+        for (int vb = blockIdx.x; vb < total; vb += G) {
+            const TileMap tmap = map_tile(vb, total, args.map);
+            {   // state of the tile the fetch stream enters during this tile (none left: the current one again, into slots nobody reads)
+                const int8_t* gs_ = gsrc;
+                const int gt_ = gstep;
+                const long long gd_ = gdelta;
+                const unsigned dl_ = dlast;
+                const int vbn_ = vb + lead * G;
+                if (vbn_ < total) F6_SET_TILE(vbn_);
+                gsrcN = gsrc, gstepN = gstep, gdeltaN = gdelta, dlastN = dlast;
+                gsrc = gs_, gstep = gt_, gdelta = gd_, dlast = dl_;
+            }
+            const int rpB = rows_pad(tmap.tn);
+            const int bx = (q * rpB + wn * 64 + r16) * 16;
+            const int by = 64 * rpB + ((q >> 1) * 2 * rpB + 2 * (wn * 64 + r16) + (q & 1)) * 8;
+            const bool dma_on = OZ2_HOOK_DMA_ON(vb == (int)blockIdx.x);  // (laboratory hook: always true in the product)
+            v4f acc[8][4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
+            {  // the tile's first fragments, exposed (their panel landed before the last barrier)
+                const char* curA = smem + (2 * cs) * F6_SLOT;
+                const char* curB = curA + F6_SLOT;
+                const unsigned ybA_ = lds0 + (unsigned)((2 * cs) * F6_SLOT + ay), ybB_ = lds0 + (unsigned)((2 * cs + 1) * F6_SLOT + by);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) F6_FRAG(bf[j], curB + bx + j * 256, ybB_, j * 256);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) F6_FRAG(aL[i], curA + ax + i * 256, ybA_, i * 256);
+            }
+            for (int kt = 0; kt + 1 < KT; ++kt) F6_KSTEP(true);
+            F6_KSTEP(false);
+            const int i0 = tmap.tm * BM + wm * 128, j0 = tmap.tn * BN + wn * 64;
+            const F8Plane pl = f8_plane(args, tmap.plane);
+            f8_epilogue_mod<EPI>(acc, args, pl, i0, j0, lane);
+        }
+    };
+    if (isB) run.template operator()<true>();
+    else run.template operator()<false>();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
+#undef F6_SET_TILE
+#undef F6_DMA
+#undef F6_FRAG
+#undef F6_MFMA
+#undef F6_KSTEP
+#undef F6_FETCH_PTRS
+#undef F6_FETCH_ADVANCE
+#undef F6_FETCH_ADVANCE_LOOP
+}
+
+#ifdef OZ2_F6_PINGPONG  // the first form (round 5, kept for A/B builds: tools/build_probes.sh SRC=oz2_gemm_f6 pp="-DOZ2_F6_PINGPONG"): ping-pong LOAD / MFMA segments as in oz2_gemm_f8.hip, five slots
+template <int EPI>
+__global__ void __launch_bounds__(F8_THREADS) gemm_f6_pingpong_kernel(const F8Args args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -223,6 +471,8 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f6_kernel(const F8Args args) 
 #undef F6_FETCH_ADVANCE
 }
 
+#endif
+
 static int num_cus() {
     static int n = 0;
     if (!n) {
@@ -239,6 +489,9 @@ template <int EPI> static hipError_t launch(hipStream_t stream, F8Args& a, int p
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) dev_ = 0;
     if (!attr_set_dev[dev_].load(std::memory_order_acquire)) {
+#ifdef OZ2_F6_PINGPONG
+#define gemm_f6_kernel gemm_f6_pingpong_kernel
+#endif
         hipError_t e = hipFuncSetAttribute((const void*)gemm_f6_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, F6_NSLOT * F6_SLOT);
         if (e != hipSuccess) return e;
         attr_set_dev[dev_].store(true, std::memory_order_release);

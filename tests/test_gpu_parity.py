@@ -738,6 +738,8 @@ def test_fp8_backend_fp6_images_and_e4m3_planes_agree(dtype, N, fast, monkeypatc
     """FP8 backend, round 5: the residue planes are FP6 panel images of the same integers (gemmul8_layout.lo_format == 1, n >= 64;
     csrc/oz2_gemm_f6.hip) unless GEMMUL8_FP8_PLANES=e4m3 keeps the reference's e4m3 bytes.  Both encodings must be bit-exact against the
     oracle -- planes, C_mid and C -- including a last row block of B that is not a multiple of 16 rows and a second tile column."""
+    import gemmul8_amd as g
+    import gpu_util as gu
     rng = np.random.default_rng(606)
     m, n, k = 300, 333, 520
     A, B = rand((m, k), dtype, rng), rand((k, n), dtype, rng)
