@@ -173,16 +173,23 @@ def run_other_config(args):
     errn = float(np.max(np.abs(gotn - ref) / np.abs(ref)))
     del Cn
     gcnt = {3: 3 * N + (0 if mode else 1), 5: 3 * N + (0 if mode else 5)}[args.config]  # complex bounds: K-concatenated 2+3 units
+    # FP8 backend: the residue GEMMs multiply the backend's integer pieces (|v| <= 16) as FP6 e2m3 codes (csrc/oz2_gemm_f6.hip: same values, same
+    # bits out, CDNA4 runs FP6 at the FP4 rate) unless GEMMUL8_FP8_PLANES=e4m3 keeps the e4m3 planes -- the roofline is priced against the format used
+    f6 = be == g.FP8 and os.environ.get("GEMMUL8_FP8_PLANES", "fp6")[:1] != "e"
+    lp_peak = 10000.0 if f6 else 5000.0  # dense MFMA peak of the operand format, TOP/s (MI355X_MICROARCH.md: FP6/FP4 ~10 PF, FP8/INT8 ~5 PF)
+    lp_dtype = ("fp6 e2m3 MFMA on the FP8 backend's integer pieces (exact; f32 accumulate) + e4m3 bound GEMM + f64 CRT" if f6 else
+                "fp8 e4m3 MFMA (f32 accumulate) + f64 CRT" if be == g.FP8 else "int8 MFMA (i32 accumulate) + f64 CRT")
     out = {"metric": f"emulated {name} TFLOPS (config {args.config})", "value": cflops * 2.0 * n ** 3 / ms * 1e-9, "unit": "TFLOPS",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
-           "vs_baseline": None, "dtype": "fp8 e4m3 MFMA (f32 accumulate) + f64 CRT" if be == g.FP8 else "int8 MFMA (i32 accumulate) + f64 CRT",
+           "vs_baseline": None, "dtype": lp_dtype,
            "data": "synthetic U(-0.5,0.5)", "config": {"workload": f"{name} {n}^3, moduli={N}, {'FP8' if be == g.FP8 else 'INT8'} backend, "
                                                                       f"{'fast' if mode else 'accurate'} mode, op N/N, alpha=1, beta=0"},
            "phase_ms": {"scaling": tm[0] * 1e-6, "lowprec_gemm": tm[1] * 1e-6, "requantise": tm[2] * 1e-6, "inverse_scaling": tm[3] * 1e-6},
            "roofline": {"bound": "mfma", "kernel": "the residue GEMMs of the low-precision phase (3 per modulus; the accurate mode's bound GEMMs "
                                                        "run inside the scaling phase and are not counted here)",
-                        "achieved": (3 * N) * 2.0 * n ** 3 / (tm[1] * 1e-6) * 1e-9, "peak": 5000.0,
-                        "frac": (3 * N) * 2.0 * n ** 3 / (tm[1] * 1e-6) * 1e-9 / 5000.0, "traffic": None, "traffic_measured_in_run": False,
+                        "achieved": (3 * N) * 2.0 * n ** 3 / (tm[1] * 1e-6) * 1e-9, "peak": lp_peak,
+                        "frac": (3 * N) * 2.0 * n ** 3 / (tm[1] * 1e-6) * 1e-9 / lp_peak, "traffic": None, "traffic_measured_in_run": False,
+                        "sustained_mfma_on_backend_data_TOPs": 6816.0 if f6 else 4487.0 if be == g.FP8 else 3969.0,
                         "unit": "TOP/s", "lowprec_units_of_2mnk_whole_call": gcnt, "lowprec_phase_ms": tm[1] * 1e-6},
            "max_rel_err": err,
            "native_same_gpu": {"lib": f"rocBLAS/hipBLASLt {name} via torch.matmul", "value": cflops * 2.0 * n ** 3 / nat_ms * 1e-9,

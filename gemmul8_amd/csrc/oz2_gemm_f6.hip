@@ -181,8 +181,12 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f6_kernel(const F8Args args) 
         int cs = 0;  // (current K-step) % 3
         const int lead = (3 + KT - 1) / KT;  // tiles between the consumers' tile and the one the fetch stream enters during it (1 for KT >= 4)
         // the prologue left the stream in tile vb_next; re-base it on (consumer tile, lead): from here on every wrap takes the prepared state
-        // One K-step.  PF_: prefetch the next K-step's first fragments.  Half 1 runs column-major over the B fragments: fragment j of the NEXT K-step is
-        // read into the registers of fragment j as soon as its last four MFMAs are issued (one B set: 128 + 72 fragment registers, room for the rest).
+        // One K-step.  PF_: prefetch the next K-step's first fragments.  The instruction stream is cut into scheduling regions of four MFMAs (one row of
+        // half 0, one column of half 1) with the reads and the DMA piece that go beside them; the ORDER of the regions' LDS reads is what the explicit
+        // waits count on (LDS operations of a wave return in order):  half 1 issues aL[0] bf[0] aL[1] bf[1] aL[2] bf[2] aL[3] bf[3] (two reads each;
+        // bf[j] into the registers of the fragment whose last four MFMAs were just issued), so the first row of the next half 0 needs
+        // lgkmcnt(12) / (8) / (4) / (0) in front of its four MFMAs -- it starts when bf[0] has landed, not when the read behind the previous
+        // K-step's last MFMA has.  Rows 1-3 carry the reads of aH (rows 64-127) and DMA pieces 3-5; lgkmcnt(0) in front of the barrier.
 #define F6_KSTEP(PF_)                                                                                                        \
     do {                                                                                                                     \
         const char* curA_ = smem + (2 * cs) * F6_SLOT;                                                                       \
@@ -191,48 +195,44 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f6_kernel(const F8Args args) 
         const char* nxtA_ = smem + (2 * cs) * F6_SLOT;                                                                       \
         const char* nxtB_ = nxtA_ + F6_SLOT;                                                                                 \
         const unsigned ynA_ = lds0 + (unsigned)((2 * cs) * F6_SLOT + ay), ynB_ = lds0 + (unsigned)((2 * cs + 1) * F6_SLOT + by); \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the fragments read in the previous half (or at the tile's start) */ \
+        /* ---- half 0, row 0 */                                                                                             \
+        asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(bf[0]), "+v"(aL[0]));                                                    \
+        F6_MFMA(aL[0], bf[0], acc[0][0]);                                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bf[1]));                                                                  \
+        F6_MFMA(aL[0], bf[1], acc[0][1]);                                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bf[2]));                                                                  \
+        F6_MFMA(aL[0], bf[2], acc[0][2]);                                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[3]), "+v"(aL[1]), "+v"(aL[2]), "+v"(aL[3]));                           \
+        F6_MFMA(aL[0], bf[3], acc[0][3]);                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
-        if (dma_on) {                                                                                                        \
-            _Pragma("unroll") for (int i = 3; i < 6; ++i) F6_DMA(fsrc, i, fdst);                                             \
+        /* ---- half 0, rows 1-3 */                                                                                          \
+        _Pragma("unroll") for (int i = 1; i < 4; ++i) {                                                                      \
+            if (dma_on) F6_DMA(fsrc, 2 + i, fdst);                                                                           \
+            if (i == 1) F6_FRAG(aH[0], curA_ + ax + 4 * 256, ycA_, 4 * 256);                                                 \
+            F6_FRAG(aH[i], curA_ + ax + (4 + i) * 256, ycA_, (4 + i) * 256);                                                 \
+            _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                               \
+                const int j = (i & 1) ? 3 - jj : jj;                                                                         \
+                F6_MFMA(aL[i], bf[j], acc[i][j]);                                                                            \
+            }                                                                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                               \
         }                                                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) F6_FRAG(aH[i], curA_ + ax + (4 + i) * 256, ycA_, (4 + i) * 256); \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                     \
-            const int j = (i & 1) ? 3 - jj : jj;                                                                             \
-            F6_MFMA(aL[i], bf[j], acc[i][j]);                                                                                \
-        }                                                                                                                    \
-        _Pragma("unroll") for (int kk = 0; kk < (OZ2_F6_SGB ? 16 : 0); ++kk) {                                               \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                               \
-            if (kk < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                   \
-            if (kk == 1 || kk == 6 || kk == 11) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                           \
-        }                                                                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                                   \
         asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
         __builtin_amdgcn_s_barrier();                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
         F6_FETCH_ADVANCE_LOOP();                                                                                             \
         F6_FETCH_PTRS();                                                                                                     \
-        if (dma_on) {                                                                                                        \
-            _Pragma("unroll") for (int i = 0; i < 3; ++i) F6_DMA(fsrc, i, fdst);                                             \
-        }                                                                                                                    \
-        if (PF_) {                                                                                                           \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) F6_FRAG(aL[i], nxtA_ + ax + i * 256, ynA_, i * 256);        \
-        }                                                                                                                    \
+        /* ---- half 1 */                                                                                                    \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \
+            if (dma_on && j < 3) F6_DMA(fsrc, j, fdst);                                                                      \
+            if (PF_) F6_FRAG(aL[j], nxtA_ + ax + j * 256, ynA_, j * 256);                                                    \
             _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) {                                                               \
                 const int i = (j & 1) ? 3 - ii : ii;                                                                         \
                 F6_MFMA(aH[i], bf[j], acc[4 + i][j]);                                                                        \
             }                                                                                                                \
-            if (PF_) F6_FRAG(bf[j], nxtB_ + bx + j * 256, ynB_, j * 256);                                             \
+            if (PF_) F6_FRAG(bf[j], nxtB_ + bx + j * 256, ynB_, j * 256);                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                               \
         }                                                                                                                    \
-        _Pragma("unroll") for (int kk = 0; kk < (OZ2_F6_SGB ? 16 : 0); ++kk) {                                               \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                               \
-            if (PF_ && kk < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               /* aL: 4 x b128 (+ the asm b64 reads) */ \
-            if (PF_ && (kk & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        /* bf[j]: behind its last MFMA */ \
-            if (kk == 1 || kk == 6 || kk == 11) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                           \
-        }                                                                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                                   \
     } while (0)
         for (int vb = blockIdx.x; vb < total; vb += G) {
             const TileMap tmap = map_tile(vb, total, args.map);
@@ -262,9 +262,11 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f6_kernel(const F8Args args) 
                 const char* curB = curA + F6_SLOT;
                 const unsigned ybA_ = lds0 + (unsigned)((2 * cs) * F6_SLOT + ay), ybB_ = lds0 + (unsigned)((2 * cs + 1) * F6_SLOT + by);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) F6_FRAG(bf[j], curB + bx + j * 256, ybB_, j * 256);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) F6_FRAG(aL[i], curA + ax + i * 256, ybA_, i * 256);
+                for (int j = 0; j < 4; ++j) {  // (the K-step's staged waits count on this order: aL[0] bf[0] aL[1] bf[1] ...)
+                    F6_FRAG(aL[j], curA + ax + j * 256, ybA_, j * 256);
+                    F6_FRAG(bf[j], curB + bx + j * 256, ybB_, j * 256);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             for (int kt = 0; kt + 1 < KT; ++kt) F6_KSTEP(true);
             F6_KSTEP(false);

@@ -616,6 +616,24 @@ template <typename T, int MODE>
 __device__ __forceinline__ void stage_kmajor_body(const StageArgs& a, const unsigned bid) {
     using E = ET<T>;
     using U = typename E::U;
+    if constexpr (MODE == MODE_MOD) {
+        if (a.f6) {
+            // FP6 panel images: one workgroup per (8 rows, one 128-element K-step), the K-step index fastest: the eight rows' 16-byte X slots and
+            // 8-byte Y slot pairs of a K group are adjacent in the image, so every plane leaves as complete 128-byte lines (row by row, a K-step's
+            // 96 bytes of one row are scattered over six lines that seven other rows complete later)
+            const unsigned nks = (unsigned)(a.kp / 128);
+            const unsigned rg = bid / nks;
+            const size_t row = (size_t)rg * 8 + (threadIdx.x >> 5);
+            const size_t k0 = (size_t)(bid - rg * nks) * 128 + (size_t)(threadIdx.x & 31) * 4;
+            if (row >= a.rows) return;  // (uniform over the 32 lanes of a row)
+            const T* x = (const T*)((const char*)a.X + OZ2_ZX) + row * a.ld;
+            const int s = -(int)((const int16_t*)((const char*)a.sft + OZ2_ZW))[row];
+            T v[4];
+            load4<T>(x, k0, a.k, v);
+            emit4<T, MODE>(a, row, k0, v, s);
+            return;
+        }
+    }
     if constexpr (MODE == MODE_MOD && OZ2_STAGE_KCHUNK && sizeof(T) <= 8) {  // (16-byte elements measured 4 % better with the row loop)
         // quantise: one workgroup per 1024-wide k chunk of a row, the chunk index fastest: the workgroups in flight walk through
         // memory together (one row after the other) instead of streaming ~2000 rows at once
@@ -903,6 +921,7 @@ template <typename T> __global__ void __launch_bounds__(256) amax_strided_kernel
 
 template <typename T, int MODE> static size_t stage_blocks(bool kmajor, const StageArgs& a) {
     if (a.rows == 0) return 0;
+    if (kmajor && MODE == MODE_MOD && a.f6) return ((a.rows + 7) / 8) * (a.kp / 128);
     if (kmajor) return a.rows * ((MODE == MODE_MOD && OZ2_STAGE_KCHUNK && sizeof(T) <= 8) ? (a.kp + 1023) / 1024 : 1);
     return (a.kp / StageTile<T>::TK) * ((a.rows + StageTile<T>::TR - 1) / StageTile<T>::TR);
 }

@@ -102,3 +102,31 @@ def test_fp8_kernels_registers_and_scratch(f8):
         assert vg <= 256 and sc == 0, (n, vg, sc)   # 8 waves per CU = 2 per SIMD
         for b in _mfma_blocks(blocks):
             assert not any("scratch_" in l for l in b), n
+
+
+@pytest.fixture(scope="module")
+def f6():
+    return _kernels(_asm("oz2_gemm_f6.hip"))
+
+
+def test_fp6_kernels_registers_scratch_and_fragment_reads(f6):
+    """The FP6 residue-GEMM kernel (round 5): 8 self-pipelined waves of 256 registers.  Its K-step block -- 32 MFMAs around the one barrier -- must
+    hold no spill traffic, every MFMA must read six-register fragments (cbsz = blgp = 2), and no two 8-byte fragment reads may fuse into a
+    ds_read2_b64 (its four registers would have to be waited for and copied in the middle of the MFMA stream: the reads are inline assembly)."""
+    ks = {n: v for n, v in f6.items() if "gemm_f6_kernel" in n}
+    assert len(ks) == 3, sorted(ks)   # EPI_PART, EPI_FINAL, EPI_FINAL_CPLX
+    for n, (vg, sc, blocks) in ks.items():
+        assert vg <= 256, (n, vg)
+        # the last K-step of a tile is scheduled together with the head of the epilogue, which keeps a few values of the tile in scratch (per tile, not per K-step)
+        assert sc <= (0 if "ILi0E" in n else 256), (n, sc)
+        flat = [l for b in blocks for l in b]
+        assert not any("ds_read2_b64" in l for l in flat), n
+        mf = [l for l in flat if "v_mfma_scale" in l]
+        assert mf and all("cbsz:2 blgp:2" in l for l in mf), n
+        for l in mf:
+            a, b = re.findall(r"v\[(\d+):(\d+)\]", l)[1:3]
+            assert int(a[1]) - int(a[0]) == 5 and int(b[1]) - int(b[0]) == 5, (n, l)
+        steady = [b for b in blocks if sum("v_mfma" in l for l in b) >= 32 and any(l.startswith("s_barrier") for l in b) and not any("scratch_" in l for l in b)]
+        assert steady, (n, "no clean K-step block")
+        for b in steady:
+            assert sum(l.startswith("s_barrier") for l in b) == 1, n   # ONE workgroup barrier per K-step
