@@ -392,6 +392,10 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     }
 }
 
+#ifdef OZ2_LAB_SELFPIPE  // laboratory build only (tools/build_probes.sh sp="-DOZ2_LAB_SELFPIPE=1"): the self-pipelined 8-wave form of the residue GEMM
+#include "../../tools/experiments/gemm_i8_selfpipe.inc"
+#endif
+
 static void fill_common(GemmArgs& a, size_t kp, size_t m, size_t n) {
     a.kp = (int)kp;
     a.m = (int)m;
@@ -462,6 +466,23 @@ template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int
 #ifdef OZ2_LAB_SHORTK  // laboratory build only (tools/experiments/shortk): the half-tile ping-pong kernel for padded k <= OZ2_LAB_SHORTK
     if constexpr (EPI != EPI_MAX) {
         if (a.nseg == 1 && a.kp <= OZ2_LAB_SHORTK) return launch_gemm_i8_shortk(stream, a, EPI);
+    }
+#endif
+#ifdef OZ2_LAB_SELFPIPE
+    if constexpr (EPI != EPI_MAX) {
+        if (a.nseg == 1) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)gemm_i8_selfpipe_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_i8_selfpipe_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES);
+                attr_set = true;
+            }
+            int grid = num_cus() & ~7;
+            if (a.total_tiles < grid) grid = a.total_tiles;
+            if (a.acc0 == 0) hipLaunchKernelGGL((gemm_i8_selfpipe_kernel<EPI, true>), dim3(grid), dim3(512), RING_LDS_BYTES, stream, a);
+            else hipLaunchKernelGGL((gemm_i8_selfpipe_kernel<EPI, false>), dim3(grid), dim3(512), RING_LDS_BYTES, stream, a);
+            return hipGetLastError();
+        }
     }
 #endif
     if constexpr (EPI != EPI_MAX) {
