@@ -93,6 +93,7 @@ static Knobs parse_knobs() {
     if (num("GEMMUL8_CPLX_BOUND_LAUNCHES", 1) == 2) k.cplx_bound_launches = 2;
     if (const int c = num("GEMMUL8_CPLX_CHUNK", 0); c >= 1) k.cplx_chunk = c;
     if (const char* e = getenv("GEMMUL8_CRT_KERNEL")) k.crt_kernel = e[0] == 'd' ? 1 : e[0] == 'r' ? 2 : 0;
+    if (const int c = num("GEMMUL8_GEMM_CUS", 0); c >= 8) k.gemm_cus = c & ~7;
     if (const char* e = getenv("GEMMUL8_FP8_PLANES")) k.fp8_planes = e[0] == 'e' ? 1 : 0;
     if (const char* e = getenv("GEMMUL8_MAP_COLBLOCK"); e && *e) k.map_colblock = atoi(e) > 0 ? atoi(e) : 0;
     return k;

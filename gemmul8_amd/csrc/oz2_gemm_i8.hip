@@ -438,6 +438,7 @@ static hipError_t launch_sched(hipStream_t stream, GemmArgs& a, const std::condi
     // Measured interleaved against one-workgroup-per-tile launches of the same kernel (tools/gemm_ab.py, 8192 x 8192 x k,
     // 14 planes): 13 % faster at k = 256, 7 % at k = 2048, 1 % at k = 8192.
     int grid = num_cus() & ~7;
+    if (const int want = knobs().gemm_cus; want > 0 && want < grid) grid = want;  // measurement switch (oz2_knobs.hpp): same results
     if (grid <= 0) grid = 8;
     if (a.total_tiles < grid) grid = a.total_tiles;
     hipLaunchKernelGGL((gemm_i8_kernel<EPI, KBAR, FUSE, SMALLK>), dim3(grid), dim3(WS_THREADS), RING_LDS_BYTES, stream, a, crt);
