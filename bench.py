@@ -298,6 +298,8 @@ def plan_model(name, world, N, n, ph, grid):
     measured on an 8-GPU node can be held against a prediction made before it existed.  Assumptions (all stated in the JSON):
       * every kernel scales with the share of rows / columns / moduli a rank works on (no efficiency loss on smaller problems);
       * bounds phase = 30 % A side (amax + extract), 17 % B side (extract), 53 % bound GEMM; quantise = 52 % A, 48 % B (DESIGN.md 3);
+      * moduli plan: the residue exchange of the first of two plane groups overlaps the second group's GEMMs (the A-side extract of the bounds
+        phase is still replicated on every rank: 0.30 b);
       * an all-reduce(MAX) of 4 (m + n) bytes: 0.05 ms; point-to-point: every xGMI peer link carries 45 GB/s per direction, all peers at
         once; reduce-scatter of FP64 partials: ring over min(G - 1, 7) links in parallel at the same rate."""
     G = world
@@ -311,8 +313,13 @@ def plan_model(name, world, N, n, ph, grid):
                  "allreduce": ar, "exchange": 0.0}
     elif name == "moduli":
         out_bytes = (G - 1) / G * mr * n * n                    # INT8 residue blocks this rank sends; (G - 1) peers in parallel
-        terms = {"bounds": b * (0.30 + 0.17 / G + 0.53 / G), "quantise": q * mr / N, "lowprec_gemm": gm * mr / N, "crt": cr / G, "allreduce": ar,
-                 "exchange": (out_bytes / max(1, G - 1)) / link * 1e3 if G > 1 else 0.0}
+        # round 5: the rank's planes go out in two groups, the exchange of the first group travels beside the GEMMs of the second (csrc/oz2_dist.cpp):
+        # only what the exchange takes beyond half of the GEMM time is exposed, plus the second group's own exchange (half of the bytes)
+        gm_r = gm * mr / N
+        ex = (out_bytes / max(1, G - 1)) / link * 1e3 if G > 1 else 0.0
+        ex_exposed = (max(0.0, ex / 2 - gm_r / 2) + ex / 2) if mr >= 2 else ex
+        terms = {"bounds": b * (0.30 + 0.17 / G + 0.53 / G), "quantise": q * mr / N, "lowprec_gemm": gm_r, "crt": cr / G, "allreduce": ar,
+                 "exchange": ex_exposed}
     else:  # fp64sum
         part_bytes = (mr + 16.0) * n * n                        # partial CRT: read mr residue planes, write two double planes
         rs_bytes = (G - 1) / G * 16.0 * n * n

@@ -321,6 +321,12 @@ struct gemmul8_dist_plan {
     }
     bool hip_engine = true;
     bool part_clean = false;  // the padding columns of `part` (world * cw > n) are zeroed once, on the first call's stream
+    // moduli plan: the rank's planes are multiplied in `groups` groups; the residue exchange of group j runs on a second stream (HIP engine) behind an
+    // event while the GEMMs of group j + 1 run on the caller's stream.  GEMMUL8_DIST_GROUPS (default 2; 1 = one exchange behind all GEMMs, the
+    // round-4 order) must be the same on every rank: group j of sender s is split_range(its moduli, groups, j) on both sides of every pair.
+    int groups = 2;
+    hipStream_t xstream = nullptr;
+    hipEvent_t xev[9] = {};  // [0 .. groups): GEMM group done (caller's stream); [8]: last exchange done (exchange stream)
     char* stage_send = nullptr;  // allgather_c staging (allocated on first use)
     char* stage_recv = nullptr;
     size_t bytes = 0;
@@ -435,6 +441,7 @@ int gemmul8_dist_create(const gemmul8_comm* comm, const gemmul8_dist_engine* eng
     P->comm = *comm;
     P->eng = engine ? *engine : kHipEngine;
     P->hip_engine = engine == nullptr;
+    if (const char* e = getenv("GEMMUL8_DIST_GROUPS"); e && *e) P->groups = std::max(1, std::min(8, atoi(e)));
     P->kind = kind, P->dtype = dtype, P->backend = backend, P->opA = op_A, P->opB = op_B, P->fast = fastmode ? 1 : 0;
     P->m = m, P->n = n, P->k = k, P->N = N;
     const bool cplx = dtype >= 2;
@@ -494,6 +501,9 @@ void gemmul8_dist_destroy(gemmul8_dist_plan* P) {
     if (!P) return;
     for (void* p : {(void*)P->work, (void*)P->mx, (void*)P->recv, (void*)P->part, (void*)P->red, (void*)P->stage_send, (void*)P->stage_recv})
         if (p) P->eng.release(p);
+    if (P->xstream) (void)hipStreamDestroy(P->xstream);
+    for (hipEvent_t e : P->xev)
+        if (e) (void)hipEventDestroy(e);
     delete P;
 }
 
@@ -610,37 +620,64 @@ int gemmul8_dist_gemm(gemmul8_dist_plan* P, void* stream, const void* alpha, con
         }
     }
     OZ2_RC(E.scale_finish(stream, P->dtype, P->backend, P->opA, P->opB, P->m, P->n, P->k, A, lda, B, ldb, N, P->fast, t0, t1, L, 0, 0));
-    if (P->ev_begin && P->hip_engine) (void)hipEventRecord((hipEvent_t)P->ev_begin, (hipStream_t)stream);
-    OZ2_RC(E.lowprec_gemm(stream, P->dtype, P->backend, P->m, P->n, P->k, N, t0, t1, L));
-    if (P->ev_end && P->hip_engine) (void)hipEventRecord((hipEvent_t)P->ev_end, (hipStream_t)stream);
     const size_t ncols = P->cols.size();
     char* Cs = (char*)C + P->cols.b * ldc * esz;
     const char* Cmid = (const char*)L->C_mid;
     const size_t mid = P->mid;
 
     if (P->kind == GEMMUL8_DIST_MODULI) {
-        // residue exchange: plane t, columns of rank s -> rank s, into its [t][cols_s][mp] buffer; both sides walk the planes in
-        // ascending order so the grouped sends and receives of a pair match one to one
+        // Residue exchange, pipelined behind the GEMMs (round 5): the rank's planes go out in `groups` groups; as soon as the GEMMs of group j
+        // are done (an event on the caller's stream) its residue blocks travel on the plan's exchange stream -- plane t, columns of rank s ->
+        // rank s, into its [t][cols_s][mp] buffer -- while the GEMMs of group j + 1 run.  Both sides of a pair walk a sender's planes in
+        // ascending order and cut them into the same groups, so the grouped sends and receives match one to one, call by call.  The CRT (reference
+        // order over all N planes of the rank's columns) waits for the last exchange.  A non-HIP engine (the CPU test engine) runs the same
+        // sequence on its one stream.
         const size_t slot = ncols * mp * mid;
-        std::vector<gemmul8_p2p_op> ops;
-        for (int s = 0; s < world; ++s) {
-            const Range sc = P->cols_of(s), st = split_range(N, world, s);
-            if (s == rank) {
-                for (unsigned t = t0; t < t1; ++t) OZ2_RC(E.copy(P->recv + t * slot, Cmid + (t * L->sizeC + sc.b * mp) * mid, slot, stream));
-                continue;
-            }
-            for (unsigned t = t0; t < t1 && sc.size(); ++t)
-                ops.push_back({(void*)(Cmid + (t * L->sizeC + sc.b * mp) * mid), sc.size() * mp * mid, s, 1});
-            for (size_t t = st.b; t < st.e && ncols; ++t) ops.push_back({P->recv + t * slot, slot, s, 0});
+        const int NG = world > 1 ? P->groups : 1;
+        const bool two_streams = P->hip_engine && world > 1 && NG > 1;
+        if (two_streams && !P->xstream) {
+            if (hipStreamCreateWithFlags(&P->xstream, hipStreamNonBlocking) != hipSuccess) return GEMMUL8_E_INTERNAL;
+            for (int i = 0; i < 9; ++i)
+                if (hipEventCreateWithFlags(&P->xev[i], hipEventDisableTiming) != hipSuccess) return GEMMUL8_E_INTERNAL;
         }
-        if (world > 1) {
-            P->mark(2, stream);
-            OZ2_RC(X.sendrecv(X.ctx, (int)ops.size(), ops.data(), stream));
-            P->mark(3, stream);
+        void* xs = two_streams ? (void*)P->xstream : stream;
+        if (P->ev_begin && P->hip_engine) (void)hipEventRecord((hipEvent_t)P->ev_begin, (hipStream_t)stream);
+        for (int j = 0; j < NG; ++j) {
+            const Range gj = split_range(P->mods.size(), NG, j);
+            const unsigned a = t0 + (unsigned)gj.b, b = t0 + (unsigned)gj.e;
+            if (b > a) OZ2_RC(E.lowprec_gemm(stream, P->dtype, P->backend, P->m, P->n, P->k, N, a, b, L));
+            if (j == NG - 1 && P->ev_end && P->hip_engine) (void)hipEventRecord((hipEvent_t)P->ev_end, (hipStream_t)stream);
+            if (two_streams) {
+                if (hipEventRecord(P->xev[j], (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(P->xstream, P->xev[j], 0) != hipSuccess) return GEMMUL8_E_INTERNAL;
+            }
+            std::vector<gemmul8_p2p_op> ops;
+            for (int s = 0; s < world; ++s) {
+                const Range sc = P->cols_of(s), st = split_range(N, world, s);
+                if (s == rank) {
+                    for (unsigned t = a; t < b; ++t) OZ2_RC(E.copy(P->recv + t * slot, Cmid + (t * L->sizeC + sc.b * mp) * mid, slot, xs));
+                    continue;
+                }
+                for (unsigned t = a; t < b && sc.size(); ++t)
+                    ops.push_back({(void*)(Cmid + (t * L->sizeC + sc.b * mp) * mid), sc.size() * mp * mid, s, 1});
+                const Range sg = split_range(st.size(), NG, j);  // group j of sender s
+                for (size_t t = st.b + sg.b; t < st.b + sg.e && ncols; ++t) ops.push_back({P->recv + t * slot, slot, s, 0});
+            }
+            if (world > 1) {
+                if (j == 0) P->mark(2, xs);
+                OZ2_RC(X.sendrecv(X.ctx, (int)ops.size(), ops.data(), xs));
+                if (j == NG - 1) P->mark(3, xs);
+            }
+        }
+        if (two_streams) {
+            if (hipEventRecord(P->xev[8], P->xstream) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, P->xev[8], 0) != hipSuccess) return GEMMUL8_E_INTERNAL;
         }
         if (!ncols) return GEMMUL8_OK;
         return E.crt(stream, P->dtype, P->backend, N, P->m, ncols, P->recv, mp, ncols * mp, L->sftA, L->sftB + P->cols.b, alpha, beta, Cs, ldc);
     }
+
+    if (P->ev_begin && P->hip_engine) (void)hipEventRecord((hipEvent_t)P->ev_begin, (hipStream_t)stream);
+    OZ2_RC(E.lowprec_gemm(stream, P->dtype, P->backend, P->m, P->n, P->k, N, t0, t1, L));
+    if (P->ev_end && P->hip_engine) (void)hipEventRecord((hipEvent_t)P->ev_end, (hipStream_t)stream);
 
     // ---- FP64 partial sums + reduce-scatter(sum)
     const size_t half = P->cw * mp * P->comps;  // doubles per (hi | lo) plane of one rank's column block

@@ -158,8 +158,22 @@ def test_moduli_plan_bit_identical(world, N, fast, n):
     the engine poisons every plane outside the rank's moduli, so a result equal to the oracle proves they are never read."""
     _, same, calls = _run(world, "moduli", N, fast, 19, n, 37)
     assert same, "moduli-sharded result differs from the single-process oracle"
-    lp = [c for c in calls if c[0] == "lowprec"][0]
-    assert (lp[3], lp[4]) == split_range(N, world, 0)
+    # rank 0 multiplies exactly its share, in ascending groups (round 5: the exchange of a group travels while the next group multiplies)
+    lp = [(c[3], c[4]) for c in calls if c[0] == "lowprec"]
+    t0, t1 = split_range(N, world, 0)
+    assert lp and lp[0][0] == t0 and lp[-1][1] == t1 and all(a[1] == b[0] for a, b in zip(lp, lp[1:])), lp
+
+
+@pytest.mark.parametrize("groups", [1, 2, 3])
+def test_moduli_plan_exchange_groups(groups, monkeypatch):
+    """GEMMUL8_DIST_GROUPS: the rank's planes go out in 1 (the round-4 order), 2 (default) or 3 groups, each followed by its grouped send / recv;
+    every rank cuts every sender's planes the same way (world 4, N = 14: 4 + 4 + 3 + 3 planes, so the groups differ from rank to rank) and the
+    result stays bit-identical."""
+    monkeypatch.setenv("GEMMUL8_DIST_GROUPS", str(groups))
+    _, same, calls = _run(4, "moduli", 14, False, 19, 11, 37)
+    assert same
+    lp = [(c[3], c[4]) for c in calls if c[0] == "lowprec"]
+    assert len(lp) == groups and lp[0][0] == 0 and lp[-1][1] == 4, lp
 
 
 def test_moduli_plan_complex_transposed():

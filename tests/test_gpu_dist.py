@@ -121,6 +121,54 @@ def test_fp64sum_variant_mismatch_count(typ, N, fast):
     assert nbad <= 0.5 * total
 
 
+def _overlap_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gemmul8_amd as g
+        from gemmul8_amd import dist as gd
+        torch.cuda.set_device(0)
+        gen = torch.Generator(device="cuda").manual_seed(9)
+        m = n = k = 2048
+        A = torch.rand((k, m), generator=gen, dtype=torch.float64, device="cuda") - 0.5
+        B = torch.rand((n, k), generator=gen, dtype=torch.float64, device="cuda") - 0.5
+        Cm = torch.zeros((n, m), dtype=torch.float64, device="cuda")
+        pl = gd.DistGemm(gd.TorchTransport(device=True), "moduli", g.D, g.INT8, m, n, k, 14)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        for e in ev:
+            e.record()   # (the handles exist after the first record)
+        pl.set_events(ev[0], ev[1])
+        pl.set_exchange_events([None, None, ev[2], ev[3]])
+        pl.run(A, B, Cm)
+        torch.cuda.synchronize()
+        pl.gather_result(Cm)
+        torch.cuda.synchronize()
+        if rank == 0:
+            ref, _, _ = g.gemm(A, B, 14)
+            torch.cuda.synchronize()
+            # ev[0] .. ev[1]: first to last residue GEMM of the rank; ev[2] .. ev[3]: first to last grouped send / recv (on the plan's exchange stream)
+            q.put((bool(torch.equal(Cm, ref)), ev[2].elapsed_time(ev[1]), ev[0].elapsed_time(ev[2]), ev[1].elapsed_time(ev[3])))
+        pl.close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_moduli_plan_exchange_starts_before_the_last_gemm_ends():
+    """Round 5: the moduli plan multiplies the rank's planes in two groups; the residue blocks of group 0 leave on the plan's exchange stream as
+    soon as its GEMMs are done, beside the GEMMs of group 1.  Checked with the plan's own events: the exchange begins after the first GEMM starts and
+    BEFORE the last GEMM ends, and ends after it; the result stays bit-identical to the single-GPU one."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    assert _start_and_reap(procs, 300) == [0, 0]
+    same, x_to_gemm_end, gemm_begin_to_x, gemm_end_to_x_end = q.get(timeout=10)
+    assert same
+    assert gemm_begin_to_x > 0 and x_to_gemm_end > 0 and gemm_end_to_x_end > 0, (gemm_begin_to_x, x_to_gemm_end, gemm_end_to_x_end)
+
+
 def _rccl_worker(port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
