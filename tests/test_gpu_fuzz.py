@@ -51,6 +51,8 @@ def test_random_case_bit_exact(seed, monkeypatch):
     cb_force = str(rng.choice(["", "1", "2", "3"]))   # column-block width of the tile walk (oz2_gemm_common.hpp map_colblock)
     if cb_force:
         gu.setknob(monkeypatch, "GEMMUL8_MAP_COLBLOCK", cb_force)
+    if backend == g.FP8 and seed % 5 == 0:  # FP8 backend: the e4m3 byte planes + e4m3 kernel instead of the FP6 panel images (round 5; no rng draw: the shapes of a seed stay)
+        gu.setknob(monkeypatch, "GEMMUL8_FP8_PLANES", "e4m3")
     cplx = np.dtype(dtype).kind == "c"
     opA = str(rng.choice(["N", "T", "C"] if cplx else ["N", "T"]))
     opB = str(rng.choice(["N", "T", "C"] if cplx else ["N", "T"]))
@@ -98,6 +100,8 @@ def test_random_case_large_k_bit_exact(seed, monkeypatch):
         else:
             n = max(1, n // 2 + 1)
     nt_force = str(rng.choice(["", "0", "1"]))
+    if backend == g.FP8 and seed % 5 == 0:
+        gu.setknob(monkeypatch, "GEMMUL8_FP8_PLANES", "e4m3")
     if nt_force:
         gu.setknob(monkeypatch, "GEMMUL8_EPI_NT", nt_force)
     tile_force = str(rng.choice(["", "128", "256"]))

@@ -34,9 +34,9 @@ for fast in (0, 1):
         Cc = torch.zeros((n, m), dtype=dt, device="cuda")
         tot, _, _ = g.work_size(False, g.INT8, m, n, k, N)
         work = torch.empty(tot, dtype=torch.uint8, device="cuda")
-        best = {"0": 1e9, "1": 1e9}
+        best = {"0": 1e9, "1": 1e9, "2": 1e9}
         for rnd in range(3):
-            for mode in ("0", "1"):
+            for mode in ("0", "1", "2"):
                 os.environ["GEMMUL8_FUSED_CRT"] = mode
                 for _ in range(2):
                     g.gemm(A, B, N, fastmode=bool(fast), C_out=Cc, work=work)
@@ -50,6 +50,7 @@ for fast in (0, 1):
         os.environ.pop("GEMMUL8_FUSED_CRT")
         sel = g.lib().gemmul8_fused_crt_selected(g.D if typ == "d" else g.S, g.INT8, m, n, N)
         fl = 2.0 * m * n * k
-        print(f"{typ}gemm {m}x{n}x{k} N={N} fast={fast}: two-launch {best['0'] * 1e3:7.3f} ms ({fl / best['0'] * 1e-12:6.1f} TFLOPS)  fused {best['1'] * 1e3:7.3f} ms "
-              f"({fl / best['1'] * 1e-12:6.1f} TFLOPS)  {100 * (best['0'] / best['1'] - 1):+5.1f} %  default rule picks {'fused' if sel else 'two-launch'}", flush=True)
+        print(f"{typ}gemm {m}x{n}x{k} N={N} fast={fast}: two-launch {best['0'] * 1e3:7.3f} ms ({fl / best['0'] * 1e-12:6.1f} TFLOPS)  fused, CRT on the producer waves {best['1'] * 1e3:7.3f} ms "
+              f"({100 * (best['0'] / best['1'] - 1):+5.1f} %)  fused, CRT tail on the consumer waves {best['2'] * 1e3:7.3f} ms ({100 * (best['0'] / best['2'] - 1):+5.1f} %)  "
+              f"default rule picks {'fused' if sel else 'two-launch'}", flush=True)
         del A, B, Cc, work
