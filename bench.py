@@ -600,7 +600,7 @@ def main():
 
     # the other mode alongside (report both; the headline above is the mode selected by --fast), timed HERE, on the device the
     # headline left warm -- behind the host-side error checks below its first launches ran on a device back in its idle power state
-    # (6.7 / 6.2 / 5.7 ms for the same GEMM launch: profiles/r04b_config2_kernel_stats_note.txt) and the fast-mode line read 169 where the sweeps read 175
+    # (6.7 / 6.2 / 5.7 ms for the same GEMM launch: profiles/archive/r04b_config2_kernel_stats_note.txt) and the fast-mode line read 169 where the sweeps read 175
     C_head = Cmat.clone()
     other = not args.fast
     for _ in range(2):
@@ -649,7 +649,7 @@ def main():
     roof = {"bound": "mfma", "kernel": "oz2::gemm_i8_kernel<EPI_MOD> (batched over moduli)", "achieved": ach, "peak": peak,
             "unit": "TOP/s", "frac": ach / peak, "traffic": None, "traffic_measured_in_run": False, "launch_ms": gemm_ms, "ops_per_launch": ops,
             "algorithmic_bytes_per_launch": N * 3.0 * n * n,
-            # measured with tools/ubench/mfma_shapes.hip (profiles/r02_mfma_shapes.txt): a register-only loop of the kernel's
+            # measured with tools/ubench/mfma_shapes.hip (profiles/archive/r02_mfma_shapes.txt): a register-only loop of the kernel's
             # instruction (v_mfma_i32_16x16x64_i8) reaches the nominal peak on all-zero operands but is limited by the 1400 W
             # socket cap to this on uniformly distributed residues (v_mfma_i32_32x32x32_i8: 3448)
             "sustained_mfma_on_residue_data_TOPs": 3969.0}

@@ -45,7 +45,7 @@ static inline bool moduli_ok(int dtype, unsigned N) { return N >= 2 && N <= (is_
 
 // FP8 backend: C0 + C1 of a square modulus may share one FP32 accumulator (K-concatenation) while every partial sum stays an exact
 // integer: 2 k products of magnitude <= 16 * 16 (src/mod.hpp:159-189) <= 2^24
-// -- and while the four operand planes of such a GEMM stay inside the Infinity Cache: interleaved (profiles/r04_f8_concat_ab.txt) SGEMM 8192^2 x 4096 /
+// -- and while the four operand planes of such a GEMM stay inside the Infinity Cache: interleaved (profiles/archive/r04_f8_concat_ab.txt) SGEMM 8192^2 x 4096 /
 // 8192, 6 moduli: +4.5 / +2.3 % of the whole call, 16384^3 (1 GiB of planes per concatenated GEMM): -0.4 %
 static inline bool f8_concat_ok(size_t k, size_t m, size_t n, size_t kp) { return k <= 32768 && 2 * (m + n) * kp <= ((size_t)384 << 20); }
 

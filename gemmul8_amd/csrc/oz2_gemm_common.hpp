@@ -34,7 +34,7 @@ struct TileMap {
 // 8 tile-rows touches ALL B panels of the plane; they stay in the 256 MiB Infinity Cache between row groups as long as they are not
 // much more than half of it (n = 16384, k = 8192: 128 MiB -- blocking costs 3 % there, A is re-streamed once per block).  Beyond
 // that (16384^2 x 16384: 256 MiB of B per plane) every row group re-read B from HBM: blocks of ~128 MiB of B panels recover it
-// (6 planes 16384^2 x 16384: 19.19 -> 18.32 ms, 12288^2 x 16384: 10.47 -> 10.24; profiles/r03_map_colblock_ab.txt).
+// (6 planes 16384^2 x 16384: 19.19 -> 18.32 ms, 12288^2 x 16384: 10.47 -> 10.24; profiles/archive/r03_map_colblock_ab.txt).
 inline int map_colblock(size_t tiles_n, size_t kbytes) {
     if (!OZ2_MAP_COLBLOCK) return 0;
     if (const int w = knobs().map_colblock; w >= 0)  // testing switch (oz2_knobs.hpp): tile-columns per block, 0 = full width

@@ -19,7 +19,7 @@
 // v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales (E8M0 0x7F) -- the scaled forms are the only full-rate FP8 MFMAs on CDNA4
 // (the unscaled fp8 forms run at the BF16 rate), and at the board's power cap the 16x16x128 shape sustains 4.28 POP/s on the
 // integers in [-16, 16] this backend multiplies where 32x32x64 holds 3.97 (tools/ubench/mfma_shapes.hip,
-// profiles/r02_mfma_shapes.txt).  One instruction consumes a whole 128-byte K-step of 16 rows: lane l holds row l & 15 and the
+// profiles/archive/r02_mfma_shapes.txt).  One instruction consumes a whole 128-byte K-step of 16 rows: lane l holds row l & 15 and the
 // 16-byte chunks q and q + 4 (q = l >> 4) of it -- any assignment of K positions works as long as A and B agree, and this one
 // keeps the ds_read_b128 pattern of the INT8 kernel (conflict-free with the row-XOR swizzle).  A K-step is two segments (row
 // halves) of 16 MFMAs: A fragments of 64 rows (32 registers) per segment, the B fragments of the wave's 64 columns (32
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
     // the whole persistent loop is instantiated twice (A-fetching waves 0-3, B-fetching waves 4-7) so that the fetch schedule is
     // branch-free inside the LOAD segments
     auto run = [&]<bool ISB>() {
-        // Measured on config 3 (18 GEMMs, interleaved builds, profiles/r02_f8_ab.txt): this kernel 54.9 ms, the round-1 32x32x64 kernel
+        // Measured on config 3 (18 GEMMs, interleaved builds, profiles/archive/r02_f8_ab.txt): this kernel 54.9 ms, the round-1 32x32x64 kernel
         // (four segments of 4 MFMAs) 55.5 ms, a four-segment (row x column halves) form of this one 55.8 ms.  The matrix pipes stay
         // ~25 % idle, and the cost sits in the L2 -> LDS operand path itself: with the DMA issued in the first tile only (real data
         // in LDS; probe build -DOZ2_PROBE=4) the 18 GEMMs take 44.2 instead of 54.2 ms (-18.5 %; the INT8 kernel: -13 %), of which
@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
                     for (int i = 0; i < 4; ++i) af[i] = frag(curA + (ah * 4 + i) * 16 * BK);
                     // As in oz2_gemm_i8.hip: only the K-step's LAST load segment completes its LDS reads (and, on the A waves, the DMA the next K-step
                     // needs) before the barrier -- the one the ring's hazards count on; the first segment arrives at the barrier with its reads issued
-                    // and waits behind it (config 3 whole call +1.25 %, SGEMM 8192^2 x 2048 / 8192 +1.2 / +0.7 %: profiles/r04e_f8_late_wait_ab.txt)
+                    // and waits behind it (config 3 whole call +1.25 %, SGEMM 8192^2 x 2048 / 8192 +1.2 / +0.7 %: profiles/archive/r04e_f8_late_wait_ab.txt)
                     if (ah == 1) {
                         if (!ISB) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
                         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -304,7 +304,7 @@ hipError_t launch_gemm_f8(hipStream_t stream, int which, const int8_t* A, const 
 
 // Inflation of the accurate-mode bound sums.  The reference uses ku = (k+1) * 2^-24, a bound on IEEE FP32 summation
 // (find_max.hpp:82-96).  v_mfma_scale_f32_16x16x128_f8f6f4 does not sum like that (tools/ubench/f8_accum.hip,
-// profiles/r02_f8_mfma_accumulation.txt): inside a group of 8 products everything is aligned to the group's largest product and
+// profiles/archive/r02_f8_mfma_accumulation.txt): inside a group of 8 products everything is aligned to the group's largest product and
 // bits below 2^-13 of it are TRUNCATED -- up to 7 * 2^-13 of a non-negative group sum is lost -- and the group sums / accumulator
 // are added with ~21-22 bits below the largest addend, again truncating (<= 16 * 2^-20 per instruction, k/128 instructions:
 // <= 2 (k+1) * 2^-24 overall).  A bound that comes out LOW can push the shift up by one and break accurate mode's no-wrap guarantee

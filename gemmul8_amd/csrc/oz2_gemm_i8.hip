@@ -56,7 +56,7 @@ namespace oz2 {
 #define OZ2_PB 4
 #endif
 #ifndef OZ2_KBAR_MAX_KP
-#define OZ2_KBAR_MAX_KP 5120  // padded k up to which the K-step-barrier schedule is used (see launch<EPI>); 0 = never, 1 << 30 = always.  Round 4 (after the epilogue / tile-prologue work): +1.0 / +1.3 % at k = 4608 / 5120 on 8192^2 x 14 planes, +0.5 % at 5120 on 16384^2 x 6; at 6144 +0.9 % / -1.1 %, at 7168 0 / -1.3 %, at 8192 -1.3 % (profiles/r04_gemm_ab_kbar_threshold.txt)
+#define OZ2_KBAR_MAX_KP 5120  // padded k up to which the K-step-barrier schedule is used (see launch<EPI>); 0 = never, 1 << 30 = always.  Round 4 (after the epilogue / tile-prologue work): +1.0 / +1.3 % at k = 4608 / 5120 on 8192^2 x 14 planes, +0.5 % at 5120 on 16384^2 x 6; at 6144 +0.9 % / -1.1 %, at 7168 0 / -1.3 %, at 8192 -1.3 % (profiles/archive/r04_gemm_ab_kbar_threshold.txt)
 #endif
 #ifndef OZ2_SLEEP_A
 #define OZ2_SLEEP_A 4  // s_sleep units (64 clocks) between the A producers' 8 groups of 2 LDS-DMA instructions
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     // ------------------------------ consumer waves
     // Matrix instruction: v_mfma_i32_16x16x64_i8 (A / B operand: lane l = row l & 15, K bytes 16 (l >> 4) .. + 15 of a 64-byte K
     // slice; result: column l & 15, rows 4 (l >> 4) + r).  At the board's power cap it sustains 3.95-3.98 POP/s on uniformly
-    // distributed residues where v_mfma_i32_32x32x32_i8 holds 3.45 (tools/ubench/mfma_shapes.hip, profiles/r02_mfma_shapes.txt):
+    // distributed residues where v_mfma_i32_32x32x32_i8 holds 3.45 (tools/ubench/mfma_shapes.hip, profiles/archive/r02_mfma_shapes.txt):
     // the same MACs with a quarter of the accumulator registers read and written per instruction.  Wave tile 128 x 64 = 8 x 4
     // accumulator tiles (128 registers); a K-step (128 bytes) is four segments (K half ks2) x (row half ah) of 16 MFMAs: the B
     // fragments of a K half are loaded in its first segment and kept for the second, the A fragments of 64 rows per segment.
@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
                     // Only the K-step's LAST load segment completes its reads BEFORE the barrier: that is the barrier the ring's WAR rule counts on
                     // (LDS operations of a wave complete in order, so its wait covers every read of the K-step).  The other three segments arrive at
                     // the barrier as soon as their reads are ISSUED and wait behind it: a wave's LDS latency no longer delays the hand-over of all
-                    // twelve (+0.4 / +0.5 % at k = 6144 / 8192, planes bit-identical: profiles/r04e_late_wait_ab.txt)
+                    // twelve (+0.4 / +0.5 % at k = 6144 / 8192, planes bit-identical: profiles/archive/r04e_late_wait_ab.txt)
                     if (ks2 == 1 && ah == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_setprio(1);
                     // serpentine order over the 4 x 4 fragment pairs: consecutive MFMAs share an operand register also across the row change
-                    // (B fragment 3, 3, 0, 0 ...): +0.5 ... 0.65 % at k >= 8192, interleaved (profiles/r04_gemm_ab_serpentine_kbar.txt)
+                    // (B fragment 3, 3, 0, 0 ...): +0.5 ... 0.65 % at k >= 8192, interleaved (profiles/archive/r04_gemm_ab_serpentine_kbar.txt)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -446,7 +446,7 @@ static hipError_t launch_sched(hipStream_t stream, GemmArgs& a, const std::condi
 }
 
 // Two schedules of the same tile loop (bit-identical results): with a workgroup barrier after every LOAD / MFMA segment (ping-pong)
-// or with one barrier per K-step.  Interleaved on one box (tools/gemm_ab.py, 8192^2 x k, 14 planes, profiles/r02_sched_ab.txt): the
+// or with one barrier per K-step.  Interleaved on one box (tools/gemm_ab.py, 8192^2 x k, 14 planes, profiles/archive/r02_sched_ab.txt): the
 // K-step-barrier form is faster by 10 / 7.5 / 4.7 / 2.4 % at k = 512 / 1024 / 2048 / 4096 (tile boundaries -- epilogue beside the
 // other half's first K-steps -- overlap better) and 2.4 % slower at k = 8192, where the board is power-bound and removing stalls
 // buys nothing while the s_sleep-paced LDS-DMA is a little less smooth than the barrier-paced one.
@@ -463,7 +463,7 @@ template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int
     a.acc0 = (size_t)a.kp * (size_t)a.nseg <= 512 ? 0 : (int)0x80000000u;  // RED_ODD_SMALL needs |sum| < 2^23
     // (the bound GEMM keeps the ping-pong schedule at every k.  In round 2 its K-step-barrier instantiation spilled accumulators INSIDE
     // the MFMA loop; with the round-3 source it no longer does, but the single-plane launch still runs slower with it: bounds phase
-    // 88.4 -> 92.4 us at 3072^3, 130.9 -> 134.6 at 4096^3, equal at 2048^3 and 8192^3.  round-3 A/B: profiles/r03_bound_ab.txt)
+    // 88.4 -> 92.4 us at 3072^3, 130.9 -> 134.6 at 4096^3, equal at 2048^3 and 8192^3.  round-3 A/B: profiles/archive/r03_bound_ab.txt)
 #ifdef OZ2_LAB_SHORTK  // laboratory build only (tools/experiments/shortk): the half-tile ping-pong kernel for padded k <= OZ2_LAB_SHORTK
     if constexpr (EPI != EPI_MAX) {
         if (a.nseg == 1 && a.kp <= OZ2_LAB_SHORTK) return launch_gemm_i8_shortk(stream, a, EPI);
@@ -499,7 +499,7 @@ template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int
 // planes of the launch fit the Infinity Cache, keeping them there is worth 8-14 % of the WHOLE call (8192^2: k = 256 / 512 / 1024
 // 0.917 -> 0.815 / 1.059 -> 0.940 / 1.470 -> 1.285 ms; 16384^2: k = 256 / 512 3.22 -> 2.88 / 3.88 -> 3.59 ms); when they do not fit
 // there is nothing to protect and the CRT pass loses the tail of C_mid it would have found in the cache (-0.5 ... -2 % from k = 1536
-// at 8192^2, k = 1024 at 16384^2); with small outputs (4096^2 and below) it is a wash.  profiles/r03_epi_nt_grid.txt
+// at 8192^2, k = 1024 at 16384^2); with small outputs (4096^2 and below) it is a wash.  profiles/archive/r03_epi_nt_grid.txt
 static int nt_residue_planes(const GemmArgs& a, int planes, bool stream_out, bool automatic = true) {
     if (const int force = knobs().epi_nt; force >= 0) return force == 1 && stream_out ? planes : 0;  // testing switch: one policy for all planes (same results)
     if (!stream_out || !automatic) return 0;
@@ -507,7 +507,7 @@ static int nt_residue_planes(const GemmArgs& a, int planes, bool stream_out, boo
     const size_t operands = all * (a.strideA + a.strideB), residues = all * a.strideO;
     // (keeping the default policy for the last 2-6 planes, so that the CRT finds them in the cache, non-temporal stores for the
     // leading planes of launches whose operands do NOT fit, and walking the planes last to first -- the order the quantise kernels
-    // left them in the cache -- were all measured: no consistent gain, profiles/r03_epi_nt_keep.txt; between 240 and ~450 MiB of
+    // left them in the cache -- were all measured: no consistent gain, profiles/archive/r03_epi_nt_keep.txt; between 240 and ~450 MiB of
     // operand planes the sign of the effect differs from box to box, -2 ... +4 %)
     return residues >= ((size_t)256 << 20) && operands <= ((size_t)240 << 20) ? planes : 0;
 }
@@ -554,7 +554,7 @@ hipError_t launch_gemm_i8_cplx(hipStream_t stream, const int8_t* A, const int8_t
 }
 
 #ifndef OZ2_MAX_SMALL_TILES
-#define OZ2_MAX_SMALL_TILES 128  // the bound GEMM takes the 128 x 128-tile kernel when (batch x) its 256 x 256 tiles number at most this (of 256 CUs): bounds phase 33 -> 28 / 41 -> 32 / 66 -> 55 us at 512^3 / 1024^3 / 2048^3, but 98 -> 111 us at 3072^3 (144 tiles), profiles/r03_bound_ab.txt
+#define OZ2_MAX_SMALL_TILES 128  // the bound GEMM takes the 128 x 128-tile kernel when (batch x) its 256 x 256 tiles number at most this (of 256 CUs): bounds phase 33 -> 28 / 41 -> 32 / 66 -> 55 us at 512^3 / 1024^3 / 2048^3, but 98 -> 111 us at 3072^3 (144 tiles), profiles/archive/r03_bound_ab.txt
 #endif
 // mid_seg > 0: the row / column maxima are taken twice per tile -- of the partial sums after the first mid_seg K-segments and of the
 // full sums.  The complex bound (max over the elements of C1 = ArBi + AiBr and of C1 + C0, C0 = (Ar-Ai)(Br-Bi)) is then ONE launch over

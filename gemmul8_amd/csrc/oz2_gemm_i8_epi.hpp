@@ -208,7 +208,7 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
         // Complex combine in TWO passes (round 4).  Vector-memory operations of a wave complete in issue order (one vmcnt for loads and stores on
         // gfx9), and a reload of a spilled register is a vector-memory load too: the sub-block-by-sub-block form of rounds 1-3 (load X / Y, combine,
         // store; its store addresses reloaded from scratch) waited for a full memory round trip per 8 rows -- sixteen serialised latencies per tile,
-        // the 40 % by which the combine launch ran longer than a plain residue launch (profiles/r04_pmc_cplx_combine.txt: waves parked at s_waitcnt).
+        // the 40 % by which the combine launch ran longer than a plain residue launch (profiles/archive/r04_pmc_cplx_combine.txt: waves parked at s_waitcnt).
         // Pass 1 reduces the accumulators sub-block by sub-block to packed residues and issues the two 16-byte X / Y loads of a sub-block as soon as
         // its accumulators are dead (the loads land in those registers): sixteen loads in flight behind the residue arithmetic, none behind a store.
         // One wait, then pass 2 combines and stores (the stores are invisible to the compiler's vmcnt bookkeeping -- store16_cols -- so it must not be

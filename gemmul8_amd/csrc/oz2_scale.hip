@@ -101,7 +101,7 @@ enum { MODE_BOUND = 0, MODE_MOD = 1 };
 
 #ifndef OZ2_STAGE_V16
 #define OZ2_STAGE_V16 0  // 1: INT8 residue planes leave as 16-byte stores (4 x 4 dword transpose over the lane quads) instead of one dword per
-                         // lane and plane.  Measured SLOWER (quantise pair 8192^2 x 14 planes: 702 vs 672 us, profiles/r03_hbm_ab.txt): the kernel is
+                         // lane and plane.  Measured SLOWER (quantise pair 8192^2 x 14 planes: 702 vs 672 us, profiles/archive/r03_hbm_ab.txt): the kernel is
                          // bound by VALU issue, not by its store pattern, and the transposes add 16 operations per 4 planes -- kept for reference
 #endif
 #ifndef OZ2_STAGE_VLOAD
@@ -266,7 +266,7 @@ __device__ __forceinline__ size_t f6_lane_offset(const StageArgs& a, size_t row,
 }
 
 // Quantise + all residues of four consecutive k in the FLOATING-POINT domain.  The quantise kernels are bound by VALU issue, not by HBM
-// (profiles/r03_hbm_ab.txt, r03_valu_rates.txt): the integer path spends ~37 operations per element on trunc(x * 2^s) = +-M * 2^E and
+// (profiles/archive/r03_hbm_ab.txt, r03_valu_rates.txt): the integer path spends ~37 operations per element on trunc(x * 2^s) = +-M * 2^E and
 // ~7.75 per residue (two v_dot4_u32_u8 over the bytes of M, sign correction, quotient step, packing).  Here:
 //   xs = trunc(ldexp(x, s))                       2 FP64 operations per element; exact (a power-of-two scaling, then v_trunc_f64)
 //   level 1, per PAIR of moduli, P = p_t * p_t+1:  R = fma(-rint(xs * RN(1/P)), P, xs)      3 FP64 operations per pair
@@ -964,7 +964,7 @@ hipError_t launch_zero(hipStream_t stream, void* p, size_t bytes) {
 }
 
 #ifndef OZ2_EXTRACT_CHUNK_MB
-#define OZ2_EXTRACT_CHUNK_MB 0    // (measured SLOWER: bounds phase 725 -> 771 us at 128 MiB, 796 at 64 MiB, profiles/r03_hbm_ab_extract_chunking.txt) row-strided extract: amax -> extract per row block of at most this many MiB of the operand, so that the
+#define OZ2_EXTRACT_CHUNK_MB 0    // (measured SLOWER: bounds phase 725 -> 771 us at 128 MiB, 796 at 64 MiB, profiles/archive/r03_hbm_ab_extract_chunking.txt) row-strided extract: amax -> extract per row block of at most this many MiB of the operand, so that the
                                   // extract's read of the block is served by the 256 MiB Infinity Cache instead of HBM; 0 = one pass each
 #endif
 hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajor, bool conj, size_t rows, size_t k, const void* X,

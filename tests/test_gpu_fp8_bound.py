@@ -1,7 +1,7 @@
 """FP8 backend, accurate mode: the CONSEQUENCE of a bound that comes out low (VERDICT r2 weak #2 / ADVICE r2).
 
 gfx950's v_mfma_scale_f32_16x16x128_f8f6f4 truncates products more than 13 binades below the largest of their group of 8
-(profiles/r02_f8_mfma_accumulation.txt), so the bound GEMM's non-negative sums come out low by up to ~8e-4 -- more than the
+(profiles/archive/r02_f8_mfma_accumulation.txt), so the bound GEMM's non-negative sums come out low by up to ~8e-4 -- more than the
 reference's (k+1)*2^-24 inflation (GEMMul8/src/find_max.hpp:82-96) covers.  A low bound matters only through
 floor(log2P - 0.5*log2(max)) (scaling_accu_real.hpp:6-18): if the exact maximum leaves the pre-floor value just BELOW an integer, the
 low maximum pushes it across, the shift of that row AND column grows by one, |A'B'| reaches ~P and the CRT wraps: the element comes
@@ -249,7 +249,7 @@ def test_fp8_bound_fuzz_regressions(seed):
     """Round 4: a 12000-seed run of tests/test_gpu_fuzz.py found these two real-type FP8 cases (one row / one column, exponent range
     phi = 3, k = 400) whose bound maxima came out 4.7e-5 / 2.2e-6 BELOW the exact sums with the relative inflation alone: the engine aligns a
     group of 8 products to the largest sum of the operands' exponent FIELDS, and an e4m3 subnormal carries the field of 2^-6
-    (tools/ubench/f8_accum2.hip, profiles/r04_f8_accum2.txt).  The default inflation now has an absolute part (oz2_gemm_f8.hip bound_kabs);
+    (tools/ubench/f8_accum2.hip, profiles/archive/r04_f8_accum2.txt).  The default inflation now has an absolute part (oz2_gemm_f8.hip bound_kabs);
     bounds_case asserts exact un-inflated maximum <= device value."""
     import gemmul8_amd as g
     import gpu_util as gu

@@ -5,7 +5,7 @@ no worse than the native run's.  (2) torch.linalg.lu_factor itself (hipSOLVER / 
 the reference's hook offers, src/hook.cu:846-1055) NONE of its flops are intercepted -- rocSOLVER's trailing updates call rocBLAS's exported
 C++ template rocblas_internal_gemm_template<T>, not a BLAS entry point; with GEMMUL8_HOOK_ROCBLAS=1, which interposes that template as
 well, at least half of the factorization's 2/3 n^3 flops run emulated and the residual is no worse than native.  Numbers:
-gpurun_out/hook_reach.jsonl -> profiles/r04_hook_reach.jsonl, INTEGRATION.md "What the hook reaches"."""
+gpurun_out/hook_reach.jsonl -> profiles/archive/r04_hook_reach.jsonl, INTEGRATION.md "What the hook reaches"."""
 import json
 import os
 import re

@@ -9,7 +9,7 @@
 //       (OZ2_DMA_SKIP = 6: -16.7 % of the L2 -> LDS bytes per MAC, what a 384 x 256 CU tile would save; 2: -50 %)
 // OZ2_KSTAG=<1..4> staggers the K-step a workgroup starts from (1: XCD x starts at x KT1 / 8; 2: plus (CU & 3) K-steps; 3: (CU & 7)
 // K-steps only; 4: odd XCDs start at KT1 / 2) -- bit-identical results (INT32 sums are order-independent), measured neutral
-// (profiles/r04_gemm_ab_kstag_order_l2.txt).
+// (profiles/archive/r04_gemm_ab_kstag_order_l2.txt).
 #pragma once
 #ifndef OZ2_PROBE
 #define OZ2_PROBE 0

@@ -23,7 +23,7 @@
 //     8 waves x 256 VGPRs, no producer waves.
 // Price: the B panel is fetched once per HALF-tile: 1.5 x the L2 -> LDS bytes per MAC of the 256 x 256 kernel -- which is why this form is
 // for short K only, where the epilogue, not the operand path, is what the tile time is made of.
-// Numbers: README.md here, DESIGN.md 3.1 "short K", profiles/r04_shortk_ab.txt.
+// Numbers: README.md here, DESIGN.md 3.1 "short K", profiles/archive/r04_shortk_ab.txt.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -1,6 +1,6 @@
 // Issue rate of the VALU instructions the HBM-side kernels of the emulation are made of (quantise, CRT, GEMM epilogue) on gfx950:
 // cycles per wave64 instruction on one SIMD, from loops of 16 independent instructions (two waves per SIMD to cover dependent latency).
-// The CRT and quantise kernels turned out to be bound by VALU issue, not by HBM (profiles/r03_hbm_ab.txt): this table prices their
+// The CRT and quantise kernels turned out to be bound by VALU issue, not by HBM (profiles/archive/r03_hbm_ab.txt): this table prices their
 // instruction mixes.
 #include <hip/hip_runtime.h>
 #include <cstdio>

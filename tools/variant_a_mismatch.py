@@ -2,7 +2,7 @@
 """Exchange variant (A) of the moduli-sharded plan (FP64 partial CRT sums added across ranks) against the
 reference-order accumulation: how many output elements change, and by how much, when the num_moduli chains are grouped by rank
 (contiguous groups, partials added in rank order).  CPU oracle on a random DGEMM / SGEMM / ZGEMM; integer intermediates are
-identical by construction, so only the final CRT step is recomputed.  Output: profiles/r02_variant_a_mismatch.txt"""
+identical by construction, so only the final CRT step is recomputed.  Output: profiles/archive/r02_variant_a_mismatch.txt"""
 import ctypes as C
 import os
 import sys
