@@ -189,7 +189,9 @@ int gemmul8_get_layout(int dtype, int backend, size_t m, size_t n, size_t k, uns
     const size_t tail = (native_sz - midsz * L->sizeC) & ~size_t(255);
     L->scratch = C_hi - tail;
     L->scratch_bytes = tail + hi_bytes;
-    L->lo_format = (backend == kFP8 && f6_planes_ok(n)) ? 1 : 0;
+    // FP6 panel images need both operands in that encoding, and whether they fit depends on n: with skip-scaling enabled an operand's planes outlive
+    // the call and may meet a partner of another shape (the reference's use: one A against changing B), so cached planes keep the e4m3 bytes
+    L->lo_format = (backend == kFP8 && !enA && !enB && f6_planes_ok(n)) ? 1 : 0;
     return GEMMUL8_OK;
 }
 

@@ -75,8 +75,8 @@ typedef struct gemmul8_layout {
     void *scratch;             /* the reference's C_hi region (free for row/col maxima etc.) */
     size_t scratch_bytes;
     size_t lo_format;          /* encoding of the A_lo / B_lo residue planes: 0 = one byte per element (int8 residues / e4m3 pieces), row r at
-                                  r * kp; 1 = FP6 panel images of the FP8 backend's pieces (csrc/oz2_gemm_f6.hip; n >= 64 unless
-                                  GEMMUL8_FP8_PLANES=e4m3): same plane offsets and strides, 3/4 of each plane used.  The bound planes stay bytes. */
+                                  r * kp; 1 = FP6 panel images of the FP8 backend's pieces (csrc/oz2_gemm_f6.hip; n >= 64, skip-scaling
+                                  not enabled -- cached planes may meet a partner of another shape --, unless GEMMUL8_FP8_PLANES=e4m3): same plane offsets and strides, 3/4 of each plane used.  The bound planes stay bytes. */
 } gemmul8_layout;
 
 GEMMUL8_API int gemmul8_get_layout(int dtype, int backend, size_t m, size_t n, size_t k, unsigned num_moduli, void *work, void *workA,

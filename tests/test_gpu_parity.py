@@ -752,3 +752,45 @@ def test_fp8_backend_fp6_images_and_e4m3_planes_agree(dtype, N, fast, monkeypatc
     gu.setknob(monkeypatch, "GEMMUL8_FP8_PLANES", "fp6")
     _, it = gu.hip_gemm(A, B[:, :48].copy(), N, fastmode=fast, backend=g.FP8, want_intermediates=True)
     assert it["lo_format"] == 0
+
+
+@pytest.mark.gpu
+def test_fp8_skip_scaling_cached_planes_meet_a_partner_of_another_width():
+    """FP8 backend, round 5: whether the residue planes are FP6 panel images depends on n (B's last row block must fit its plane).  With skip-scaling
+    enabled an operand's planes outlive the call and may meet a partner of another width -- the reference's use of the flag: one A against changing B
+    (gemmul8_real.hpp:82-83,123-139) -- so layouts with skip-scaling enabled keep the e4m3 byte planes: A quantised beside a 96-column B is reused beside
+    a 40-column B2 (skip_scalA = 1, separate workA / workB) and the result equals the oracle's, fed with the kept shifts."""
+    import ctypes as C
+    import gemmul8_amd as g
+    import gpu_util as gu
+    import oracle_lib as ol
+    rng = np.random.default_rng(55)
+    m, k, n1, n2, N = 130, 300, 96, 40, 8
+    A, B1, B2 = rand((m, k), np.float32, rng), rand((k, n1), np.float32, rng), rand((k, n2), np.float32, rng)
+    lib = g.lib()
+    dA, dB1, dB2 = gu.to_dev(A), gu.to_dev(B1), gu.to_dev(B2)
+    one, zero = np.array([1], np.float32), np.array([0], np.float32)
+    st = torch.cuda.current_stream().cuda_stream
+    wA_bytes = C.c_size_t(0)
+    wB_bytes = C.c_size_t(0)
+    tot = lib.gemmul8_work_size(0, g.FP8, m, max(n1, n2), k, N, 1, 1, C.byref(wA_bytes), C.byref(wB_bytes))
+    work = torch.zeros(tot, dtype=torch.uint8, device="cuda")
+    workA = torch.zeros(wA_bytes.value, dtype=torch.uint8, device="cuda")
+    workB = torch.zeros(wB_bytes.value, dtype=torch.uint8, device="cuda")
+
+    def call(dB, n, skA):
+        dC = torch.zeros((n, m), dtype=torch.float32, device="cuda")
+        g.check(lib.gemmul8_gemm(st, g.S, g.FP8, 0, 0, m, n, k, one.ctypes.data, dA.data_ptr(), m, dB.data_ptr(), k, zero.ctypes.data, dC.data_ptr(), m, N, 1,
+                                 work.data_ptr(), workA.data_ptr(), workB.data_ptr(), 1, 1, skA, 0, None))
+        torch.cuda.synchronize()
+        L = g.Layout()
+        g.check(lib.gemmul8_get_layout(g.S, g.FP8, m, n, k, N, work.data_ptr(), workA.data_ptr(), workB.data_ptr(), 1, 1, C.byref(L)))
+        assert L.lo_format == 0
+        sA = workA.cpu().numpy()[L.sftA - workA.data_ptr():][:2 * m].view(np.int16).copy()
+        sB = workB.cpu().numpy()[L.sftB - workB.data_ptr():][:2 * n].view(np.int16).copy()
+        return gu.from_dev(dC).copy(), sA, sB
+    C1, sA1, sB1 = call(dB1, n1, 0)
+    assert gu.bits_equal(C1, ol.gemm(A, B1, N, fastmode=True, backend=g.FP8, sftA_in=sA1, sftB_in=sB1))
+    C2, sA2, sB2 = call(dB2, n2, 1)
+    assert np.array_equal(sA1, sA2)
+    assert gu.bits_equal(C2, ol.gemm(A, B2, N, fastmode=True, backend=g.FP8, sftA_in=sA2, sftB_in=sB2))
