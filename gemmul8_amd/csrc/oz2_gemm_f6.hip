@@ -100,9 +100,15 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f6_kernel(const F8Args args) 
         gdelta = isB ? ((long long)args.planeB2[pl_.tt] - args.planeB[pl_.tt]) * (long long)args.strideB - (long long)KT1 * gstep \
                      : ((long long)args.planeA2[pl_.tt] - args.planeA[pl_.tt]) * (long long)args.strideA - (long long)KT1 * gstep; \
     } while (0)
+    // (the 32-bit lane offset passes through an empty asm so that its zero-extension stays next to the load: SGPR base + VGPR offset addressing.
+    //  Hoisted out of the loop as a 64-bit value it costs a v_lshl_add_u64 and a register pair per piece)
 #define F6_DMA(src_, q_, stage_)                                                                                             \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((src_) + min(dbase + (q_) * 1024u, dlast)), \
-                                     (__attribute__((address_space(3))) void*)((stage_) + ((wave & 3) * 6 + (q_)) * 1024), 16, 0, 0)
+    do {                                                                                                                     \
+        unsigned off_ = min(dbase + (q_) * 1024u, dlast);                                                                    \
+        asm volatile("" : "+v"(off_));                                                                                       \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((src_) + off_),                     \
+                                         (__attribute__((address_space(3))) void*)((stage_) + ((wave & 3) * 6 + (q_)) * 1024), 16, 0, 0); \
+    } while (0)
 
     const int wm = wave >> 2, wn = wave & 3;
     const int r16 = lane & 15;

@@ -130,3 +130,24 @@ def test_fp6_kernels_registers_scratch_and_fragment_reads(f6):
         assert steady, (n, "no clean K-step block")
         for b in steady:
             assert sum(l.startswith("s_barrier") for l in b) == 1, n   # ONE workgroup barrier per K-step
+            # the inline-asm 8-byte reads are invisible to the compiler's waitcnt pass: their destinations must be the upper third of an operand tuple
+            # directly (a register copy placed between the read and the K-step's own wait would copy stale registers), and the LDS-DMA must use
+            # SGPR base + VGPR offset addressing
+            dst = set()
+            for l in b:
+                m = re.match(r"ds_read_b64 v\[(\d+):(\d+)\]", l)
+                if m:
+                    dst.update(range(int(m.group(1)), int(m.group(2)) + 1))
+            assert dst, n
+            for l in b:
+                if l.startswith("v_mov_b32") or l.startswith("v_mov_b64") or l.startswith("v_accvgpr"):
+                    srcs = [int(x) for x in re.findall(r"v(\d+)", l.split(",", 1)[1])] if "," in l else []
+                    assert not (set(srcs) & dst), (n, l)
+            tops = set()
+            for l in b:
+                if "v_mfma_scale" in l:
+                    for lo, hi in re.findall(r"v\[(\d+):(\d+)\]", l)[1:3]:
+                        tops.update((int(hi) - 1, int(hi)))
+            assert dst <= tops, (n, sorted(dst - tops))
+            dma = [l for l in b if l.startswith("global_load_lds")]
+            assert dma and all(re.match(r"global_load_lds_dwordx4 v\d+, s\[", l) for l in dma), (n, dma[:2])
