@@ -94,6 +94,7 @@ static Knobs parse_knobs() {
     if (const int c = num("GEMMUL8_CPLX_CHUNK", 0); c >= 1) k.cplx_chunk = c;
     if (const char* e = getenv("GEMMUL8_CRT_KERNEL")) k.crt_kernel = e[0] == 'd' ? 1 : e[0] == 'r' ? 2 : 0;
     if (const int c = num("GEMMUL8_GEMM_CUS", 0); c >= 8) k.gemm_cus = c & ~7;
+    if (const char* e = getenv("GEMMUL8_FP8_FUSED"); e && e[0] == '0') k.fp8_fused = 0;
     if (const char* e = getenv("GEMMUL8_FP8_PLANES")) k.fp8_planes = e[0] == 'e' ? 1 : 0;
     if (const char* e = getenv("GEMMUL8_MAP_COLBLOCK"); e && *e) k.map_colblock = atoi(e) > 0 ? atoi(e) : 0;
     return k;
@@ -335,6 +336,37 @@ int gemmul8_lowprec_gemm(void* stream_, int dtype, int backend, size_t m, size_t
         return f6 ? oz2::launch_gemm_f6(st, which, A, B, sA, sB, kp, mm, nn, tb, te, out, ldo, sO, r0, r1, sR, rx, ry)
                   : oz2::launch_gemm_f8(st, which, A, B, sA, sB, kp, mm, nn, tb, te, out, ldo, sO, r0, r1, sR, rx, ry);
     };
+    // FP6 planes (round 5): the three products of a modulus run as ONE tile loop over three K segments with the accumulators reduced in between
+    // (launch_gemm_f6 which = 7 / 8, f8_fill_planes): no partial-residue planes, one epilogue and one launch instead of two or three.  Every
+    // accumulator stays an exact integer while kp * 256 + 2^16.1 <= 2^24; beyond that (kp > 65024) the three-launch form below.
+    const bool f6_fused = f6 && L->kp <= 65024 && knobs().fp8_fused != 0;
+    if (f6_fused && !is_complex(dtype)) {
+        OZ2_HIP(launch_gemm_f8(stream, 7, A_lo, B_lo, L->sizeA, L->sizeB, L->kp, m, n, (int)t_begin, (int)t_end,
+                               (int16_t*)L->C_mid + (size_t)t_begin * L->sizeC, L->mp, L->sizeC, nullptr, nullptr, 0));
+        return GEMMUL8_OK;
+    }
+    if (f6_fused) {
+        // complex: the parts X = ArBr, Y = AiBi to canonical int16 scratch planes, the part Z = (Ar+Ai)(Br+Bi) with the complex combine behind it
+        const size_t per_mod = 2 * 2 * L->sizeC;
+        const size_t chunk = L->scratch_bytes / per_mod;
+        if (chunk == 0) return GEMMUL8_E_ARG;
+        int16_t* rx = (int16_t*)L->scratch;
+        for (unsigned t0 = t_begin; t0 < t_end; t0 += (unsigned)chunk) {
+            const unsigned t1 = std::min<unsigned>(t_end, t0 + (unsigned)chunk);
+            int16_t* ry = rx + (size_t)(t1 - t0) * L->sizeC;
+            for (int part = 0; part < 3; ++part) {
+                const int8_t* Ap = A_lo + part * L->part_strideA;
+                const int8_t* Bp = B_lo + part * L->part_strideB;
+                if (part < 2) {
+                    OZ2_HIP(launch_gemm_f8(stream, 7, Ap, Bp, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1, part == 0 ? rx : ry, L->mp, L->sizeC, nullptr, nullptr, 0));
+                } else {
+                    OZ2_HIP(launch_gemm_f8(stream, 8, Ap, Bp, L->sizeA, L->sizeB, L->kp, m, n, (int)t0, (int)t1, (int16_t*)L->C_mid + (size_t)t0 * 2 * L->sizeC, L->mp,
+                                           2 * L->sizeC, nullptr, nullptr, L->sizeC, rx, ry));
+                }
+            }
+        }
+        return GEMMUL8_OK;
+    }
     if (backend == kFP8 && !is_complex(dtype)) {
         // three e4m3 GEMMs per modulus (gemmul8_real.hpp:159-181); the residues of the first two wait in int16 scratch planes
         // (the reference's C_hi region) for the third one's epilogue.  Moduli are chunked to the scratch size.

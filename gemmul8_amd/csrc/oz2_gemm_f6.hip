@@ -78,7 +78,8 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f6_kernel(const F8Args args) 
     unsigned dlast = 0;    // byte offset of the last 16-byte chunk of the panel being fetched
     const int8_t* gsrc;
     int gstep = 0;         // bytes between consecutive K-steps of the block: Rp * 96
-    long long gdelta = 0;  // nseg == 2: from the panel of K-step KT1 + j of segment 1's plane to K-step j of segment 2's plane
+    long long gdelta = 0;  // nseg >= 2: from the panel of K-step KT1 + j of segment 1's plane to K-step j of segment 2's plane
+    long long gdelta2 = 0; // nseg == 3: the same for K-step 2 KT1 + j and segment 3's plane
     auto uniform = [](const int8_t* ptr) {
         const unsigned long long v = (unsigned long long)ptr;
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -95,6 +96,8 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f6_kernel(const F8Args args) 
         const int rp_ = isB ? rows_pad(tmap_.tn) : BM;                                                                       \
         gstep = rp_ * F6_ROWB;                                                                                               \
         dlast = (unsigned)(rp_ * F6_ROWB - 16);                                                                              \
+        gdelta2 = isB ? ((long long)args.planeB3[pl_.tt] - args.planeB[pl_.tt]) * (long long)args.strideB - 2ll * KT1 * gstep \
+                      : ((long long)args.planeA3[pl_.tt] - args.planeA[pl_.tt]) * (long long)args.strideA - 2ll * KT1 * gstep; \
         gsrc = uniform(isB ? args.B + pl_.boff + (size_t)args.planeB[pl_.tt] * args.strideB + (size_t)tmap_.tn * blockbytes   \
                            : args.A + pl_.boff + (size_t)args.planeA[pl_.tt] * args.strideA + (size_t)tmap_.tm * blockbytes); \
         gdelta = isB ? ((long long)args.planeB2[pl_.tt] - args.planeB[pl_.tt]) * (long long)args.strideB - (long long)KT1 * gstep \
@@ -117,15 +120,24 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f6_kernel(const F8Args args) 
     const int ay = 64 * BM + ((q >> 1) * 2 * BM + 2 * (wm * 128 + r16) + (q & 1)) * 8;
     constexpr int SC3 = (int)0x82828282u;  // E8M0 scale 2^3 for every block
     typedef int v2i __attribute__((ext_vector_type(2)));
-    // a fragment = the six operand registers: 16 bytes of the X region (px_: a pointer) + 8 bytes of the Y region (LDS byte address yb_ + constant yo_).
-    // The 8-byte read is inline assembly: written as a load, two fragments' reads fuse into one ds_read2_b64 whose four registers then have to be
-    // waited for and COPIED into the two operand tuples, in the middle of the MFMA stream.  The compiler's waitcnt pass does not see these reads: the
-    // K-step waits for them itself (lgkmcnt(0) at its top and in front of its barrier; LDS operations of a wave return in order).
-#define F6_FRAG(dst_, px_, yb_, yo_)                                                                                         \
+    // a fragment = the six operand registers: 16 bytes of the X region (LDS byte address xb_ + constant o_) + 8 bytes of the Y region (yb_ + o_).
+    // Both reads are inline assembly.  Written as loads, the compiler fuses two fragments' 8-byte reads into one ds_read2_b64 and hoists the 16-byte
+    // read of an in-place reload above the MFMAs that still read the old fragment -- either way registers have to be waited for (lgkmcnt(0)) and
+    // COPIED in the middle of the MFMA stream.  The compiler's waitcnt pass does not see these reads: the K-step waits for them itself, region by
+    // region (LDS operations of a wave return in order).
+#define F6_FRAG(dst_, xb_, yb_, o_)                                                                                          \
     do {                                                                                                                     \
-        const v4i lo_ = *(const v4i*)(px_);                                                                                  \
+        v4i lo_;                                                                                                             \
         v2i hi_;                                                                                                             \
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(hi_) : "v"(yb_), "n"(yo_));                                       \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(lo_) : "v"(xb_), "n"(o_));                                       \
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(hi_) : "v"(yb_), "n"(o_));                                        \
+        dst_ = v6i{lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1]};                                                          \
+    } while (0)
+    // the same as plain loads (visible to the compiler: waited for by it, safe to spill): only where a K-step runs into an epilogue
+#define F6_FRAG_PLAIN(dst_, px_, py_, o_)                                                                                    \
+    do {                                                                                                                     \
+        const v4i lo_ = *(const v4i*)((px_) + (o_));                                                                         \
+        const v2i hi_ = *(const v2i*)((py_) + (o_));                                                                         \
         dst_ = v6i{lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1]};                                                          \
     } while (0)
     const unsigned lds0 = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char*)smem;
@@ -156,16 +168,16 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f6_kernel(const F8Args args) 
         // the same step inside the K loop: the state of the tile the stream enters next was prepared at the consumer's tile start
         const int8_t* gsrcN = nullptr;
         int gstepN = 0;
-        long long gdeltaN = 0;
+        long long gdeltaN = 0, gdelta2N = 0;
         unsigned dlastN = 0;
 #define F6_FETCH_ADVANCE_LOOP()                                                                                              \
     do {                                                                                                                     \
         fs = fs == 2 ? 0 : fs + 1;                                                                                           \
-        if (++kt_next == KT) kt_next = 0, gsrc = gsrcN, gstep = gstepN, gdelta = gdeltaN, dlast = dlastN;                    \
+        if (++kt_next == KT) kt_next = 0, gsrc = gsrcN, gstep = gstepN, gdelta = gdeltaN, gdelta2 = gdelta2N, dlast = dlastN; \
     } while (0)
 #define F6_FETCH_PTRS()                                                                                                      \
     do {                                                                                                                     \
-        fsrc = gsrc + (long long)OZ2_HOOK_KSTEP(kt_next) * gstep + (kt_next >= KT1 ? gdelta : 0);                            \
+        fsrc = gsrc + (long long)OZ2_HOOK_KSTEP(kt_next) * gstep + (kt_next >= 2 * KT1 ? gdelta2 : kt_next >= KT1 ? gdelta : 0); \
         fdst = smem + (2 * fs + (ISB ? 1 : 0)) * F6_SLOT;                                                                    \
     } while (0)
         // prologue: panels 0 and 1 whole, pieces 0-2 of panel 2
@@ -187,37 +199,46 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f6_kernel(const F8Args args) 
         int cs = 0;  // (current K-step) % 3
         const int lead = (3 + KT - 1) / KT;  // tiles between the consumers' tile and the one the fetch stream enters during it (1 for KT >= 4)
         // the prologue left the stream in tile vb_next; re-base it on (consumer tile, lead): from here on every wrap takes the prepared state
-        // One K-step.  PF_: prefetch the next K-step's first fragments.  The instruction stream is cut into scheduling regions of four MFMAs (one row of
-        // half 0, one column of half 1) with the reads and the DMA piece that go beside them; the ORDER of the regions' LDS reads is what the explicit
-        // waits count on (LDS operations of a wave return in order):  half 1 issues aL[0] bf[0] aL[1] bf[1] aL[2] bf[2] aL[3] bf[3] (two reads each;
-        // bf[j] into the registers of the fragment whose last four MFMAs were just issued), so the first row of the next half 0 needs
-        // lgkmcnt(12) / (8) / (4) / (0) in front of its four MFMAs -- it starts when bf[0] has landed, not when the read behind the previous
-        // K-step's last MFMA has.  Rows 1-3 carry the reads of aH (rows 64-127) and DMA pieces 3-5; lgkmcnt(0) in front of the barrier.
+        // One K-step.  PF_: prefetch the next K-step's first fragments.  The instruction stream is cut into scheduling regions of four MFMAs (one COLUMN
+        // of B fragments, both halves) with the reads and the DMA piece that go beside them; the regions are what the explicit waits count (LDS
+        // operations of a wave return in order; inside a region the scheduler may order the plain 16-byte reads freely, which only makes a wait stronger):
+        //   half 1 issues   R0 = {aL[0], aL[1], bf[0]}  R1 = {aL[2], aL[3], bf[1]}  R2 = {bf[2]}  R3 = {bf[3]}   (two reads per fragment; bf[j] into the
+        //   registers of the column whose four MFMAs were just issued), 16 reads; the next half 0 then needs lgkmcnt(10) (R0 landed) for its first two
+        //   MFMAs, (4) (R1) for the next two and column 1, and -- with the reads of aH (rows 64-127) issued behind columns 1 and 2 -- (6) for column 2
+        //   and (8) for column 3: the read issued behind the previous K-step's LAST MFMA is needed thirteen MFMAs into this one.
+        // lgkmcnt(0) in front of the barrier (every read of panel g complete), vmcnt(6) (the wave's pieces of panel g + 1 landed).
 #define F6_KSTEP(PF_)                                                                                                        \
     do {                                                                                                                     \
-        const char* curA_ = smem + (2 * cs) * F6_SLOT;                                                                       \
-        const unsigned ycA_ = lds0 + (unsigned)((2 * cs) * F6_SLOT + ay);                                                    \
+        const unsigned xcA_ = lds0 + (unsigned)((2 * cs) * F6_SLOT + ax), ycA_ = lds0 + (unsigned)((2 * cs) * F6_SLOT + ay);  \
         cs = cs == 2 ? 0 : cs + 1;                                                                                           \
-        const char* nxtA_ = smem + (2 * cs) * F6_SLOT;                                                                       \
-        const char* nxtB_ = nxtA_ + F6_SLOT;                                                                                 \
-        const unsigned ynA_ = lds0 + (unsigned)((2 * cs) * F6_SLOT + ay), ynB_ = lds0 + (unsigned)((2 * cs + 1) * F6_SLOT + by); \
-        /* ---- half 0, row 0 */                                                                                             \
-        asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(bf[0]), "+v"(aL[0]));                                                    \
+        const unsigned xnA_ = lds0 + (unsigned)((2 * cs) * F6_SLOT + ax), ynA_ = lds0 + (unsigned)((2 * cs) * F6_SLOT + ay);  \
+        const unsigned xnB_ = lds0 + (unsigned)((2 * cs + 1) * F6_SLOT + bx), ynB_ = lds0 + (unsigned)((2 * cs + 1) * F6_SLOT + by); \
+        /* ---- half 0 (rows 0-63), column 0 */                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(bf[0]), "+v"(aL[0]), "+v"(aL[1]));                                       \
         F6_MFMA(aL[0], bf[0], acc[0][0]);                                                                                    \
-        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bf[1]));                                                                  \
-        F6_MFMA(aL[0], bf[1], acc[0][1]);                                                                                    \
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bf[2]));                                                                  \
-        F6_MFMA(aL[0], bf[2], acc[0][2]);                                                                                    \
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[3]), "+v"(aL[1]), "+v"(aL[2]), "+v"(aL[3]));                           \
-        F6_MFMA(aL[0], bf[3], acc[0][3]);                                                                                    \
+        F6_MFMA(aL[1], bf[0], acc[1][0]);                                                                                    \
+        __builtin_amdgcn_sched_barrier(0); /* (the second wait stays behind the two MFMAs that do not need it) */            \
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bf[1]), "+v"(aL[2]), "+v"(aL[3]));                                        \
+        F6_MFMA(aL[2], bf[0], acc[2][0]);                                                                                    \
+        F6_MFMA(aL[3], bf[0], acc[3][0]);                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
-        /* ---- half 0, rows 1-3 */                                                                                          \
-        _Pragma("unroll") for (int i = 1; i < 4; ++i) {                                                                      \
-            if (dma_on) F6_DMA(fsrc, 2 + i, fdst);                                                                           \
-            if (i == 1) F6_FRAG(aH[0], curA_ + ax + 4 * 256, ycA_, 4 * 256);                                                 \
-            F6_FRAG(aH[i], curA_ + ax + (4 + i) * 256, ycA_, (4 + i) * 256);                                                 \
-            _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                                               \
-                const int j = (i & 1) ? 3 - jj : jj;                                                                         \
+        /* ---- half 0, columns 1-3 */                                                                                       \
+        _Pragma("unroll") for (int j = 1; j < 4; ++j) {                                                                      \
+            if (j == 2 && (PF_)) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bf[2]));                                         \
+            if (j == 3 && (PF_)) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bf[3]));                                         \
+            if (j >= 2 && !(PF_)) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[2]), "+v"(bf[3]));                           \
+            if (dma_on) F6_DMA(fsrc, 2 + j, fdst);                                                                           \
+            if (j < 3) {                                                                                                     \
+                if (PF_) {                                                                                                   \
+                    F6_FRAG(aH[2 * j - 2], xcA_, ycA_, (4 + 2 * j - 2) * 256);                                               \
+                    F6_FRAG(aH[2 * j - 1], xcA_, ycA_, (4 + 2 * j - 1) * 256);                                               \
+                } else { /* the tile's last K-step runs into the epilogue: there the compiler may spill, and it must KNOW these reads */ \
+                    F6_FRAG_PLAIN(aH[2 * j - 2], smem + xcA_ - lds0, smem + ycA_ - lds0, (4 + 2 * j - 2) * 256);             \
+                    F6_FRAG_PLAIN(aH[2 * j - 1], smem + xcA_ - lds0, smem + ycA_ - lds0, (4 + 2 * j - 1) * 256);             \
+                }                                                                                                            \
+            }                                                                                                                \
+            _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) {                                                               \
+                const int i = (j & 1) ? 3 - ii : ii;                                                                         \
                 F6_MFMA(aL[i], bf[j], acc[i][j]);                                                                            \
             }                                                                                                                \
             __builtin_amdgcn_sched_barrier(0);                                                                               \
@@ -228,15 +249,19 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f6_kernel(const F8Args args) 
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
         F6_FETCH_ADVANCE_LOOP();                                                                                             \
         F6_FETCH_PTRS();                                                                                                     \
-        /* ---- half 1 */                                                                                                    \
+        /* ---- half 1 (rows 64-127) */                                                                                      \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \
             if (dma_on && j < 3) F6_DMA(fsrc, j, fdst);                                                                      \
-            if (PF_) F6_FRAG(aL[j], nxtA_ + ax + j * 256, ynA_, j * 256);                                                    \
+            if (PF_ && j < 2) {                                                                                              \
+                F6_FRAG(aL[2 * j], xnA_, ynA_, (2 * j) * 256);                                                               \
+                F6_FRAG(aL[2 * j + 1], xnA_, ynA_, (2 * j + 1) * 256);                                                       \
+            }                                                                                                                \
             _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) {                                                               \
                 const int i = (j & 1) ? 3 - ii : ii;                                                                         \
                 F6_MFMA(aH[i], bf[j], acc[4 + i][j]);                                                                        \
             }                                                                                                                \
-            if (PF_) F6_FRAG(bf[j], nxtB_ + bx + j * 256, ynB_, j * 256);                                                    \
+            __builtin_amdgcn_sched_barrier(0); /* the in-place reload stays behind the column's MFMAs */                     \
+            if (PF_) F6_FRAG(bf[j], xnB_, ynB_, j * 256);                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                                               \
         }                                                                                                                    \
     } while (0)
@@ -245,12 +270,12 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f6_kernel(const F8Args args) 
             {   // state of the tile the fetch stream enters during this tile (none left: the current one again, into slots nobody reads)
                 const int8_t* gs_ = gsrc;
                 const int gt_ = gstep;
-                const long long gd_ = gdelta;
+                const long long gd_ = gdelta, gd2_ = gdelta2;
                 const unsigned dl_ = dlast;
                 const int vbn_ = vb + lead * G;
                 if (vbn_ < total) F6_SET_TILE(vbn_);
-                gsrcN = gsrc, gstepN = gstep, gdeltaN = gdelta, dlastN = dlast;
-                gsrc = gs_, gstep = gt_, gdelta = gd_, dlast = dl_;
+                gsrcN = gsrc, gstepN = gstep, gdeltaN = gdelta, gdelta2N = gdelta2, dlastN = dlast;
+                gsrc = gs_, gstep = gt_, gdelta = gd_, gdelta2 = gd2_, dlast = dl_;
             }
             const int rpB = rows_pad(tmap.tn);
             const int bx = (q * rpB + wn * 64 + r16) * 16;
@@ -264,21 +289,61 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f6_kernel(const F8Args args) 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
             {  // the tile's first fragments, exposed (their panel landed before the last barrier)
-                const char* curA = smem + (2 * cs) * F6_SLOT;
-                const char* curB = curA + F6_SLOT;
-                const unsigned ybA_ = lds0 + (unsigned)((2 * cs) * F6_SLOT + ay), ybB_ = lds0 + (unsigned)((2 * cs + 1) * F6_SLOT + by);
+                const unsigned xbA_ = lds0 + (unsigned)((2 * cs) * F6_SLOT + ax), ybA_ = lds0 + (unsigned)((2 * cs) * F6_SLOT + ay);
+                const unsigned xbB_ = lds0 + (unsigned)((2 * cs + 1) * F6_SLOT + bx), ybB_ = lds0 + (unsigned)((2 * cs + 1) * F6_SLOT + by);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {  // (the K-step's staged waits count on this order: aL[0] bf[0] aL[1] bf[1] ...)
-                    F6_FRAG(aL[j], curA + ax + j * 256, ybA_, j * 256);
-                    F6_FRAG(bf[j], curB + bx + j * 256, ybB_, j * 256);
+                for (int j = 0; j < 4; ++j) {  // (in the regions the K-step's waits count: {aL0, aL1, bf0} {aL2, aL3, bf1} {bf2} {bf3})
+                    if (j < 2) {
+                        F6_FRAG(aL[2 * j], xbA_, ybA_, (2 * j) * 256);
+                        F6_FRAG(aL[2 * j + 1], xbA_, ybA_, (2 * j + 1) * 256);
+                    }
+                    F6_FRAG(bf[j], xbB_, ybB_, j * 256);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            for (int kt = 0; kt + 1 < KT; ++kt) F6_KSTEP(true);
-            F6_KSTEP(false);
+            if constexpr (EPI == EPI_FUSED || EPI == EPI_FUSED_CPLX) {
+                // three K segments (the modulus' three products); between them the accumulators -- exact integers -- are replaced by m x (their loose
+                // residue mod p), three fp32 instructions + the product each (f8_fill_planes has the algebra, oz2_gemm_f8_epi.hpp red_acc the bound)
+                const F8Plane plc = f8_plane(args, tmap.plane);
+                const float pf = (float)args.moduli[args.t_begin + plc.tt], invp = 1.0f / pf;
+                float mm = args.m1[plc.tt];
+                int kseg = KT1;  // K-steps until the next transform
+                for (int kt = 0; kt + 1 < KT; ++kt) {
+                    F6_KSTEP(true);
+                    if (--kseg == 0) {  // (uniform, twice per tile)
+                        // the fragments prefetched for the next K-step are inline-asm reads the compiler does not know to be in flight: were it to
+                        // spill one around the arithmetic below it would store a register that has not landed -- so they land first
+                        asm volatile("s_waitcnt lgkmcnt(0)"
+                                     : "+v"(aL[0]), "+v"(aL[1]), "+v"(aL[2]), "+v"(aL[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]));
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float c = acc[i][j][r];
+                                    acc[i][j][r] = mm * fmaf(-rintf(c * invp), pf, c);
+                                }
+                        mm = args.m2[plc.tt];
+                        kseg = KT1;
+                    }
+                }
+                F6_KSTEP(false);
+            } else {
+                for (int kt = 0; kt + 1 < KT; ++kt) F6_KSTEP(true);
+                F6_KSTEP(false);
+            }
+#if OZ2_HOOK_SKIP_EPILOGUE
+            (void)tmap;  // laboratory probe: no epilogue; the accumulators stay live
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+#else
             const int i0 = tmap.tm * BM + wm * 128, j0 = tmap.tn * BN + wn * 64;
             const F8Plane pl = f8_plane(args, tmap.plane);
             f8_epilogue_mod<EPI>(acc, args, pl, i0, j0, lane);
+#endif
         }
     };
     if (isB) run.template operator()<true>();
@@ -287,6 +352,7 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f6_kernel(const F8Args args) 
 #undef F6_SET_TILE
 #undef F6_DMA
 #undef F6_FRAG
+#undef F6_FRAG_PLAIN
 #undef F6_MFMA
 #undef F6_KSTEP
 #undef F6_FETCH_PTRS
@@ -528,6 +594,8 @@ hipError_t launch_gemm_f6(hipStream_t stream, int which, const int8_t* A, const 
     F8Args a{};
     if (f8_fill_planes(a, which, A, B, strideA, strideB, kp, m, n, t_begin, t_end, out, ldo, strideO, r0, r1, strideR, rx, ry) != 0) return hipErrorInvalidValue;
     const int planes = t_end - t_begin;
+    if (which == 7) return launch<EPI_FUSED>(stream, a, planes);
+    if (which == 8) return launch<EPI_FUSED_CPLX>(stream, a, planes);
     if (which == 3 || which == 6) return launch<EPI_FINAL_CPLX>(stream, a, planes);
     return (which == 2 || which == 5) ? launch<EPI_FINAL>(stream, a, planes) : launch<EPI_PART>(stream, a, planes);
 }

@@ -19,15 +19,20 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 //   Stage 3, reference (args.cplx_rule = 0): s0 = add_ru(fma_ru(ku, c, c), s12).  Default here (cplx_rule = 1):
 //   s0 = add_ru(fma_ru(ku, add_ru(|c|, 2 s12), c), s12) -- c is a sum of products of BOTH signs, so the engine's truncation error on it
 //   scales with the sum of the MAGNITUDES of its terms (<= T + C1, T = the bound sought, C1 <= s12), not with |c|: see bound_ku below
-enum { EPI_PART = 0, EPI_FINAL = 1, EPI_FMAX = 2, EPI_FINAL_CPLX = 3, EPI_FB1 = 4, EPI_FB2 = 5, EPI_FB3 = 6 };
+// EPI_FUSED / EPI_FUSED_CPLX (round 5, FP6 kernel): the three products of a modulus as ONE tile loop over three K segments -- between the segments the
+//   accumulators are replaced by m x (their loose residue), so that the tile ends with  gam x acc == value (mod p): no partial-residue planes at all.
+enum { EPI_PART = 0, EPI_FINAL = 1, EPI_FMAX = 2, EPI_FINAL_CPLX = 3, EPI_FB1 = 4, EPI_FB2 = 5, EPI_FB3 = 6, EPI_FUSED = 7, EPI_FUSED_CPLX = 8 };
 
 struct F8Args {
     const int8_t* A;      // base of the A planes; plane of block b at A + planeA[b]*strideA
     const int8_t* B;
     size_t strideA, strideB;
     int planeA[20], planeB[20];
-    int planeA2[20], planeB2[20];  // nseg == 2: operand planes of the second K segment (K-concatenation: C0 + C1 in ONE accumulator)
-    int nseg;                      // 1, or 2: virtual K = 2 kp -- exact while 2 k * 256 <= 2^24 (launch_gemm_f8 checks)
+    int planeA2[20], planeB2[20];  // nseg >= 2: operand planes of the second K segment (K-concatenation: C0 + C1 in ONE accumulator)
+    int planeA3[20], planeB3[20];  // nseg == 3 (EPI_FUSED*): operand planes of the third K segment
+    float m1[20], m2[20];          // EPI_FUSED*: accumulator <- m x loose residue behind segment 1 / 2 (f8_fill_planes)
+    int gam[20];                   //             value == gam x final accumulator (mod p)
+    int nseg;                      // 1; 2: virtual K = 2 kp -- exact while 2 k * 256 <= 2^24 (launch_gemm_f8 checks); 3: EPI_FUSED*
     int nres;                      // EPI_FINAL / EPI_FINAL_CPLX: residue planes combined with the accumulator: 2 (r0, r1), or 1 (r0 = residue of C0 + C1)
     int kp, m, n, tiles_m, tiles_n;
     int colblock;  // tile-columns per column block of the tile walk (map_colblock; 0 = full width)
@@ -83,9 +88,12 @@ constexpr int F8_THREADS = 512;
 #ifndef OZ2_HOOK_KSTEP
 #define OZ2_HOOK_KSTEP(kin) (kin)
 #endif
+#ifndef OZ2_HOOK_SKIP_EPILOGUE
+#define OZ2_HOOK_SKIP_EPILOGUE 0
+#endif
 
 // int16 residue epilogues (EPI_PART / EPI_FINAL / EPI_FINAL_CPLX) of a wave's 128 x 64 accumulator block.  The accumulators are exact integers
-// (|c| <= 2^24): one exact FP64 quotient step (five full-rate instructions); the combined value (|v| < 2^18) needs one fp32 step.
+// (|c| <= 2^24): a loose three-instruction fp32 residue (red_acc below); the combined value (|v| < 2^18) needs one fp32 step for the canonical one.
 // ONE reduction form for every modulus (round 4): q = ceil(x / p - 1/2), r = x - q p, the representative in (-p/2, p/2].  For odd p that is the
 // symmetric residue (x / p - 1/2 is never an integer; its distance from one is >= 1/(2p) = 4.6e-4, the evaluation errors are 1e-12 in FP64 and
 // 4.5e-5 in fp32 for |v| < 2^18: CPU models in tests/test_residue_math.py), for p = 1024 -- the only even FP8 modulus, where the arithmetic is
@@ -114,15 +122,18 @@ __device__ __forceinline__ void f8_epilogue_mod(const v4f (&acc)[8][4], const F8
     const int k1 = t < 6 ? k0 : -15;
     const int k2 = t < 6 ? 1 : 16;
     const float pf = (float)p, invp = 1.0f / pf;
-    const double pd = (double)p, invpd = 1.0 / pd;
-    auto red_acc = [&](float c) -> int {
-        const double x = (double)c;
-        return (int)fma(-ceil(fma(x, invpd, -0.5)), pd, x);
-    };
+    // Accumulators (exact integers, |c| <= 2^24): a LOOSE residue in three fp32 instructions (round 5; rounds 1-4: one FP64 quotient step, five
+    // instructions at a quarter of the rate).  q = rint(RN32(c RN32(1/p))) is within 2^-7 of c / p, r = fma(-q, p, c) is formed EXACTLY (q p < 2^26
+    // inside the fma, the result is a small integer): r == c (mod p), |r| <= (1/2 + 2^-7) p.  A loose residue is all these uses need -- the int16
+    // scratch planes of the partial products and the input of the combination k0 R0 + k1 R1 + k2 R2 (|.| <= 271 * 0.508 * 511 < 2^17), whose own
+    // reduction red_small yields the canonical representative; C_mid is unchanged bit for bit (CPU model: tests/test_residue_math.py).
+    auto red_acc = [&](float c) -> int { return (int)fmaf(-rintf(c * invp), pf, c); };
     auto red_small = [&](int v) -> int {
         const float vf = (float)v;
         return (int)fmaf(-ceilf(fmaf(vf, invp, -0.5f)), pf, vf);
     };
+    constexpr bool FUSED = EPI == EPI_FUSED || EPI == EPI_FUSED_CPLX;
+    [[maybe_unused]] const int gam = args.gam[t];  // FUSED: the canonical residue is that of gam x (loose residue of the accumulator), |.| <= 16 * 0.508 p
     // int16 residues of the 64 x 16 sub-block (tj, tg): z[0..7] = this lane's 16 consecutive rows (first row i0 + 64 tg + 16 q) of column j0 + 16 tj + c16
     auto reduce_block = [&](int tj, int tg, unsigned (&z)[8]) {
         unsigned d[4][2];  // tile ti of the group: this lane quad's rows 4 q .. 4 q + 3 as 4 x int16
@@ -130,7 +141,7 @@ __device__ __forceinline__ void f8_epilogue_mod(const v4f (&acc)[8][4], const F8
         for (int ti = 0; ti < 4; ++ti) {
             int r[4];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) r[b] = red_acc(acc[tg * 4 + ti][tj][b]);
+            for (int b = 0; b < 4; ++b) r[b] = FUSED ? red_small(gam * red_acc(acc[tg * 4 + ti][tj][b])) : red_acc(acc[tg * 4 + ti][tj][b]);
             d[ti][0] = pack16(r[0], r[1]);
             d[ti][1] = pack16(r[2], r[3]);
         }
@@ -150,7 +161,7 @@ __device__ __forceinline__ void f8_epilogue_mod(const v4f (&acc)[8][4], const F8
     };
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     const size_t po = (size_t)plane * args.strideO, pr = (size_t)plane * args.strideR;
-    if constexpr (EPI == EPI_PART || EPI == EPI_FINAL_CPLX) {
+    if constexpr (EPI == EPI_PART || EPI == EPI_FINAL_CPLX || FUSED) {
         // EPI_FINAL_CPLX keeps the sub-block-by-sub-block form: five plane pointers and 64 more registers of X / Y residues beside the kernel's DMA
         // state do not fit the two-pass form below (it was built: 290-750 bytes of scratch, reloads between the stores)
 #pragma unroll
@@ -162,11 +173,12 @@ __device__ __forceinline__ void f8_epilogue_mod(const v4f (&acc)[8][4], const F8
                 reduce_block(tj, tg, z);
                 if (col < args.n) {
                     const size_t e = (size_t)col * args.ldo + i0 + tg * 64 + q * 16;
-                    if constexpr (EPI == EPI_PART) {
+                    if constexpr (EPI == EPI_PART || EPI == EPI_FUSED) {
                         v4u* dst = (v4u*)(out_ + po + e);
                         dst[0] = v4u{z[0], z[1], z[2], z[3]};
                         dst[1] = v4u{z[4], z[5], z[6], z[7]};
                     } else {
+                        if constexpr (EPI == EPI_FINAL_CPLX) {  // (EPI_FUSED_CPLX: z already holds the canonical residue of the part Z)
                         const v4u* p0 = (const v4u*)(r0_ + pr + e);
                         const v4u x0 = p0[0], x1 = p0[1];
                         v4u y0 = v4u{0, 0, 0, 0}, y1 = y0;
@@ -185,6 +197,7 @@ __device__ __forceinline__ void f8_epilogue_mod(const v4f (&acc)[8][4], const F8
                                 o[hlf] = red_small(k0 * a0 + k1 * a1 + k2 * a2);
                             }
                             z[w] = pack16(o[0], o[1]);
+                        }
                         }
                         const v4u* px = (const v4u*)(rx_ + pr + e);
                         const v4u* py = (const v4u*)(ry_ + pr + e);
@@ -380,12 +393,37 @@ inline int f8_fill_planes(F8Args& a, int which, const int8_t* A, const int8_t* B
     a.strideR = strideR;
     a.rx = rx;
     a.ry = ry;
-    const bool concat = which == 4, single = which == 5 || which == 6;
+    const bool concat = which == 4, single = which == 5 || which == 6, fused = which == 7 || which == 8;
     const int wh = (which == 3 || single) ? 2 : which;
-    a.nseg = concat ? 2 : 1;
+    a.nseg = fused ? 3 : concat ? 2 : 1;
     a.nres = single ? 1 : 2;
     for (int t = t_begin; t < t_end; ++t) {
         const int q = f8_first_plane(t), b = t - t_begin;
+        if (fused) {
+            // which = 7 / 8 (FP6 kernel): all three products of a modulus in ONE tile loop over three K segments (no partial-residue planes): behind
+            // segment 1 the accumulators become m1 x (their loose residue), behind segment 2 m2 x ..., and value == gam x acc (mod p) at the end:
+            //   squares (t < 6):  value = s (C0 + C1) + C2:   segments Ahi Blo | Alo Bhi | Alo Blo,      m1 = 1, m2 = s, gam = 1
+            //   Karatsuba:        value = 240 C0 - 15 C1 + 16 C2 = 16 (m2 (-16 C0 + C1) + C2), m2 == -15 / 16 (mod p):
+            //                     segments hi hi | lo lo | (hi+lo)(hi+lo),                               m1 = -16, gam = 16
+            // Every accumulator stays an exact integer below 2^24 while kp * 256 + 255 * 0.508 p <= 2^24 (kp <= 65024: the caller checks).
+            const int p = GEMMUL8_MODULI_FP8[t];
+            if (t < 6) {
+                a.planeA[b] = q, a.planeB[b] = q + 1;
+                a.planeA2[b] = q + 1, a.planeB2[b] = q;
+                a.planeA3[b] = q + 1, a.planeB3[b] = q + 1;
+                a.m1[b] = 1.0f, a.m2[b] = (float)GEMMUL8_SQRT_MODULI_FP8[t], a.gam[t] = 1;
+            } else {
+                a.planeA[b] = q, a.planeB[b] = q;
+                a.planeA2[b] = q + 1, a.planeB2[b] = q + 1;
+                a.planeA3[b] = q + 2, a.planeB3[b] = q + 2;
+                int inv16 = 1;
+                while ((16 * inv16) % p != 1) ++inv16;
+                int m2 = (int)(((long long)(p - 15) * inv16) % p);  // -15 / 16 mod p
+                if (m2 > p / 2) m2 -= p;
+                a.m1[b] = -16.0f, a.m2[b] = (float)m2, a.gam[t] = 16;
+            }
+            continue;
+        }
         if (concat) {  // (t < 6 only) segment 1: C0 = Ahi * Blo, segment 2: C1 = Alo * Bhi
             if (t >= 6) return -1;
             a.planeA[b] = q, a.planeB[b] = q + 1;
@@ -399,6 +437,7 @@ inline int f8_fill_planes(F8Args& a, int which, const int8_t* A, const int8_t* B
             a.planeB[b] = q + wh;
         }
         if (!concat) a.planeA2[b] = a.planeA[b], a.planeB2[b] = a.planeB[b];
+        a.planeA3[b] = a.planeA2[b], a.planeB3[b] = a.planeB2[b];
     }
     f8_fill_common(a, kp, m, n);
     return 0;

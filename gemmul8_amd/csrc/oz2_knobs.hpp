@@ -13,6 +13,7 @@ struct Knobs {
     int cplx_chunk = 0;            // GEMMUL8_CPLX_CHUNK=<n>: moduli per X / Y / Z launch group of the complex INT8 path (0: as many as the scratch holds)
     int crt_kernel = 0;            // GEMMUL8_CRT_KERNEL=dma|reg: force the LDS-DMA (1) / register (2) form of the CRT kernel (0: by eligibility and size)
     int fp8_planes = 0;            // GEMMUL8_FP8_PLANES=e4m3|fp6: FP8 backend's residue planes as e4m3 bytes (1) / FP6 panel images where they fit (0, default)
+    int fp8_fused = 1;             // GEMMUL8_FP8_FUSED=0: FP6 planes, but the three products of a modulus as two or three launches with int16 partial-residue planes (the round-4 structure) instead of one three-segment tile loop
     int gemm_cus = 0;              // GEMMUL8_GEMM_CUS=<n>: workgroups (= CUs) of the persistent INT8 residue-GEMM launches, a multiple of 8 (0: every CU); the phase-overlap measurements leave CUs to a second stream with it
     int map_colblock = -1;         // GEMMUL8_MAP_COLBLOCK=<w>: tile-columns per column block of the GEMM tile walk, 0 = full width (-1: map_colblock's rule)
 };

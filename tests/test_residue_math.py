@@ -410,24 +410,70 @@ def test_fp8_epilogue_small_reduction_exhaustive(p):
 
 @pytest.mark.parametrize("p", FP8_MODULI)
 def test_fp8_epilogue_accumulator_reduction(p):
-    """red_acc: q = ceil(fma(double(c), RN64(1/p), -0.5)), r = c - q p for the exact integer accumulators |c| <= 2^24 (k <= 65536 with |a|, |b| <= 16):
-    every residue class next to many quotients including the half-way points, the range ends, and random values; the fma is modelled exactly
-    with rationals (its rounding to double, 2^-38 absolute here, cannot reach an integer: the distance is >= 1/(2p) for odd p, and for p = 1024
-    the arithmetic is exact)."""
-    from fractions import Fraction
-    import math
+    """red_acc (round 5): the LOOSE fp32 residue of an exact integer accumulator |c| <= 2^24 (k <= 65536 with |a|, |b| <= 16):
+    t = RN32(c * RN32(1/p)), q = rint(t) (ties to even), r = fma(-q, p, c).  Modelled in exact integer arithmetic with numpy's float32 product (one
+    rounding): r == c (mod p), |r| <= (1/2 + 2^-7) p (quotients reach 2^15.2 for the smallest moduli: half an ulp of the product plus the error of RN32(1/p)), q p and r are exactly representable where the fma forms them, and r fits the int16 scratch
+    planes; then the combination k0 R0 + k1 R1 + k2 R2 of three loose residues stays inside the exhaustively tested range of red_small (2^18),
+    whose result is the canonical residue of the exact value."""
     rng = np.random.default_rng(3000 + p)
     lim = 1 << 24
-    qs = np.concatenate([rng.integers(-(lim // p), lim // p, size=300), [-(lim // p), lim // p - 1, 0, 1, -1]])
-    rs = np.arange(-(p // 2) - 1, p // 2 + 2)
-    xs = np.concatenate([np.clip((qs[:, None] * p + rs[None, :]).ravel(), -lim, lim), rng.integers(-lim, lim + 1, size=20000),
-                         np.arange(-lim, -lim + 2000), np.arange(lim - 2000, lim + 1)])
-    xs = np.unique(xs)[:: max(1, len(np.unique(xs)) // 60000)]
-    invpd = Fraction(float(1.0 / p))
-    got = np.empty(len(xs), dtype=np.int64)
-    for i, x in enumerate(xs.tolist()):
-        y = float(Fraction(x) * invpd - Fraction(1, 2))                       # fma: one rounding
-        got[i] = x - math.ceil(y) * p
-        exact = Fraction(x, p) - Fraction(1, 2)
-        assert math.ceil(y) == math.ceil(exact), (x, p)
-    assert np.array_equal(got, _sym_half_open(xs, p))
+    qs = np.concatenate([rng.integers(-(lim // p), lim // p, size=400), [-(lim // p), lim // p - 1, 0, 1, -1]])
+    rs = np.arange(-(p // 2) - 2, p // 2 + 3)
+    xs = np.concatenate([np.clip((qs[:, None] * p + rs[None, :]).ravel(), -lim, lim), rng.integers(-lim, lim + 1, size=200000),
+                         np.arange(-lim, -lim + 4000), np.arange(lim - 4000, lim + 1)])
+    xs = np.unique(xs)
+    invp = np.float32(1.0) / np.float32(p)
+    t = xs.astype(np.float32) * invp                       # |c| <= 2^24 is exact in float32; one rounding in the product
+    q = np.rint(t.astype(np.float64)).astype(np.int64)     # rint of a float32 value: ties to even, as v_rndne_f32
+    r = xs - q * p
+    assert np.all(np.mod(r - xs, p) == 0)
+    assert np.max(np.abs(r)) <= (0.5 + 2.0 ** -7) * p + 1e-9, (p, np.max(np.abs(r)))
+    assert np.max(np.abs(q * p)) < (1 << 26) and np.max(np.abs(r)) < 32768
+    # the combination of three loose residues (worst coefficients: Karatsuba 240, -15, 16 for p <= 511; squares s, s, 1) and its canonical reduction
+    t_idx = FP8_MODULI.index(p)
+    k0, k1, k2 = ((int(round(p ** 0.5)),) * 2 + (1,)) if t_idx < 6 else (240, -15, 16)
+    bound = (abs(k0) + abs(k1) + abs(k2)) * np.max(np.abs(r))
+    assert bound < (1 << 18), (p, bound)
+    a = rng.choice(r, size=(3, 50000))
+    v = k0 * a[0] + k1 * a[1] + k2 * a[2]
+    y = (v.astype(np.float64) * np.float64(invp) - 0.5).astype(np.float32)
+    got = v - np.ceil(y.astype(np.float64)).astype(np.int64) * p
+    assert np.array_equal(got, _sym_half_open(v, p))
+
+
+@pytest.mark.parametrize("p", FP8_MODULI)
+def test_fp8_fused_three_segment_tile_loop(p):
+    """Round 5, FP6 kernel (csrc/oz2_gemm_f8_epi.hpp f8_fill_planes which = 7 / 8): the three products S0, S1, S2 of a modulus run as ONE tile loop; behind
+    segment 1 the accumulators become m1 x loose(acc), behind segment 2 m2 x loose(acc), and the canonical residue of gam x loose(final acc) must equal
+    the canonical residue of the reference's value -- s (S0 + S1) + S2 for the square moduli (mod.hpp:176-189), 256 S0 + 16 (S2 - S0 - S1) + S1 for the
+    Karatsuba ones (mod.hpp:117-129) -- while every accumulator stays an exact integer below 2^24 at the largest padded k the fused form is used for
+    (65024: |S| <= 65024 * 256)."""
+    rng = np.random.default_rng(5000 + p)
+    t = FP8_MODULI.index(p)
+    lim = 65024 * 256
+    n = 200000
+    S = rng.integers(-lim, lim + 1, size=(3, n))
+    S[:, :8] = np.array([[lim, lim, lim], [-lim, -lim, -lim], [lim, -lim, lim], [-lim, lim, -lim], [0, 0, 0], [1, -1, 1], [lim, 0, -lim], [p, p, p]]).T
+    invp = np.float32(1.0) / np.float32(p)
+
+    def loose(c):
+        assert np.max(np.abs(c)) < (1 << 24), (p, np.max(np.abs(c)))          # exact in float32, as an MFMA accumulator
+        q = np.rint((c.astype(np.float32) * invp).astype(np.float64)).astype(np.int64)
+        return c - q * p
+    if t < 6:
+        s = int(round(p ** 0.5))
+        m1, m2, gam = 1, s, 1
+        value = s * (S[0] + S[1]) + S[2]
+    else:
+        inv16 = next(i for i in range(1, p) if (16 * i) % p == 1)
+        m2 = ((p - 15) * inv16) % p
+        m2 = m2 - p if m2 > p // 2 else m2
+        m1, gam = -16, 16
+        value = 256 * S[0] + 16 * (S[2] - S[0] - S[1]) + S[1]
+    acc = m1 * loose(S[0]) + S[1]
+    acc = m2 * loose(acc) + S[2]
+    v = gam * loose(acc)
+    assert np.max(np.abs(v)) < (1 << 18)
+    y = (v.astype(np.float64) * np.float64(invp) - 0.5).astype(np.float32)
+    got = v - np.ceil(y.astype(np.float64)).astype(np.int64) * p
+    assert np.array_equal(got, _sym_half_open(value, p))

@@ -3,7 +3,8 @@
 loaded in ONE process and timed INTERLEAVED (A,B,C,A,B,C,...).  The operand planes are the real ones: the first build quantises random
 U(-0.5, 0.5) operands once per plane format (GEMMUL8_FP8_PLANES), every build multiplies the same planes.
 usage: python tools/f8_ab.py [--size 8192] [--k 8192] [--moduli 6] [--rounds 7] [--check] [--smi] lib_a.so[:e4m3] lib_b.so ...
-       a ':e4m3' suffix runs that build on e4m3 byte planes (the round-4 kernel) instead of FP6 panel images"""
+       a ':e4m3' suffix runs that build on e4m3 byte planes (the round-4 kernel) instead of FP6 panel images, ':nofuse' on FP6 planes with the
+       three products of a modulus as separate launches (GEMMUL8_FP8_FUSED=0)"""
 import argparse
 import ctypes as C
 import os
@@ -35,7 +36,7 @@ ref = g.lib()
 dt = g.S if a.dtype == "S" else g.D
 tdt = torch.float32 if a.dtype == "S" else torch.float64
 tmp = tempfile.mkdtemp()
-libs, fmts = [], []
+libs, fmts, nofuse = [], [], []
 for i, spec in enumerate(a.libs):
     pth, _, fmt = spec.partition(":")
     cp = os.path.join(tmp, f"v{i}.so")
@@ -47,6 +48,7 @@ for i, spec in enumerate(a.libs):
     L.gemmul8_reload_knobs.restype = None
     libs.append(L)
     fmts.append("e4m3" if fmt == "e4m3" else "fp6")
+    nofuse.append(fmt == "nofuse")
 st = torch.cuda.current_stream().cuda_stream
 for k in [int(x) for x in a.k.split(",")]:
     torch.manual_seed(k)
@@ -64,9 +66,11 @@ for k in [int(x) for x in a.k.split(",")]:
         g.check(L0.gemmul8_scale(st, dt, g.FP8, 0, 0, n, n, k, A.data_ptr(), n, B.data_ptr(), k, N, 1, 0, N, C.byref(Lo), 0, 0))
         torch.cuda.synchronize()
         works[fmt], Ls[fmt] = w, Lo
-    for L, fmt in zip(libs, fmts):  # every build reads the knob once: its own format
+    for L, fmt, nf in zip(libs, fmts, nofuse):  # every build reads the knobs once: its own format; ':nofuse' = FP6 planes, three-launch form
         os.environ["GEMMUL8_FP8_PLANES"] = fmt
+        os.environ["GEMMUL8_FP8_FUSED"] = "0" if nf else "1"
         L.gemmul8_reload_knobs()
+    os.environ.pop("GEMMUL8_FP8_FUSED", None)
     ts = [[] for _ in libs]
     for r in range(a.rounds + 2):
         for i, L in enumerate(libs):
