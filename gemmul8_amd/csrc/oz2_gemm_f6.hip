@@ -229,7 +229,8 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f6_kernel(const F8Args args) 
             if (j >= 2 && !(PF_)) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[2]), "+v"(bf[3]));                           \
             if (dma_on) F6_DMA(fsrc, 2 + j, fdst);                                                                           \
             if (j < 3) {                                                                                                     \
-                if (PF_) {                                                                                                   \
+                if (OZ2_HOOK_SKIP_AH) { /* laboratory probe: a third of the fragment reads not issued (stale registers) */     \
+                } else if (PF_) {                                                                                            \
                     F6_FRAG(aH[2 * j - 2], xcA_, ycA_, (4 + 2 * j - 2) * 256);                                               \
                     F6_FRAG(aH[2 * j - 1], xcA_, ycA_, (4 + 2 * j - 1) * 256);                                               \
                 } else { /* the tile's last K-step runs into the epilogue: there the compiler may spill, and it must KNOW these reads */ \

@@ -88,6 +88,9 @@ constexpr int F8_THREADS = 512;
 #ifndef OZ2_HOOK_KSTEP
 #define OZ2_HOOK_KSTEP(kin) (kin)
 #endif
+#ifndef OZ2_HOOK_SKIP_AH
+#define OZ2_HOOK_SKIP_AH 0  // FP6 kernel: 1 = a third of the fragment reads (rows 64-127 of A) not issued (timing probe; stale registers)
+#endif
 #ifndef OZ2_HOOK_SKIP_EPILOGUE
 #define OZ2_HOOK_SKIP_EPILOGUE 0
 #endif

@@ -395,6 +395,9 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #ifdef OZ2_LAB_SELFPIPE  // laboratory build only (tools/build_probes.sh sp="-DOZ2_LAB_SELFPIPE=1"): the self-pipelined 8-wave form of the residue GEMM
 #include "../../tools/experiments/gemm_i8_selfpipe.inc"
 #endif
+#ifdef OZ2_LAB_W4  // laboratory build only (tools/build_probes.sh w4="-DOZ2_LAB_W4=1"): four waves x 512 registers, wave tile 128 x 128
+#include "../../tools/experiments/gemm_i8_w4.inc"
+#endif
 
 static void fill_common(GemmArgs& a, size_t kp, size_t m, size_t n) {
     a.kp = (int)kp;
@@ -482,6 +485,23 @@ template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int
             if (a.total_tiles < grid) grid = a.total_tiles;
             if (a.acc0 == 0) hipLaunchKernelGGL((gemm_i8_selfpipe_kernel<EPI, true>), dim3(grid), dim3(512), RING_LDS_BYTES, stream, a);
             else hipLaunchKernelGGL((gemm_i8_selfpipe_kernel<EPI, false>), dim3(grid), dim3(512), RING_LDS_BYTES, stream, a);
+            return hipGetLastError();
+        }
+    }
+#endif
+#ifdef OZ2_LAB_W4
+    if constexpr (EPI != EPI_MAX) {
+        if (a.nseg == 1 && a.kp >= 4 * BK) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)gemm_i8_w4_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_i8_w4_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS_BYTES);
+                attr_set = true;
+            }
+            int grid = num_cus() & ~7;
+            if (a.total_tiles < grid) grid = a.total_tiles;
+            if (a.acc0 == 0) hipLaunchKernelGGL((gemm_i8_w4_kernel<EPI, true>), dim3(grid), dim3(256), RING_LDS_BYTES, stream, a);
+            else hipLaunchKernelGGL((gemm_i8_w4_kernel<EPI, false>), dim3(grid), dim3(256), RING_LDS_BYTES, stream, a);
             return hipGetLastError();
         }
     }

@@ -15,7 +15,7 @@ namespace oz2 {
 // no timing ablation.  Laboratory builds (tools/experiments/: real-data timing probes, the in-kernel CRT forms) compile a second TU that
 // defines OZ2_LAB_* and #includes this file; the shipped Makefile passes -DOZ2_PRODUCT_BUILD, which refuses every such macro, so no
 // -D in EXTRA can turn libgemmul8.so into a library that computes something else.
-#if defined(OZ2_PRODUCT_BUILD) && (defined(OZ2_LAB_HOOKS) || defined(OZ2_LAB_FUSED_CRT) || defined(OZ2_LAB_SHORTK) || defined(OZ2_LAB_SELFPIPE))
+#if defined(OZ2_PRODUCT_BUILD) && (defined(OZ2_LAB_HOOKS) || defined(OZ2_LAB_FUSED_CRT) || defined(OZ2_LAB_SHORTK) || defined(OZ2_LAB_SELFPIPE) || defined(OZ2_LAB_W4))
 #error "laboratory switches (OZ2_LAB_*) are not allowed in the product build of libgemmul8.so: use tools/experiments/"
 #endif
 #ifdef OZ2_LAB_HOOKS
