@@ -421,8 +421,10 @@ bool try_dist(int kind, int dtype, int backend, hipblasOperation_t ta, hipblasOp
 // per type against the native routine on the same box; median model error 5-7 %).  On the scanned shapes the rule emulates 31-53 of
 // 180-204 cases per type and mode, lets 0-2 marginal losses through (worst 1.05x the native time, one 1.19x), and the summed time is
 // within 0.3-10 % of always picking the faster of the two (always-native: +25-45 %); repeated on a second box with the final binaries
-// (r03_floor_scan2_*.csv, not used for the fit) it stays within 0.4-12 % (tests/test_hook_floor.py).  The FP8 backend costs ~2.2x
-// the INT8 one.
+// (r03_floor_scan2_*.csv, not used for the fit) it stays within 0.4-12 % (tests/test_hook_floor.py).  The FP8 backend is priced as
+// the INT8 model x a per-type factor: the median time ratio at EQUAL moduli count over the same shape classes on the round-5 kernels (FP6 operand
+// planes, fused three-product tile loop; tools/fp8_factor_scan.py, profiles/sweeps/r05_fp8_factor_{s,d,c,z}.csv: 1.74 / 1.90 / 2.04 / 2.12,
+// range 1.3-3.1; 2.2 for every type until round 4).
 // GEMMUL8_MIN_FLOPS unset / 0 = the reference's behaviour (emulate every call); any other number is a plain floor on 2*m*n*k per call.
 // GEMMUL8_HOOK_STATS=1: how much of an application's GEMM work the hook reaches (tests/test_gpu_hook_reach.py)
 // A call handed to the native routine comes back through the interposed layers below it (hipblasDgemm -> rocblas_dgemm ->
@@ -475,7 +477,8 @@ static bool floor_model_declines(int dtype, double m, double n, double k, unsign
     const FloorModel& fm = kFloor[dtype][fast ? 1 : 0];
     const double mk = (m + n) * k, mn = m * n, mnk = mn * k, Nd = (double)N;
     double te = fm.e[0] + batch * ((fm.e[1] + fm.e[2] * Nd) * mk + (fm.e[3] + fm.e[4] * Nd) * mn + fm.e[5] * Nd * mnk);
-    if (backend == GEMMUL8_FP8) te *= 2.2;
+    static const double kFp8Factor[4] = {1.75, 1.9, 2.05, 2.1};  // [S, D, C, Z]
+    if (backend == GEMMUL8_FP8) te *= kFp8Factor[dtype];
     const double tn = fm.n[0] + batch * (fm.n[1] * mn + fm.n[2] * mnk);
     return te > 0.95 * tn;
 }
@@ -496,7 +499,7 @@ bool below_floor(int dtype, double m, double n, double k, unsigned N, bool fast,
         std::call_once(told, [&] {
             std::fprintf(stderr, "[GEMMUL8 HOOK] GEMMUL8_MIN_FLOPS=%s: a %cGEMM %.0f x %.0f x %.0f (batch %.0f, %u moduli%s) stays on the native routine -- "
                                  "calls below the floor are NOT emulated (this message is printed once)\n",
-                         s, "SDCZ"[dtype], m, n, k, batch, N, backend == GEMMUL8_FP8 ? ", FP8 backend: cost x 2.2" : "");
+                         s, "SDCZ"[dtype], m, n, k, batch, N, backend == GEMMUL8_FP8 ? ", FP8 backend: cost x 1.75-2.1" : "");
         });
     }
     return declined;
@@ -523,13 +526,13 @@ bool try_emulate_impl(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, 
     const bool enA = env_one("GEMMUL8_SKIP_SCALE_A"), enB = env_one("GEMMUL8_SKIP_SCALE_B");
     const int backend = env_backend("GEMMUL8_BACKEND", 0, false);
     if (backend == GEMMUL8_FP8) {
-        // the FP8 backend exists for parity with the reference; on this chip it is dominated: three FP8 GEMMs per modulus at about the
-        // INT8 MFMA rate against one INT8 GEMM (profiles/sweeps/*_types_backends.csv: SGEMM 8192^3 133 vs 305 TFLOPS, native 152;
-        // DGEMM 69 vs 160, native 72).  Say so once.
+        // the FP8 backend exists for parity with the reference; on this chip the INT8 backend dominates it: three GEMMs per modulus (on FP6 codes
+        // of the backend's integer pieces, 1.5x the INT8 kernel's rate since round 5) against one INT8 GEMM (profiles/sweeps/r05_types_backends.csv:
+        // SGEMM 8192^3 183 vs 296 TFLOPS, native 150; DGEMM 91 vs 159, native 70).  Say so once.
         static std::once_flag told;
         std::call_once(told, [] {
-            std::fprintf(stderr, "[GEMMUL8 HOOK] GEMMUL8_BACKEND=FP8: on MI355X the INT8 backend (GEMMUL8_BACKEND=0) is ~2.2x faster at equal or better "
-                                 "accuracy for S/D/C/Z, and the FP8 backend is slower than the native SGEMM / DGEMM; continuing with FP8 as requested\n");
+            std::fprintf(stderr, "[GEMMUL8 HOOK] GEMMUL8_BACKEND=FP8: on MI355X the INT8 backend (GEMMUL8_BACKEND=0) is 1.6-2x faster at equal or better "
+                                 "accuracy for S/D/C/Z; continuing with FP8 as requested\n");
         });
     }
     if (below_floor(dtype, m, n, k, N, fastmode, backend)) return false;

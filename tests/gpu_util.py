@@ -59,6 +59,35 @@ def f6_plane_values(buf, rows, rows_img, kp):
     return out
 
 
+def f6_plane_image(vals, rows_img, kp, nbytes):
+    """Inverse of f6_plane_values: the FP6 panel-image bytes (length nbytes) of integers vals[rows, kp], |v| <= 16; rows beyond vals are zero."""
+    buf = np.zeros(nbytes, np.uint8)
+    rows = vals.shape[0]
+    kt_n = kp // 128
+    nb = (rows_img + 255) // 256
+    blockbytes = 256 * (kp // 4 * 3)
+    for tb in range(nb):
+        nr = min(256, rows_img - 256 * tb)
+        rp = 256 if tb < nb - 1 else (nr + 15) // 16 * 16
+        blk = np.zeros((rp, kp), np.int16)
+        r0, r1 = 256 * tb, min(rows, 256 * tb + rp)
+        if r1 > r0:
+            blk[:r1 - r0] = vals[r0:r1]
+        codes = (np.where(blk < 0, 32, 0) | np.abs(blk)).astype(np.uint8)                       # [rp][kp]
+        bits = ((codes[..., None] >> np.arange(6, dtype=np.uint8)) & 1).astype(np.uint8)          # [rp][kp][6]
+        frag = np.packbits(bits.reshape(rp, kt_n, 4, 32 * 6), axis=3, bitorder="little")          # [rp][kt][q][24]
+        for kt in range(kt_n):
+            f = frag[:, kt].transpose(1, 0, 2)                                                    # [q][rp][24]
+            X = f[:, :, :16]                                                                      # 16-byte slot q * rp + r
+            Y = np.zeros((2, rp, 2, 8), np.uint8)                                                 # 8-byte slot (q >> 1) * 2 rp + 2 r + (q & 1)
+            for q in range(4):
+                Y[q >> 1, :, q & 1] = f[q, :, 16:]
+            off = tb * blockbytes + kt * rp * 96
+            buf[off:off + 64 * rp] = X.ravel()
+            buf[off + 64 * rp:off + 96 * rp] = Y.ravel()
+    return buf
+
+
 def e4m3_of_ints(v):
     """e4m3 byte (OCP, +0 for zero) of integers |v| <= 16: what the reference's planes hold (mod.hpp:159-189)."""
     a = np.abs(v.astype(np.int32))

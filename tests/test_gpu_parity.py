@@ -443,6 +443,81 @@ def test_epilogue_reduction_on_extreme_accumulators(k):
         assert np.array_equal(got[t], r.T.astype(np.int8)), (k, p)
 
 
+@pytest.mark.parametrize("k", [512, 8192, 65024, 65536])
+def test_fp8_residue_gemms_on_extreme_accumulators(k, monkeypatch):
+    """FP8 backend, the three residue GEMMs of a modulus on accumulators AT the bound the planes allow: integer pieces of +-16 with long runs of equal
+    sign (|sum| reaches 256 k per product; k = 65536 -> 2^24, the last exactly representable value), fed straight to gemmul8_lowprec_gemm in every
+    form the driver has -- FP6 panel images through the fused three-segment tile loop (k <= 65024; csrc/oz2_gemm_f6.hip EPI_FUSED: loose fp32 residues
+    between the segments), FP6 through three launches (k = 65536, or GEMMUL8_FP8_FUSED=0), e4m3 byte planes (the round-4 kernel).  All three must agree
+    bit for bit and equal plain integer arithmetic: squares value = s (hi.lo + lo.hi) + lo.lo, Karatsuba moduli 240 hi.hi - 15 lo.lo + 16 (hi+lo).(hi+lo)
+    (src/mod.hpp:159-189 pieces, src/conv_hi2mid_real.hpp combine).  Random operands never come near these sums."""
+    import ctypes as C
+    import gemmul8_amd as g
+    import gpu_util as gu
+    from bigint_ref import MODULI_FP8
+    L = g.lib()
+    m, n, N = 80, 96, 8   # six square moduli + two Karatsuba moduli
+    rng = np.random.default_rng(k)
+    nplanes = 2 * 6 + 3 * 2
+
+    def step_planes(rows):  # one K-step (128 columns) of every plane; the full plane repeats it along k
+        x = rng.choice(np.array([-16, 16, 15, -15, 0, 1], dtype=np.int8), size=(nplanes, rows, 128), p=[0.3, 0.3, 0.15, 0.15, 0.05, 0.05])
+        x[:, 0, :] = 16
+        x[:, 1, :] = -16
+        x[:, 2, ::2] = 16
+        return x
+    A, B = step_planes(m), step_planes(n)
+    reps = k // 128
+    st = torch.cuda.current_stream().cuda_stream
+    got = {}
+    for form in ("fp6", "fp6_three_launches", "e4m3"):
+        gu.setknob(monkeypatch, "GEMMUL8_FP8_PLANES", "e4m3" if form == "e4m3" else "fp6")
+        gu.setknob(monkeypatch, "GEMMUL8_FP8_FUSED", "0" if form == "fp6_three_launches" else None)
+        tot, _, _ = g.work_size(False, g.FP8, m, n, k, N)
+        work = torch.zeros(tot, dtype=torch.uint8, device="cuda")
+        Lo = g.Layout()
+        g.check(L.gemmul8_get_layout(g.S, g.FP8, m, n, k, N, work.data_ptr(), None, None, 0, 0, C.byref(Lo)))
+        assert Lo.kp == k and Lo.lo_format == (0 if form == "e4m3" else 1) and Lo.num_mat == nplanes
+        base = work.data_ptr()
+        for X, ptr, size, rows_img in ((A, Lo.A_lo, Lo.sizeA, Lo.mp), (B, Lo.B_lo, Lo.sizeB, n)):
+            for q in range(nplanes):
+                if form == "e4m3":
+                    img = np.zeros((size // k, k), np.uint8)
+                    img[:X.shape[1]] = np.tile(gu.e4m3_of_ints(X[q]), (1, reps))
+                else:  # the panel of a K-step is the same in every K-step: encode one, repeat it inside each row block
+                    nb = (rows_img + 255) // 256
+                    one = gu.f6_plane_image(X[q], rows_img, 128, nb * 256 * 96)
+                    img = np.zeros(size, np.uint8)
+                    for tb in range(nb):
+                        rp = 256 if tb < nb - 1 else (min(256, rows_img - 256 * tb) + 15) // 16 * 16
+                        img[tb * 256 * (k // 4 * 3):][:reps * rp * 96] = np.tile(one[tb * 256 * 96:][:rp * 96], reps)
+                off = ptr - base + q * size
+                work[off:off + size] = torch.from_numpy(img.ravel()).cuda()
+        g.check(L.gemmul8_lowprec_gemm(st, g.S, g.FP8, m, n, k, N, 0, N, C.byref(Lo)))
+        torch.cuda.synchronize()
+        offC = Lo.C_mid - base
+        got[form] = work[offC:offC + 2 * N * Lo.sizeC].cpu().numpy().view(np.int16).reshape(N, Lo.sizeC // Lo.mp, Lo.mp)[:, :n, :m].copy()
+        del work
+    assert np.array_equal(got["fp6"], got["e4m3"]) and np.array_equal(got["fp6"], got["fp6_three_launches"])
+    A64, B64 = A.astype(np.int64), B.astype(np.int64)
+    reached = 0
+    for t in range(N):
+        pm = MODULI_FP8[t]
+        if t < 6:
+            q, s = 2 * t, int(round(pm ** 0.5))
+            c0, c1, c2 = A64[q] @ B64[q + 1].T, A64[q + 1] @ B64[q].T, A64[q + 1] @ B64[q + 1].T
+            val = s * (c0 + c1) + c2
+        else:
+            q = 12 + 3 * (t - 6)
+            c0, c1, c2 = A64[q] @ B64[q].T, A64[q + 1] @ B64[q + 1].T, A64[q + 2] @ B64[q + 2].T
+            val = 240 * c0 - 15 * c1 + 16 * c2
+        reached = max(reached, reps * int(max(np.abs(c0).max(), np.abs(c1).max(), np.abs(c2).max())))
+        r = got["fp6"][t].T.astype(np.int64)                 # C_mid is stored [n][mp]
+        assert not ((r - reps * val) % pm).any(), (k, pm)
+        assert np.abs(r).max() <= pm // 2, (k, pm)
+    assert reached == 256 * k                                # the bound is reached
+
+
 @pytest.mark.parametrize("kernel", ["dma", "reg"])
 @pytest.mark.parametrize("dtype,N", [(np.float64, 14), (np.float64, 20), (np.float32, 7), (np.complex128, 16)])
 def test_crt_on_extreme_residues(dtype, N, kernel, monkeypatch):

@@ -50,8 +50,10 @@ def test_known_crossovers():
     assert would("c", 2048, 2048, 256, 7) == 0
     # more moduli cost more: a shape that wins with 10 may lose with 18
     assert would("d", 8192, 8192, 512, 10, fast=1) >= would("d", 8192, 8192, 512, 18, fast=1)
-    # the FP8 backend costs ~2.2x: DGEMM never wins with it on this chip below very large k
+    # the FP8 backend costs 1.9x the INT8 one for DGEMM (round 5): 107 / 1.9 = 56 TFLOPS against 65-70 native at this shape
     assert would("d", 8192, 8192, 1024, 14, backend=g.FP8) == 0
+    assert would("d", 8192, 8192, 8192, 14, backend=g.FP8) == 1   # measured 91 (12 moduli) vs 70 native
+    assert would("s", 8192, 8192, 8192, 6, backend=g.FP8) == 1    # 183 vs 150
 
 
 def test_monotone_in_k_for_large_squares():
