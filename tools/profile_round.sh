@@ -15,8 +15,9 @@ import csv, glob
 f = glob.glob("$O/${TAG}_stats/**/*kernel_trace.csv", recursive=True)[0]
 t = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(f)) if "gemm_i8_kernel<0" in r["Kernel_Name"]]
 print("rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu")
-print("oz2::gemm_i8_kernel<0, ...> launches in order (ms):", ", ".join(f"{x:.3f}" for x in t))
-print("launches 1-3 = warm-up, 4-13 = the 10 timed steps: mean %.3f ms; the rest = the fast-mode calls of the other_mode line" % (sum(t[3:13]) / 10))
+print("oz2::gemm_i8_kernel<0, ...>: %d launches; the first 16 in order (ms):" % len(t), ", ".join(f"{x:.3f}" for x in t[:16]))
+print("launches 1-3 = warm-up, 4-13 = the 10 timed steps: mean %.3f ms; the rest = the settled-figure protocol (300 untimed + 30 event-timed calls: "
+      "mean of the last 30 of them %.3f ms) and the fast-mode calls of the other_mode line" % (sum(t[3:13]) / 10, sum(t[313:343]) / 30 if len(t) >= 343 else float("nan")))
 PY
 rocprofv3 -i $R/tools/pmc_mfma.txt --kernel-trace --output-format csv -d $O/${TAG}_pmc_mfma -o p -- python $R/tools/gemm_bench.py --iters 4 --warmup 1 > $O/${TAG}_pmc_mfma.log 2>&1
 python $R/tools/pmc_summary.py $O/${TAG}_pmc_mfma gemm_i8 > $O/${TAG}_pmc_mfma_summary.txt
