@@ -195,6 +195,9 @@ struct StageArgs {
 #define OZ2_STAGE_RTFAST 1  // row-strided kernels: the row-tile index is the fast grid dimension: the workgroups in flight read whole columns (one sequential
                            // window of the operand) and write 4 adjacent 128-byte runs per row and plane; 0 = k-tile index fastest (quantise A: 314 vs 283 us)
 #endif
+#ifndef OZ2_F6_FLOAT_CHAIN
+#define OZ2_F6_FLOAT_CHAIN 1  // FP6 panel images: residue, split, codes and packing in fp32 (put_f6_planes_f); 0 = the integer chain of the e4m3 writer
+#endif
 #ifndef OZ2_STAGE_FLOATRES
 #define OZ2_STAGE_FLOATRES 1  // 1: residues from a two-level FLOATING-POINT reduction (below); 0: the byte-wise integer path (v_dot4_u32_u8)
 #endif
@@ -263,6 +266,57 @@ __device__ __forceinline__ size_t f6_lane_offset(const StageArgs& a, size_t row,
     const size_t panel = (size_t)tb * 256u * (a.kp / 4 * 3) + (size_t)kt * rp * 96u;
     const unsigned inner = d < 4u ? (qf * rp + r) * 16u + 4u * d : 64u * rp + ((qf >> 1) * 2u * rp + 2u * r + (qf & 1u)) * 8u + 4u * (d - 4u);
     return panel + inner;
+}
+
+// The same planes from residues kept as FLOATS (round 5).  The FP6 writer is VALU-bound (config 3: 3.0 ms against ~1.3 ms of memory time) and the integer
+// form spends ~20 operations per value and modulus: residue (fma, mad, add), int -> float, split (mul, rint, fma), float -> int twice, two sign-magnitude
+// codes (sub, cmp, select each), shifts and ors.  Every quantity here is an integer below 2^24, so the whole chain runs in fp32 with the SAME quotients:
+//   residue  q = fma(R, RN(1/p), 1.5 * 2^23) - 1.5 * 2^23 (the very rounding of residue_from_small), r = fma(-q, p, R)              3
+//   split    squares: hi = rint(r / s), lo = fma(-s, hi, r) (fp8_split_sq);  Karatsuba: hi = copysign(ceil(|r| / 16), r), lo = fma(-16, hi, r)   3
+//   code     c = v < 0 ? 32 - v : v as a float (a negative zero stays a zero)                                                           3 per piece
+//   word     ((c3 * 64 + c2) * 64 + c1) * 64 + c0 by three fma (exact: < 2^24), ONE float -> int conversion per four codes               1 per piece
+// ~14 operations.  Bit-identical planes (the GPU parity tests and the fuzz sweep compare every code with the oracle's integers).
+__device__ __forceinline__ float residue_wide_f(float Rf, const ModConst& mc, float pf) {
+    const float q = fmaf(Rf, mc.invp, 12582912.0f) - 12582912.0f;
+    float r = fmaf(-q, pf, Rf);
+    if (!(mc.p & 1)) r = (r == -0.5f * pf) ? 0.5f * pf : r;  // (uniform) even p: a tie takes +p/2, as residue_from_small
+    return r;
+}
+__device__ __forceinline__ float wrapping_f(float a, float pf, float hf) { return a > hf ? a - pf : (a < -hf ? a + pf : a); }
+__device__ __forceinline__ void put_f6_word_f(int8_t* o, const float (&v)[4]) {
+    float c[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c[e] = v[e] < 0.0f ? 32.0f - v[e] : v[e];
+    const unsigned w = (unsigned)fmaf(fmaf(fmaf(c[3], 64.0f, c[2]), 64.0f, c[1]), 64.0f, c[0]);
+    const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xF9, 0xF, 0xF, true);  // quad_perm [1, 2, 3, 3]
+    const unsigned j = threadIdx.x & 3u;
+    const unsigned d = (w >> (8u * j)) | (nb << (24u - 8u * j));
+#ifdef OZ2_PROBE_F6_NOSTORE  // timing probe: everything but the store
+    asm volatile("" ::"v"(d), "v"(o));
+#else
+    if (j < 3u) *(unsigned*)o = d;
+#endif
+}
+__device__ __forceinline__ void put_f6_planes_f(const StageArgs& a, int8_t* o, int t, const float (&r)[4]) {
+    float hi[4], lo[4];
+    if (t < 6) {
+        const float sq = (float)a.sqrtp[t], inv = 1.0f / sq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hi[e] = rintf(r[e] * inv), lo[e] = fmaf(-sq, hi[e], r[e]);
+        put_f6_word_f(o, hi);
+        put_f6_word_f(o + a.plane_stride, lo);
+    } else {
+        float sm[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = copysignf(ceilf(fabsf(r[e]) * 0.0625f), r[e]);
+            lo[e] = fmaf(-16.0f, hi[e], r[e]);
+            sm[e] = hi[e] + lo[e];
+        }
+        put_f6_word_f(o, hi);
+        put_f6_word_f(o + a.plane_stride, lo);
+        put_f6_word_f(o + 2 * a.plane_stride, sm);
+    }
 }
 
 // Quantise + all residues of four consecutive k in the FLOATING-POINT domain.  The quantise kernels are bound by VALU issue, not by HBM
@@ -387,6 +441,24 @@ template <typename T> __device__ __forceinline__ void emit4_mod_float(const Stag
                 const int tt = t + u;
                 if (tt >= a.t_end) break;
                 const ModConst mc = a.mt.mc[tt];
+                if constexpr (WIDE && OZ2_F6_FLOAT_CHAIN) {
+                    if (a.f6) {  // (uniform) FP6 panel images from float residues: see put_f6_planes_f
+                        const float pf = (float)mc.p, hf = (float)(mc.p >> 1);
+                        float fr[4], fi[4], fs[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            fr[e] = residue_wide_f(Fr[e], mc, pf);
+                            if constexpr (E::cplx) fi[e] = residue_wide_f(Fi[e], mc, pf), fs[e] = wrapping_f(fr[e] + fi[e], pf, hf);
+                        }
+                        int8_t* o = out + (size_t)(tt < 6 ? 2 * tt : 12 + 3 * (tt - 6)) * a.plane_stride;
+                        put_f6_planes_f(a, o, tt, fr);
+                        if constexpr (E::cplx) {
+                            put_f6_planes_f(a, o + a.part_stride, tt, fi);
+                            put_f6_planes_f(a, o + 2 * a.part_stride, tt, fs);
+                        }
+                        continue;
+                    }
+                }
                 int rr[4], ri[4], rs[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -848,6 +920,196 @@ template <typename T> __global__ void __launch_bounds__(256) quantise_pair_kerne
 }
 static_assert(2 * sizeof(StageArgs) + 16 <= 4096, "two argument blocks must fit the 4 KiB kernel-argument segment");
 
+// ---- FP6 panel images of REAL operands: one lane = one fragment (round 5).  The generic stage kernels above give a lane four consecutive k; for the
+// FP6 images that form is bound by VALU issue (config 3: 2.4 ms for 7 GB, ~19 operations per value and modulus, half of them the sign-magnitude codes,
+// their 6-bit packing and the quad shuffle that assembles a dword).  Here a lane owns the 32 consecutive k of one row that make ONE fragment of the image
+// (oz2_gemm_f6.hip: 16 bytes in the X region + 8 in the Y region), and gfx950 converts and packs them in hardware: v_cvt_scalef32_2xpk16_fp6_f32 takes
+// two 16-float operands a, b and a scale and returns the 32 e2m3 codes of a[0]/scale, b[0]/scale, a[1]/scale, ... in six registers -- with scale 8 the code
+// of an integer |v| <= 16 is sign << 5 | |v| (tools/ubench/cvt_fp6.hip; a negative zero keeps its sign bit: the same value for the MFMA).  What is left per
+// value and modulus is the residue (3) and the split (3) in packed fp32 plus two FP64 operations per pair: the kernel runs at the HBM side.
+//   * workgroup = 64 rows x one 128-element K-step, wave q = fragment column q: a wave's 64 X slots are one contiguous KiB, its Y slots 512 bytes in 8-byte pieces;
+//   * row-strided operand (k strided by ld): lane = row, 32 coalesced loads; K-major operand: coalesced 16-byte loads of 8 rows x 128 bytes per instruction,
+//     transposed through a wave-private LDS tile (row pitch 144 bytes: conflict-free 16-byte reads), 128 bytes of every row at a time.
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef unsigned v6u __attribute__((ext_vector_type(6)));
+#ifndef OZ2_F6_LANE_KERNEL
+#define OZ2_F6_LANE_KERNEL 1  // 0: real FP6 planes through the generic stage kernels (four k per lane), as complex operands
+#endif
+template <typename T> __device__ __forceinline__ void stage_f6_body(const StageArgs& a, const unsigned bid, const bool kmajor, char* tile /* this wave's 64 x 144 bytes */) {
+    static_assert(!ET<T>::cplx, "real operands");
+    constexpr int EPL = 16 / (int)sizeof(T);   // elements per 16-byte piece
+    constexpr int CH = 128 / (int)sizeof(T);   // elements per 128-byte chunk of a row
+    const unsigned lane = threadIdx.x & 63u, q = threadIdx.x >> 6;
+    const unsigned nks = (unsigned)(a.kp / 128), nrb = (unsigned)((a.rows + 63) / 64);
+    unsigned rb, kt;
+    if (kmajor) rb = bid / nks, kt = bid - rb * nks;   // the workgroups in flight walk along the rows' memory
+    else kt = bid / nrb, rb = bid - kt * nrb;           // ... down the columns'
+    const size_t r0 = (size_t)rb * 64, row = r0 + lane, k0 = (size_t)kt * 128 + (size_t)q * 32;
+    const T* X = (const T*)((const char*)a.X + OZ2_ZX);
+    typedef unsigned V4 __attribute__((ext_vector_type(4)));
+    T v[32];
+    if (kmajor) {
+        const unsigned pc = lane & 7u, pr = lane >> 3;
+#pragma unroll
+        for (int c = 0; c < 32 / CH; ++c) {
+            V4 buf[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const size_t r = r0 + pr + 8 * j, kk = k0 + (size_t)c * CH + (size_t)pc * EPL;
+                const T* src = X + r * a.ld + kk;
+                V4 t = {0u, 0u, 0u, 0u};
+                if (r < a.rows) {
+                    if (kk + EPL <= a.k && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+                        t = OZ2_LOAD_NT ? __builtin_nontemporal_load((const V4*)src) : *(const V4*)src;
+                    } else {
+                        T e[EPL];
+#pragma unroll
+                        for (int u = 0; u < EPL; ++u) e[u] = kk + u < a.k ? src[u] : ET<T>::zero();
+                        __builtin_memcpy(&t, e, 16);
+                    }
+                }
+                buf[j] = t;
+            }
+            if (c > 0) __builtin_amdgcn_wave_barrier();  // (the tile is re-used: every lane has read its row of the previous chunk -- LDS operations of a wave execute in order)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *(V4*)(tile + (pr + 8 * j) * 144 + pc * 16) = buf[j];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const V4 t = *(const V4*)(tile + lane * 144 + i * 16);
+                __builtin_memcpy(&v[c * CH + i * EPL], &t, 16);
+            }
+        }
+    } else {
+        const T* src = X + row;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            const size_t kg = k0 + kk;
+            v[kk] = (row < a.rows && kg < a.k) ? (OZ2_LOAD_NT ? __builtin_nontemporal_load(src + kg * a.ld) : src[kg * a.ld]) : ET<T>::zero();
+        }
+    }
+    if (row >= a.rows) return;
+    const int s = -(int)((const int16_t*)((const char*)a.sft + OZ2_ZW))[row];
+    // xs = trunc(x 2^s): exact; a float operand's xs is a float again (24 significant bits), kept in 32 registers and widened pair by pair
+    using XS = typename std::conditional<sizeof(T) == 4, float, double>::type;
+    XS xs[32];
+    bool big = false;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        if constexpr (sizeof(T) == 4) xs[e] = truncf(ldexpf(v[e], s));
+        else xs[e] = trunc(ldexp((double)v[e], s));
+        big |= fabs((double)xs[e]) >= 0x1.0p53;
+    }
+    // this lane's fragment in plane 0: X slot (q Rp + r), Y slot ((q >> 1) 2 Rp + 2 r + (q & 1))
+    const unsigned tb = (unsigned)(row >> 8), r = (unsigned)row & 255u;
+    const unsigned rp = tb == a.f6_last ? a.f6_rp_last : 256u;
+    int8_t* const panel = a.lo + OZ2_ZW + (size_t)tb * 256u * (a.kp / 4 * 3) + (size_t)kt * rp * 96u;
+    int8_t* const ox = panel + (size_t)(q * rp + r) * 16u;
+    int8_t* const oy = panel + 64u * (size_t)rp + (size_t)((q >> 1) * 2u * rp + 2u * r + (q & 1u)) * 8u;
+    auto put = [&](int plane, const float (&w)[32]) {
+        v16f ev, od;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ev[i] = w[2 * i], od[i] = w[2 * i + 1];
+        const v6u c = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ev, od, 8.0f);
+        typedef unsigned V2 __attribute__((ext_vector_type(2)));
+        *(V4*)(ox + (size_t)plane * a.plane_stride) = V4{c[0], c[1], c[2], c[3]};
+        *(V2*)(oy + (size_t)plane * a.plane_stride) = V2{c[4], c[5]};
+    };
+    // (the loops over the 32 values are cut into groups of eight by scheduling barriers: left alone the scheduler interleaves all 32 chains and the
+    // kernel needs 263 registers -- one wave per SIMD)
+    auto run = [&]<bool BIG>() {
+        for (int t = a.t_begin; t < a.t_end; t += 2) {
+            const double P = a.pairP[(t - a.t_begin) >> 1], invP = a.pairInvP[(t - a.t_begin) >> 1];
+            float Rf[32];
+#pragma unroll
+            for (int g8 = 0; g8 < 4; ++g8) {
+#pragma unroll
+                for (int e = 8 * g8; e < 8 * g8 + 8; ++e) {
+                    const double x = (double)xs[e];
+                    double R = fma(-rint(x * invP), P, x);
+                    if constexpr (BIG) R = fma(-rint(R * invP), P, R);
+                    Rf[e] = (float)R;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll 1
+            for (int u = 0; u < 2; ++u) {
+                const int tt = t + u;
+                if (tt >= a.t_end) break;
+                const ModConst mc = a.mt.mc[tt];
+                const float pf = (float)mc.p;
+                const bool even = !(mc.p & 1);  // (uniform; p = 1024 only) a tie takes +p/2
+                const bool sqm = tt < 6;
+                float lo[32], hi[32];
+                // the residue of every value first (into lo): q = the quotient of residue_from_small, r = R - q p; for the one even modulus (p = 1024) a tie
+                // (-p/2) takes +p/2 -- in a real branch (written as a select the compiler ran it for every modulus: a third of the block)
+                if (even) {
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int e = 0; e < 32; ++e) {
+                        const float qq = fmaf(Rf[e], mc.invp, 12582912.0f) - 12582912.0f;
+                        const float rr = fmaf(-qq, pf, Rf[e]);
+                        lo[e] = rr == -0.5f * pf ? 0.5f * pf : rr;
+                    }
+                } else {
+#pragma unroll
+                    for (int g8 = 0; g8 < 4; ++g8) {
+#pragma unroll
+                        for (int e = 8 * g8; e < 8 * g8 + 8; ++e) {
+                            const float qq = fmaf(Rf[e], mc.invp, 12582912.0f) - 12582912.0f;
+                            lo[e] = fmaf(-qq, pf, Rf[e]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (sqm) {  // fp8_split_sq: hi = rint(r / s), lo = r - s hi
+                    const float sq = (float)a.sqrtp[tt], inv = 1.0f / sq;
+#pragma unroll
+                    for (int g8 = 0; g8 < 4; ++g8) {
+#pragma unroll
+                        for (int e = 8 * g8; e < 8 * g8 + 8; ++e) {
+                            hi[e] = rintf(lo[e] * inv);
+                            lo[e] = fmaf(-sq, hi[e], lo[e]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {    // fp8_split_kara: hi = sign(r) ceil(|r| / 16), lo = r - 16 hi
+#pragma unroll
+                    for (int g8 = 0; g8 < 4; ++g8) {
+#pragma unroll
+                        for (int e = 8 * g8; e < 8 * g8 + 8; ++e) {
+                            hi[e] = copysignf(ceilf(fabsf(lo[e]) * 0.0625f), lo[e]);
+                            lo[e] = fmaf(-16.0f, hi[e], lo[e]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                const int plane = sqm ? 2 * tt : 12 + 3 * (tt - 6);
+                put(plane, hi);
+                put(plane + 1, lo);
+                if (!sqm) {
+#pragma unroll
+                    for (int e = 0; e < 32; ++e) hi[e] += lo[e];
+                    put(plane + 2, hi);
+                }
+            }
+        }
+    };
+    if (__any(big)) run.template operator()<true>();
+    else run.template operator()<false>();
+}
+#ifdef OZ2_F6_WAVES  // experiment: force the register budget of that many waves per SIMD
+#define OZ2_F6_KATTR __attribute__((amdgpu_waves_per_eu(OZ2_F6_WAVES, OZ2_F6_WAVES)))
+#else
+#define OZ2_F6_KATTR
+#endif
+template <typename T> __global__ void __launch_bounds__(256) OZ2_F6_KATTR quantise_f6_pair_kernel(const StageArgs a, const StageArgs b, const unsigned nA, const int kmA, const int kmB) {
+    __shared__ __attribute__((aligned(16))) char tile[4][64 * 144];
+    char* const mine = tile[threadIdx.x >> 6];
+    if (blockIdx.x < nA) stage_f6_body<T>(a, blockIdx.x, kmA != 0, mine);
+    else stage_f6_body<T>(b, blockIdx.x - nA, kmB != 0, mine);
+}
+
 // per-row amax of a row-strided operand: grid (ceil(rows/64), ksplit), 256 threads = 64 rows x 4 k-lanes
 template <typename T> __global__ void __launch_bounds__(256) amax_strided_kernel(const T* X, size_t ld, size_t rows, size_t k, void* amax, size_t bx, size_t bw) {
     X = (const T*)((const char*)X + blockIdx.z * bx);  // batched launch: item blockIdx.z
@@ -943,6 +1205,15 @@ static hipError_t dispatch_extract_stage(hipStream_t stream, int dtype, bool kma
     return hipErrorInvalidValue;
 }
 template <typename T> static hipError_t launch_quantise_stage(hipStream_t stream, bool kmA, const StageArgs& a, bool kmB, const StageArgs& b) {
+    if constexpr (OZ2_F6_LANE_KERNEL && !ET<T>::cplx) {
+        // real operands, FP6 panel images on both sides (an operand that is skipped has no rows): one lane per fragment
+        if ((a.rows == 0 || a.f6) && (b.rows == 0 || b.f6) && (a.rows != 0 || b.rows != 0) && (a.rows ? a.backend : b.backend) == kFP8) {
+            const size_t nA = a.rows ? ((a.rows + 63) / 64) * (a.kp / 128) : 0, nB = b.rows ? ((b.rows + 63) / 64) * (b.kp / 128) : 0;
+            if (nA + nB > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
+            hipLaunchKernelGGL(quantise_f6_pair_kernel<T>, dim3((unsigned)(nA + nB), 1, g_batch.batch), dim3(256), 0, stream, a, b, (unsigned)nA, (int)kmA, (int)kmB);
+            return hipGetLastError();
+        }
+    }
     const size_t nA = stage_blocks<T, MODE_MOD>(kmA, a), nB = stage_blocks<T, MODE_MOD>(kmB, b);
     if (nA + nB == 0) return hipSuccess;
     if (nA + nB > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;

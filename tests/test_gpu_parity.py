@@ -830,6 +830,27 @@ def test_fp8_backend_fp6_images_and_e4m3_planes_agree(dtype, N, fast, monkeypatc
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype,N", [(np.float32, 8), (np.float64, 12), (np.float64, 18)])
+@pytest.mark.parametrize("opA,opB", [("N", "N"), ("T", "N"), ("N", "T"), ("T", "T")])
+def test_fp6_lane_per_fragment_writer_on_ragged_shapes(dtype, N, opA, opB):
+    """Real operands of the FP8 backend are quantised by the lane-per-fragment kernel (csrc/oz2_scale.hip quantise_f6_pair_kernel: a lane owns the 32
+    consecutive k of one row, the hardware packs the 32 e2m3 codes; row-strided operands by 32 coalesced loads, K-major ones through a wave-private
+    LDS transpose).  Shapes that leave every loop ragged -- rows not a multiple of 64 (nor of 16), k not a multiple of 32 / 128 / the 16-byte load,
+    odd leading dimensions (element-wise tail loads), Karatsuba moduli (N > 6), 18 moduli (scaled values beyond 2^53: the second reduction step) --
+    in all four operand orientations, bit-exact against the oracle (planes, C_mid, C)."""
+    import gemmul8_amd as g
+    import gpu_util as gu
+    rng = np.random.default_rng(2026)
+    for (m, n, k) in ((65, 64, 33), (130, 257, 127), (64, 70, 2049), (300, 96, 515)):
+        A = rand((m, k) if opA == "N" else (k, m), dtype, rng, phi=1.0)
+        B = rand((k, n) if opB == "N" else (n, k), dtype, rng, phi=1.0)
+        _, it = gu.hip_gemm(A, B, N, fastmode=True, backend=g.FP8, opA=opA, opB=opB, want_intermediates=True)
+        assert it["lo_format"] == 1
+        gu.parity_case(A, B, N, True, backend=g.FP8, opA=opA, opB=opB)
+    gu.parity_case(A, B, N, False, backend=g.FP8, opA=opA, opB=opB)
+
+
+@pytest.mark.gpu
 def test_fp8_skip_scaling_cached_planes_meet_a_partner_of_another_width():
     """FP8 backend, round 5: whether the residue planes are FP6 panel images depends on n (B's last row block must fit its plane).  With skip-scaling
     enabled an operand's planes outlive the call and may meet a partner of another width -- the reference's use of the flag: one A against changing B

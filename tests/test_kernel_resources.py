@@ -197,3 +197,22 @@ def test_fp6_inline_asm_reads_are_never_spilled_or_copied_in_flight():
             used.update(int(x) for x in re.findall(r"\bv(\d+)\b", srcs))
             assert not (used & inflight), (lines[st][:60], t)
         assert nreads >= 32, (lines[st][:60], nreads)
+
+
+def test_fp6_quantise_lane_kernel_uses_the_hardware_pack_and_two_waves():
+    """quantise_f6_pair_kernel (csrc/oz2_scale.hip, round 5): a lane converts its 32 values with v_cvt_scalef32_2xpk16_fp6_f32 -- no sign-magnitude codes
+    built by hand, no fragment operand copied into place (the 16-float operands must be allocated where the values are produced) --, the even-modulus tie
+    fix is a branch and not 32 selects per modulus, nothing spills, and the register budget leaves two waves per SIMD."""
+    ks = _kernels(_asm("oz2_scale.hip"))
+    names = [n for n in ks if "quantise_f6_pair_kernel" in n]
+    assert len(names) == 2, names  # float, double
+    for n in names:
+        vg, sc, blocks = ks[n]
+        assert sc == 0, (n, sc)
+        assert vg <= 256, (n, vg)
+        cvt = [b for b in blocks if any("v_cvt_scalef32_2xpk16_fp6_f32" in l for l in b)]
+        assert cvt, n
+        for b in cvt:
+            assert sum(l.startswith("v_mov_b32") for l in b) <= 8, (n, "fragment operands are copied into place")
+        hot = [b for b in blocks if sum(l.startswith("v_pk_fma_f32") or l.startswith("v_fma_f32") for l in b) >= 32 and not any("v_cmp_eq_f32" in l for l in b)]
+        assert hot, (n, "no residue block without the tie compare: the even-modulus fix runs for every modulus")
