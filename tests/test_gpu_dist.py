@@ -24,7 +24,7 @@ def _port():
     return p
 
 
-def _worker(rank, world, port, plan, grid_rows, N, fast, m, n, k, typ, q):
+def _worker(rank, world, port, plan, grid_rows, N, fast, m, n, k, typ, q, be=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -44,13 +44,13 @@ def _worker(rank, world, port, plan, grid_rows, N, fast, m, n, k, typ, q):
         A, B = rnd((k, m)), rnd((n, k))      # (cols, rows) = column-major m x k, k x n
         Cm = torch.zeros((n, m), dtype=tdt, device="cuda")
         comm = gd.TorchTransport(device=True)
-        pl = gd.DistGemm(comm, plan, g._dtype_code(tdt), g.INT8, m, n, k, N, fastmode=fast, grid_rows=grid_rows)
+        pl = gd.DistGemm(comm, plan, g._dtype_code(tdt), be, m, n, k, N, fastmode=fast, grid_rows=grid_rows)
         pl.run(A, B, Cm)
         torch.cuda.synchronize()
         pl.gather_result(Cm)
         torch.cuda.synchronize()
         if rank == 0:
-            ref, _, _ = g.gemm(A, B, N, fastmode=fast)
+            ref, _, _ = g.gemm(A, B, N, fastmode=fast, backend=be)
             torch.cuda.synchronize()
             a = torch.view_as_real(Cm) if tdt.is_complex else Cm
             b = torch.view_as_real(ref) if tdt.is_complex else ref
@@ -84,12 +84,12 @@ def _start_and_reap(procs, timeout):
     return codes
 
 
-def _run(plan, grid_rows, N, fast, m, n, k, typ="d"):
+def _run(plan, grid_rows, N, fast, m, n, k, typ="d", be=0):
     ctx = mp.get_context("spawn")
     for attempt in range(2):   # the free port is chosen before the ranks bind it: one retry for the rare rendezvous collision
         q = ctx.Queue()
         port = _port()
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, plan, grid_rows, N, fast, m, n, k, typ, q)) for r in range(2)]
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, plan, grid_rows, N, fast, m, n, k, typ, q, be)) for r in range(2)]
         codes = _start_and_reap(procs, 300)
         if codes == [0] * len(procs):
             return q.get(timeout=10)
@@ -107,6 +107,15 @@ def test_two_ranks_one_gpu_bitwise(plan, grid_rows, N, fast):
 def test_two_ranks_one_gpu_bitwise_other_types(typ, N):
     for plan in ("blocks", "moduli"):
         nbad, total, _ = _run(plan, 0, N, False, 260, 130, 520, typ=typ)
+        assert nbad == 0, (plan, typ, nbad, total)
+
+
+@pytest.mark.parametrize("typ,N,fast", [("s", 8, False), ("d", 13, True), ("z", 9, False)])
+def test_two_ranks_one_gpu_bitwise_fp8_backend(typ, N, fast):
+    """The FP8 backend through the plans (round 5: FP6 panel images, the fused three-product tile loop with t_begin > 0 and in plane groups, the
+    lane-per-fragment writer on a moduli range that starts at an odd modulus, int16 residue exchange): bit-identical to the single-GPU call."""
+    for plan in ("blocks", "moduli"):
+        nbad, total, _ = _run(plan, 0, N, fast, 260, 140, 520, typ=typ, be=1)
         assert nbad == 0, (plan, typ, nbad, total)
 
 
