@@ -933,7 +933,9 @@ static_assert(2 * sizeof(StageArgs) + 16 <= 4096, "two argument blocks must fit 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef unsigned v6u __attribute__((ext_vector_type(6)));
 #ifndef OZ2_F6_LANE_KERNEL
-#define OZ2_F6_LANE_KERNEL 1  // 0: real FP6 planes through the generic stage kernels (four k per lane), as complex operands
+#define OZ2_F6_LANE_KERNEL 1  // 0: real FP6 planes through the generic stage kernels (four k per lane), as complex operands.  (A complex form was built in
+                              // round 5 -- the fragment in two halves of 16 k, three plane sets per value -- and needs 282-314 registers: the 16-float operand
+                              // tuples of the pack instruction with half their lanes as padding fragment the register file; one wave per SIMD: not kept.)
 #endif
 template <typename T> __device__ __forceinline__ void stage_f6_body(const StageArgs& a, const unsigned bid, const bool kmajor, char* tile /* this wave's 64 x 144 bytes */) {
     static_assert(!ET<T>::cplx, "real operands");
