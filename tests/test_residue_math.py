@@ -477,3 +477,66 @@ def test_fp8_fused_three_segment_tile_loop(p):
     y = (v.astype(np.float64) * np.float64(invp) - 0.5).astype(np.float32)
     got = v - np.ceil(y.astype(np.float64)).astype(np.int64) * p
     assert np.array_equal(got, _sym_half_open(value, p))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# FP6 plane writers (oz2_scale.hip, round 5): the residue, the split and the e2m3 codes in fp32 (put_f6_planes_f, quantise_f6_pair_kernel) against the
+# integer chain of the e4m3 writer (residue_from_small + fp8_split_sq / fp8_split_kara + f6_code), exhaustively over every level-1 remainder.
+FP8_SQRT = [33, 32, 31, 29, 25, 23]
+
+
+@pytest.mark.parametrize("t", range(20))
+def test_fp6_writer_float_chain_equals_integer_chain(t):
+    p = FP8_MODULI[t]
+    R = np.arange(-(1 << 20), (1 << 20) + 1, dtype=np.int64)
+    Rf = R.astype(np.float32)
+    invp = np.float32(1.0) / np.float32(p)
+    magic = np.float32(12582912.0)
+    # integer chain: q from the low 24 bits of fma(R, 1/p, 1.5 * 2^23), r = R - q p, the even-modulus tie to +p/2
+    qf = (Rf.astype(np.float64) * np.float64(invp) + np.float64(magic)).astype(np.float32)
+    q_int = (qf.view(np.uint32).astype(np.int64) & 0xFFFFFF) - (1 << 22)
+    r_int = R - q_int * p
+    if p % 2 == 0:
+        r_int = np.where(r_int == -(p // 2), p // 2, r_int)
+    # float chain: q = fma(..) - magic (exact: both are integers below 2^24), r = fma(-q, p, R) (exact), the same tie rule
+    q_f = qf - magic
+    r_f = (-q_f.astype(np.float64) * np.float64(p) + Rf.astype(np.float64)).astype(np.float32)
+    if p % 2 == 0:
+        r_f = np.where(r_f == np.float32(-0.5 * p), np.float32(0.5 * p), r_f)
+    assert np.array_equal(r_f.astype(np.int64), r_int) and np.all(np.abs(r_int) <= p // 2)
+    # split: squares hi = rint(r / s) (float multiply by RN(1/s), as fp8_split_sq), lo = r - s hi; Karatsuba: hi = sign(r) ceil(|r| / 16), lo = r - 16 hi
+    if t < 6:
+        s = FP8_SQRT[t]
+        inv = np.float32(1.0) / np.float32(s)
+        hi_f = np.rint(r_f * inv)
+        lo_f = (r_f.astype(np.float64) - np.float64(s) * hi_f.astype(np.float64)).astype(np.float32)
+        a = r_int.astype(np.float32)
+        hi_i = np.rint(a * inv).astype(np.int64)
+        lo_i = r_int - s * hi_i
+        pieces_f, pieces_i = [hi_f, lo_f], [hi_i, lo_i]
+    else:
+        hi_f = np.copysign(np.ceil(np.abs(r_f) * np.float32(0.0625)), r_f)
+        lo_f = (r_f.astype(np.float64) - 16.0 * hi_f.astype(np.float64)).astype(np.float32)
+        qa = (np.abs(r_int) + 15) >> 4
+        hi_i = np.where(r_int < 0, -qa, qa)
+        lo_i = r_int - 16 * hi_i
+        pieces_f, pieces_i = [hi_f, lo_f, hi_f + lo_f], [hi_i, lo_i, hi_i + lo_i]
+    for pf_, pi_ in zip(pieces_f, pieces_i):
+        assert np.array_equal(pf_.astype(np.int64), pi_), t
+        assert np.abs(pi_).max() <= 16, (t, np.abs(pi_).max())     # every piece is an exact e2m3 code: sign << 5 | |v| (value v / 8)
+        # the code the four-k writer builds in fp32: v < 0 ? 32 - v : v;  the hardware pack of the lane-per-fragment writer returns sign << 5 | |v| (tools/ubench/cvt_fp6.hip)
+        code_f = np.where(pf_ < 0, np.float32(32.0) - pf_, pf_).astype(np.int64)
+        code_i = np.where(pi_ < 0, 32 - pi_, pi_)
+        assert np.array_equal(code_f, code_i) and code_i.max() <= 48
+
+
+def test_fp6_panel_image_codec_round_trip():
+    """tests/gpu_util.py f6_plane_image / f6_plane_values (the test-side encoder / decoder of the FP6 panel images, csrc/oz2_gemm_f6.hip layout): inverse of
+    each other on ragged row counts, several K-steps and a last row block that is not a multiple of 16 rows."""
+    import gpu_util as gu
+    rng = np.random.default_rng(7)
+    for rows, rows_img, kp in ((300, 512, 256), (333, 333, 384), (70, 80, 128), (16, 16, 128)):
+        v = rng.integers(-16, 17, size=(rows, kp)).astype(np.int8)
+        nb = (rows_img + 255) // 256
+        img = gu.f6_plane_image(v, rows_img, kp, nb * 256 * (kp // 4 * 3))
+        assert np.array_equal(gu.f6_plane_values(img, rows, rows_img, kp), v)
