@@ -841,7 +841,8 @@ def test_fp6_lane_per_fragment_writer_on_ragged_shapes(dtype, N, opA, opB):
     import gemmul8_amd as g
     import gpu_util as gu
     rng = np.random.default_rng(2026)
-    for (m, n, k) in ((65, 64, 33), (130, 257, 127), (64, 70, 2049), (300, 96, 515)):
+    shapes = ((65, 64, 33), (130, 257, 127)) if N > 12 else ((65, 64, 33), (130, 257, 127), (64, 70, 2049), (300, 96, 515))  # (the oracle's cost grows with N)
+    for (m, n, k) in shapes:
         A = rand((m, k) if opA == "N" else (k, m), dtype, rng, phi=1.0)
         B = rand((k, n) if opB == "N" else (n, k), dtype, rng, phi=1.0)
         _, it = gu.hip_gemm(A, B, N, fastmode=True, backend=g.FP8, opA=opA, opB=opB, want_intermediates=True)

@@ -36,7 +36,7 @@ ref = g.lib()
 dt = g.S if a.dtype == "S" else g.D
 tdt = torch.float32 if a.dtype == "S" else torch.float64
 tmp = tempfile.mkdtemp()
-libs, fmts, nofuse = [], [], []
+libs, fmts, nofuse, colblk = [], [], [], []
 for i, spec in enumerate(a.libs):
     pth, _, fmt = spec.partition(":")
     cp = os.path.join(tmp, f"v{i}.so")
@@ -49,6 +49,7 @@ for i, spec in enumerate(a.libs):
     libs.append(L)
     fmts.append("e4m3" if fmt == "e4m3" else "fp6")
     nofuse.append(fmt == "nofuse")
+    colblk.append(fmt[2:] if fmt.startswith("cb") else None)   # ':cb<w>' = GEMMUL8_MAP_COLBLOCK=<w> (tile-columns per column block; 0 = full width)
 st = torch.cuda.current_stream().cuda_stream
 for k in [int(x) for x in a.k.split(",")]:
     torch.manual_seed(k)
@@ -66,10 +67,13 @@ for k in [int(x) for x in a.k.split(",")]:
         g.check(L0.gemmul8_scale(st, dt, g.FP8, 0, 0, n, n, k, A.data_ptr(), n, B.data_ptr(), k, N, 1, 0, N, C.byref(Lo), 0, 0))
         torch.cuda.synchronize()
         works[fmt], Ls[fmt] = w, Lo
-    for L, fmt, nf in zip(libs, fmts, nofuse):  # every build reads the knobs once: its own format; ':nofuse' = FP6 planes, three-launch form
+    for L, fmt, nf, cb in zip(libs, fmts, nofuse, colblk):  # every build reads the knobs once: its own format; ':nofuse' = FP6 planes, three-launch form
         os.environ["GEMMUL8_FP8_PLANES"] = fmt
         os.environ["GEMMUL8_FP8_FUSED"] = "0" if nf else "1"
+        if cb is not None:
+            os.environ["GEMMUL8_MAP_COLBLOCK"] = cb
         L.gemmul8_reload_knobs()
+        os.environ.pop("GEMMUL8_MAP_COLBLOCK", None)
     os.environ.pop("GEMMUL8_FP8_FUSED", None)
     ts = [[] for _ in libs]
     for r in range(a.rounds + 2):
