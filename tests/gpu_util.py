@@ -264,7 +264,8 @@ def parity_case(A, B, N, fastmode, opA="N", opB="N", alpha=1.0, beta=0.0, C0=Non
     # oracle fed with the device's shifts -> everything downstream is bit-exact
     Co, ito = ol.gemm(A, B, N, fastmode=fastmode, backend=backend, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0,
                       sftA_in=it["sftA"], sftB_in=it["sftB"], want_intermediates=True)
-    if it["lo_format"] == 1:  # FP6 codes carry no sign on a zero: the oracle's -0 (rint of a small negative quotient) compares as +0
+    if it["lo_format"] == 1:  # the FP6 images are compared as INTEGERS (f6_plane_values: a zero decodes to 0 whichever sign bit its code carries -- the four-k writer emits +0, the
+        # hardware pack of the lane-per-fragment writer keeps the sign of a -0): the oracle's -0 byte (rint of a small negative quotient) compares as +0
         for key in ("A_lo", "B_lo"):
             ito[key] = np.where(ito[key] == 0x80, 0, ito[key]).astype(np.uint8)
     assert np.array_equal(it["A_lo"], ito["A_lo"]), "A_lo planes differ"
