@@ -36,6 +36,9 @@
 
 #include "oz2_gemm_f8_epi.hpp"
 
+#ifndef OZ2_F8_KBAR
+#define OZ2_F8_KBAR 1  // 1 (round 5): one workgroup barrier per K-step with the two wave halves in anti-phase -- residue GEMMs neutral (+-0.6 %), the accurate mode's single-plane bound GEMM +6 % (scaling phase of config 3 5.41 -> 5.23 ms), bit-identical: profiles/r05z_f8_kbar_ab.txt; 0: a barrier after every LOAD / MFMA segment (rounds 2-4)
+#endif
 namespace oz2 {
 
 // Persistent: one workgroup per CU loops over tiles vb = blockIdx.x, blockIdx.x + gridDim.x, ...; the two-stage K pipeline
@@ -157,7 +160,7 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        if (wm == 1) __builtin_amdgcn_s_barrier();
+        if (!OZ2_F8_KBAR && wm == 1) __builtin_amdgcn_s_barrier();
         // Hazards: a panel's slot was last read two (A) / one (B) K-steps before the refill is issued, and every wave finishes a
         // K-step's LOAD segments (lgkmcnt(0) + barrier) before the leading half enters slot 0 of the next one; each wave drains the
         // DMA the NEXT K-step needs in its last LOAD segment (A waves: everything but the 8 instructions just issued), one barrier
@@ -202,6 +205,20 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
                     // As in oz2_gemm_i8.hip: only the K-step's LAST load segment completes its LDS reads (and, on the A waves, the DMA the next K-step
                     // needs) before the barrier -- the one the ring's hazards count on; the first segment arrives at the barrier with its reads issued
                     // and waits behind it (config 3 whole call +1.25 %, SGEMM 8192^2 x 2048 / 8192 +1.2 / +0.7 %: profiles/archive/r04e_f8_late_wait_ab.txt)
+#if OZ2_F8_KBAR
+                    // K-step-barrier schedule (as oz2_gemm_i8.hip below k = 5120): ONE workgroup barrier per K-step.  The A-fetching half (wm = 0) runs
+                    // L0 M0 L1 M1 | barrier, the B-fetching half (wm = 1) L0 M0 L1 | barrier | M1 -- its last fragments cross the barrier in registers --
+                    // so on every SIMD one wave's LDS reads sit beside the other's MFMAs without a barrier per segment.  RAW: every wave's pieces of
+                    // the panels of K-step g + 1 have landed (vmcnt) before it arrives; WAR: every read of K-step g is complete (lgkmcnt(0) / consumed
+                    // by issued MFMAs) before it arrives, the refills of those slots are issued behind the barrier.
+                    if (ISB && ah == 1) {
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_barrier();
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+#else
                     if (ah == 1) {
                         if (!ISB) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
                         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -212,6 +229,7 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
                     if (ah == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_setprio(1);
+#endif
                     // serpentine order over the 4 x 4 fragment pairs, as in oz2_gemm_i8.hip (consecutive MFMAs share an operand register across the row change)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
@@ -223,9 +241,17 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
                         }
                     __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
+#if OZ2_F8_KBAR
+                    if (!ISB && ah == 1) {
+                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#else
                     if (ah == 1 && ISB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
             }
             const TileMap tmap = map_tile(vb, total, args.map);
@@ -241,7 +267,7 @@ __global__ void __launch_bounds__(F8_THREADS) gemm_f8_kernel(const F8Args args) 
     if (isB) run.template operator()<true>();
     else run.template operator()<false>();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the workgroup
-    if (wm == 0) __builtin_amdgcn_s_barrier();
+    if (!OZ2_F8_KBAR && wm == 0) __builtin_amdgcn_s_barrier();
 #undef F8_SET_TILE
 #undef F8_DMA
 #undef F8_FETCH_BEGIN
