@@ -528,7 +528,7 @@ bool try_emulate_impl(int dtype, hipblasHandle_t handle, hipblasOperation_t ta, 
     if (backend == GEMMUL8_FP8) {
         // the FP8 backend exists for parity with the reference; on this chip the INT8 backend dominates it: three GEMMs per modulus (on FP6 codes
         // of the backend's integer pieces, 1.5x the INT8 kernel's rate since round 5) against one INT8 GEMM (profiles/sweeps/r05_types_backends.csv:
-        // SGEMM 8192^3 183 vs 296 TFLOPS, native 150; DGEMM 91 vs 159, native 70).  Say so once.
+        // SGEMM 8192^3 193 vs 302 TFLOPS, native 153; DGEMM 101 vs 160, native 71).  Say so once.
         static std::once_flag told;
         std::call_once(told, [] {
             std::fprintf(stderr, "[GEMMUL8 HOOK] GEMMUL8_BACKEND=FP8: on MI355X the INT8 backend (GEMMUL8_BACKEND=0) is 1.6-2x faster at equal or better "

@@ -52,8 +52,8 @@ def test_known_crossovers():
     assert would("d", 8192, 8192, 512, 10, fast=1) >= would("d", 8192, 8192, 512, 18, fast=1)
     # the FP8 backend costs 1.9x the INT8 one for DGEMM (round 5): 107 / 1.9 = 56 TFLOPS against 65-70 native at this shape
     assert would("d", 8192, 8192, 1024, 14, backend=g.FP8) == 0
-    assert would("d", 8192, 8192, 8192, 14, backend=g.FP8) == 1   # measured 91 (12 moduli) vs 70 native
-    assert would("s", 8192, 8192, 8192, 6, backend=g.FP8) == 1    # 183 vs 150
+    assert would("d", 8192, 8192, 8192, 14, backend=g.FP8) == 1   # measured 101 (12 moduli) vs 71 native
+    assert would("s", 8192, 8192, 8192, 6, backend=g.FP8) == 1    # 193 vs 153
 
 
 def test_monotone_in_k_for_large_squares():
