@@ -94,6 +94,9 @@ constexpr int F8_THREADS = 512;
 #ifndef OZ2_HOOK_SKIP_EPILOGUE
 #define OZ2_HOOK_SKIP_EPILOGUE 0
 #endif
+#if defined(OZ2_PRODUCT_BUILD) && (OZ2_HOOK_SKIP_AH || OZ2_HOOK_SKIP_EPILOGUE)
+#error "timing probes (OZ2_HOOK_SKIP_*) compute something else: not allowed in the product build of libgemmul8.so"
+#endif
 
 // int16 residue epilogues (EPI_PART / EPI_FINAL / EPI_FINAL_CPLX) of a wave's 128 x 64 accumulator block.  The accumulators are exact integers
 // (|c| <= 2^24): a loose three-instruction fp32 residue (red_acc below); the combined value (|v| < 2^18) needs one fp32 step for the canonical one.

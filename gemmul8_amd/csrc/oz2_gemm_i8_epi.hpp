@@ -30,6 +30,9 @@ namespace oz2 {
 #ifndef OZ2_HOOK_SKIP_EPILOGUE
 #define OZ2_HOOK_SKIP_EPILOGUE 0          // consumers: 1 = keep the accumulators live, no epilogue
 #endif
+#if defined(OZ2_PRODUCT_BUILD) && OZ2_HOOK_SKIP_EPILOGUE
+#error "timing probes (OZ2_HOOK_SKIP_*) compute something else: not allowed in the product build of libgemmul8.so"
+#endif
 
 enum { EPI_MOD = 0, EPI_MAX = 1, EPI_CPLX = 2 };
 

@@ -195,6 +195,9 @@ struct StageArgs {
 #define OZ2_STAGE_RTFAST 1  // row-strided kernels: the row-tile index is the fast grid dimension: the workgroups in flight read whole columns (one sequential
                            // window of the operand) and write 4 adjacent 128-byte runs per row and plane; 0 = k-tile index fastest (quantise A: 314 vs 283 us)
 #endif
+#if defined(OZ2_PRODUCT_BUILD) && defined(OZ2_PROBE_F6_NOSTORE)
+#error "OZ2_PROBE_F6_NOSTORE is a timing probe (the planes are never written): not allowed in the product build of libgemmul8.so"
+#endif
 #ifndef OZ2_F6_FLOAT_CHAIN
 #define OZ2_F6_FLOAT_CHAIN 1  // FP6 panel images: residue, split, codes and packing in fp32 (put_f6_planes_f); 0 = the integer chain of the e4m3 writer
 #endif
