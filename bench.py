@@ -216,6 +216,35 @@ def run_other_config(args):
                          "max_rel_err": float(np.max(np.abs(got2 - ref) / np.abs(ref)))})
             del work2
         out["more_moduli"] = more
+    if be == g.FP8 and not mode:
+        # how far is the default (engine-safe) FP8 accurate-mode bound from the reference's formula (k+1)*2^-24
+        # (src/find_max.hpp:82-96) on THESE inputs?  Same call in both modes: rows / columns whose shift differs, elements of C that differ.
+        import ctypes as C_
+        L = g.Layout()
+        g.check(g.lib().gemmul8_get_layout(g._dtype_code(dt), be, n, n, n, N, work.data_ptr(), None, None, 0, 0, C_.byref(L)))
+        base = work.data_ptr()
+        def shifts():
+            w16 = work.view(torch.int16)
+            a0, b0 = (L.sftA - base) // 2, (L.sftB - base) // 2
+            return w16[a0:a0 + n].clone(), w16[b0:b0 + n].clone()
+        prev = g.lib().gemmul8_set_fp8_bound_mode(0)
+        g.gemm(A, B, N, fastmode=False, backend=be, C_out=Cm, work=work)
+        torch.cuda.synchronize()
+        sA0, sB0 = shifts()
+        C0 = Cm.clone()
+        g.lib().gemmul8_set_fp8_bound_mode(1)
+        g.gemm(A, B, N, fastmode=False, backend=be, C_out=Cm, work=work)
+        torch.cuda.synchronize()
+        sA1, sB1 = shifts()
+        g.lib().gemmul8_set_fp8_bound_mode(prev)
+        dA_, dB_ = (sA0 != sA1), (sB0 != sB1)
+        out["fp8_bound_mode"] = {"default": "engine-safe inflation 7*2^-13 + 4(k+1)*2^-24 + 7 kp 2^-14 (mode 0)" if prev == 0 else f"mode {prev}",
+                                 "reference_formula": "(k+1)*2^-24 (src/find_max.hpp:82-96; mode 1, GEMMUL8_FP8_BOUND=reference)",
+                                 "rows_with_a_different_shift": int(dA_.sum()), "cols_with_a_different_shift": int(dB_.sum()), "of": n,
+                                 "max_abs_shift_diff": int(max((sA0 - sA1).abs().max().item(), (sB0 - sB1).abs().max().item())),
+                                 "elements_of_C_that_differ": int((C0 != Cm).sum().item()), "elements": n * n,
+                                 "max_rel_diff_of_C_between_modes": float(((C0 - Cm).abs() / C0.abs().clamp_min(1e-30)).max().item())}
+        del C0
     print(json.dumps(out))
 
 
@@ -471,6 +500,9 @@ def run_plans(args, n, N, A, B, dev, stream, backend, rank, world):
         rec = {"value": 2.0 * n ** 3 / (ms * 1e-3) * 1e-12, "unit": "TFLOPS", "ms_per_step": ms, "parallelism": plan.describe(),
                "gemm_launch_ms_rank0": gemm_ms, "gemm_ops_rank0": ops, "gemm_achieved_TOPs_rank0": ach, "gemm_frac_of_int8_peak_rank0": ach / peak if ach else None,
                "bounds_allreduce_ms_rank0": ev_ms(ar_ev) if has_ar else 0.0, "exchange_ms_rank0": ev_ms(xc_ev) if has_xc else 0.0,
+               # the moduli plan's exchange runs beside the later groups' GEMMs: exchange_ms spans GEMM time; what the step actually waits for is the
+               # part behind the last GEMM (include/gemmul8_dist.h, gemmul8_dist_set_exchange_events)
+               "exchange_exposed_ms_rank0": max(0.0, ev_ms([(g_[1], x_[1]) for g_, x_ in zip(gemm_ev, xc_ev)])) if has_xc else 0.0,
                "allreduce_bytes": ar_bytes, "bytes_sent_rank0": sent, "bytes_received_rank0": recvd,
                "workspace_bytes_rank0": plan.workspace_bytes()}
         full = plan.gather_result(Cmat)

@@ -35,7 +35,9 @@ _lib = None
 
 EXPORTS = ["gemmul8_version", "gemmul8_work_size", "gemmul8_gemm", "gemmul8_get_layout", "gemmul8_scale",
            "gemmul8_scale_bounds", "gemmul8_scale_finish", "gemmul8_lowprec_gemm", "gemmul8_crt", "gemmul8_set_fp8_bound_mode",
-           "gemmul8_hook_would_emulate", "gemmul8_reload_knobs"]
+           "gemmul8_hook_would_emulate", "gemmul8_reload_knobs", "gemmul8_abi_version", "gemmul8_layout_bytes"]
+
+ABI_VERSION = 6  # GEMMUL8_ABI_VERSION of include/gemmul8_c.h this module's struct mirrors were written against
 
 
 def _bind_hip_runtime():
@@ -74,6 +76,11 @@ def bind(L):
     """Declare the C-ABI signatures (include/gemmul8_c.h) on a loaded library object: libgemmul8.so, or a laboratory build of it
     (tools/build_probes.sh, tools/experiments/) that a measurement script wants to drive through the same helpers."""
     L.gemmul8_version.restype = C.c_char_p
+    L.gemmul8_abi_version.restype = C.c_int
+    L.gemmul8_layout_bytes.restype = C.c_size_t
+    if L.gemmul8_abi_version() != ABI_VERSION or L.gemmul8_layout_bytes() != C.sizeof(Layout):
+        raise RuntimeError(f"libgemmul8.so has ABI version {L.gemmul8_abi_version()} / a {L.gemmul8_layout_bytes()}-byte gemmul8_layout; this module mirrors "
+                           f"version {ABI_VERSION} / {C.sizeof(Layout)} bytes: rebuild the library (python -c 'import __graft_entry__ as g; g.build()')")
     L.gemmul8_work_size.restype = C.c_size_t
     L.gemmul8_work_size.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.c_int, C.c_int,
                                     C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]

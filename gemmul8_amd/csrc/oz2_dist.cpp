@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <random>
 #include <string>
 #include <thread>
 #include <vector>
@@ -157,17 +158,80 @@ bool recv_all(int fd, void* p, size_t n) {
     return true;
 }
 
-// Rank 0 listens on the address MASTER_ADDR resolves to; only if that bind fails (MASTER_ADDR is a service / NAT address the host does
-// not own, or resolves to 127.0.1.1 on rank 0 itself) does it fall back to all interfaces, as torch's TCPStore does.  Every client
-// introduces itself with a 16-byte hello {magic, rank, world, nonce} before it is handed the id; the nonce is MASTER_PORT mixed with
-// GEMMUL8_DIST_SECRET (a job secret the launcher may export to every rank: without it any host that reaches the port and guesses the
-// world size could obtain the communicator id).  A rank is served once; a rank that asks AGAIN (its first reply may have been lost to its
-// 5 s receive timeout) is served one more time, no more.  Every accept / recv has a deadline: a missing rank ends in an error message
-// after GEMMUL8_DIST_TIMEOUT seconds (default 120) instead of a silent hang inside ncclCommInitRank.
+// Rank 0's listening address.  MASTER_ADDR names rank 0 for the OTHER ranks; on rank 0 itself it may resolve to an address other nodes
+// cannot reach: Debian / Ubuntu map the host's own name to 127.0.1.1 in /etc/hosts, and every 127/8 address is locally bindable, so a
+// bind to the resolved address "succeeds" and listens on loopback only (a multi-node rendezvous then times out).
+// Policy: a non-loopback address or the canonical 127.0.0.1 (a deliberately single-node job) is bound as given, falling back to all
+// interfaces when the host does not own it (service / NAT address); any OTHER 127/8 result is the hostname alias -> all interfaces
+// first, as torch's TCPStore does.  Strangers that reach the port are turned away by the challenge below.
+//
+// Hand-off protocol (version 2): on accept rank 0 sends a 16-byte random salt; the client answers with a 24-byte hello
+// {magic, rank, world, reserved, mac} where mac = SipHash-2-4(key; salt | rank | world | port) and key is 128 bits derived from
+// GEMMUL8_DIST_SECRET (a job secret the launcher may export to every rank).  The secret itself never travels and a recorded hello cannot be
+// replayed (fresh salt per connection).  WITHOUT GEMMUL8_DIST_SECRET the key derives from MASTER_PORT alone: then this is only a filter
+// against stray connections, not authentication -- anyone who knows the port can compute it.  A rank is served once; a rank that asks AGAIN
+// (its first reply may have been lost to its 5 s receive timeout) is served one more time, no more.  Every accept / recv has a deadline: a
+// missing rank ends in an error message after GEMMUL8_DIST_TIMEOUT seconds (default 120) instead of a silent hang inside ncclCommInitRank.
 struct IdHello {
-    uint32_t magic, rank, world, nonce;
+    uint32_t magic, rank, world, reserved;
+    uint64_t mac;
 };
-constexpr uint32_t kHelloMagic = 0x384c5547u;  // "GUL8"
+static_assert(sizeof(IdHello) == 24, "hello is 24 bytes on the wire");
+constexpr uint32_t kHelloMagic = 0x324c5547u;  // "GUL2"
+struct IdKey {
+    uint64_t k0, k1;
+};
+inline uint64_t rotl64(uint64_t x, int b) { return (x << b) | (x >> (64 - b)); }
+// SipHash-2-4 (Aumasson & Bernstein), 64-bit tag over `n` bytes
+uint64_t siphash24(const IdKey& key, const unsigned char* in, size_t n) {
+    uint64_t v0 = 0x736f6d6570736575ull ^ key.k0, v1 = 0x646f72616e646f6dull ^ key.k1, v2 = 0x6c7967656e657261ull ^ key.k0, v3 = 0x7465646279746573ull ^ key.k1;
+    auto round = [&] {
+        v0 += v1, v1 = rotl64(v1, 13), v1 ^= v0, v0 = rotl64(v0, 32);
+        v2 += v3, v3 = rotl64(v3, 16), v3 ^= v2;
+        v0 += v3, v3 = rotl64(v3, 21), v3 ^= v0;
+        v2 += v1, v1 = rotl64(v1, 17), v1 ^= v2, v2 = rotl64(v2, 32);
+    };
+    const size_t full = n / 8 * 8;
+    for (size_t i = 0; i < full; i += 8) {
+        uint64_t mword;
+        std::memcpy(&mword, in + i, 8);
+        v3 ^= mword, round(), round(), v0 ^= mword;
+    }
+    uint64_t last = (uint64_t)(n & 0xff) << 56;
+    for (size_t i = full; i < n; ++i) last |= (uint64_t)in[i] << (8 * (i - full));
+    v3 ^= last, round(), round(), v0 ^= last;
+    v2 ^= 0xff;
+    round(), round(), round(), round();
+    return v0 ^ v1 ^ v2 ^ v3;
+}
+IdKey id_key_from_env(int master_port) {
+    IdKey key{0x9e3779b97f4a7c15ull ^ (uint64_t)master_port, 0xc2b2ae3d27d4eb4full + (uint64_t)master_port};
+    if (const char* sec = std::getenv("GEMMUL8_DIST_SECRET")) {
+        uint64_t h0 = 14695981039346656037ull, h1 = 0x84222325cbf29ce4ull;  // two FNV-1a-64 chains with different offsets
+        for (const char* c = sec; *c; ++c) {
+            h0 = (h0 ^ (unsigned char)*c) * 1099511628211ull;
+            h1 = (h1 ^ (unsigned char)*c ^ 0x5c) * 1099511628211ull;
+            h1 = rotl64(h1, 29) + h0;
+        }
+        key.k0 ^= h0, key.k1 ^= h1;
+    }
+    return key;
+}
+uint64_t id_mac(const IdKey& key, const unsigned char salt[16], uint32_t rank, uint32_t world, uint32_t port) {
+    unsigned char msg[28];
+    std::memcpy(msg, salt, 16);
+    std::memcpy(msg + 16, &rank, 4);
+    std::memcpy(msg + 20, &world, 4);
+    std::memcpy(msg + 24, &port, 4);
+    return siphash24(key, msg, sizeof msg);
+}
+void random_salt(unsigned char salt[16]) {
+    std::random_device rd;  // /dev/urandom on Linux
+    for (int i = 0; i < 16; i += 4) {
+        const uint32_t v = rd();
+        std::memcpy(salt + i, &v, 4);
+    }
+}
 void set_io_timeout(int fd, int seconds) {
     timeval tv{};
     tv.tv_sec = seconds;
@@ -179,8 +243,14 @@ int rendezvous_timeout_s() {
     const int v = s ? std::atoi(s) : 0;
     return v > 0 ? v : 120;
 }
+// true: bind all interfaces before trying the resolved address (see the policy above)
+bool bind_any_first(const sockaddr* resolved) {
+    if (resolved->sa_family != AF_INET) return true;
+    const uint32_t a = ntohl(reinterpret_cast<const sockaddr_in*>(resolved)->sin_addr.s_addr);
+    return (a >> 24) == 127 && a != INADDR_LOOPBACK;
+}
 
-int exchange_id_tcp(const char* addr, int port, int rank, int world, uint32_t nonce, ncclUniqueId* id) {
+int exchange_id_tcp(const char* addr, int port, int rank, int world, const IdKey& key, ncclUniqueId* id) {
     addrinfo hints{}, *res = nullptr;
     hints.ai_family = AF_INET;
     hints.ai_socktype = SOCK_STREAM;
@@ -200,8 +270,11 @@ int exchange_id_tcp(const char* addr, int port, int rank, int world, uint32_t no
         any.sin_family = AF_INET;
         any.sin_addr.s_addr = htonl(INADDR_ANY);
         any.sin_port = htons((uint16_t)port);
-        const bool bound = ls >= 0 && (::bind(ls, res->ai_addr, res->ai_addrlen) == 0 ||
-                                       ::bind(ls, reinterpret_cast<const sockaddr*>(&any), sizeof any) == 0);
+        const sockaddr* first = bind_any_first(res->ai_addr) ? reinterpret_cast<const sockaddr*>(&any) : res->ai_addr;
+        const sockaddr* second = first == res->ai_addr ? reinterpret_cast<const sockaddr*>(&any) : res->ai_addr;
+        const socklen_t len1 = first == res->ai_addr ? (socklen_t)res->ai_addrlen : (socklen_t)sizeof any;
+        const socklen_t len2 = second == res->ai_addr ? (socklen_t)res->ai_addrlen : (socklen_t)sizeof any;
+        const bool bound = ls >= 0 && (::bind(ls, first, len1) == 0 || ::bind(ls, second, len2) == 0);
         if (!bound || ::listen(ls, world) != 0) {
             std::fprintf(stderr, "[GEMMUL8 DIST] cannot listen on %s:%d\n", addr, port);
             if (ls >= 0) ::close(ls);
@@ -219,9 +292,11 @@ int exchange_id_tcp(const char* addr, int port, int rank, int world, uint32_t no
             const int fd = ::accept(ls, nullptr, nullptr);
             if (fd < 0) continue;  // timeout or a transient error: the deadline check ends the loop
             set_io_timeout(fd, 5);
+            unsigned char salt[16];
+            random_salt(salt);
             IdHello h{};
-            if (recv_all(fd, &h, sizeof h) && h.magic == kHelloMagic && h.world == (uint32_t)world && h.nonce == nonce && h.rank >= 1 &&
-                h.rank < (uint32_t)world && served[h.rank] < 2 && send_all(fd, id, sizeof *id)) {
+            if (send_all(fd, salt, sizeof salt) && recv_all(fd, &h, sizeof h) && h.magic == kHelloMagic && h.world == (uint32_t)world && h.rank >= 1 &&
+                h.rank < (uint32_t)world && h.mac == id_mac(key, salt, h.rank, h.world, (uint32_t)port) && served[h.rank] < 2 && send_all(fd, id, sizeof *id)) {
                 if (served[h.rank]++ == 0) --left;
             }
             ::close(fd);
@@ -230,12 +305,15 @@ int exchange_id_tcp(const char* addr, int port, int rank, int world, uint32_t no
         if (left == 0) rc = 0;
         else std::fprintf(stderr, "[GEMMUL8 DIST] id rendezvous: %d of %d ranks did not connect to %s:%d within %d s\n", left, world - 1, addr, port, limit);
     } else {
-        const IdHello h{kHelloMagic, (uint32_t)rank, (uint32_t)world, nonce};
         while (rc && std::chrono::steady_clock::now() < deadline) {  // rank 0 may not be listening yet: retry until the deadline
             const int fd = ::socket(AF_INET, SOCK_STREAM, 0);
             if (fd < 0) break;
             set_io_timeout(fd, 5);
-            if (::connect(fd, res->ai_addr, res->ai_addrlen) == 0 && send_all(fd, &h, sizeof h) && recv_all(fd, id, sizeof *id)) rc = 0;
+            unsigned char salt[16];
+            if (::connect(fd, res->ai_addr, res->ai_addrlen) == 0 && recv_all(fd, salt, sizeof salt)) {
+                const IdHello h{kHelloMagic, (uint32_t)rank, (uint32_t)world, 0u, id_mac(key, salt, (uint32_t)rank, (uint32_t)world, (uint32_t)port)};
+                if (send_all(fd, &h, sizeof h) && recv_all(fd, id, sizeof *id)) rc = 0;
+            }
             ::close(fd);
             if (rc) std::this_thread::sleep_for(std::chrono::milliseconds(100));
         }
@@ -325,6 +403,7 @@ struct gemmul8_dist_plan {
     // event while the GEMMs of group j + 1 run on the caller's stream.  GEMMUL8_DIST_GROUPS (default 2; 1 = one exchange behind all GEMMs, the
     // round-4 order) must be the same on every rank: group j of sender s is split_range(its moduli, groups, j) on both sides of every pair.
     int groups = 2;
+    bool groups_agreed = false;  // checked across the ranks on the first call (one small all-reduce)
     hipStream_t xstream = nullptr;
     hipEvent_t xev[9] = {};  // [0 .. groups): GEMM group done (caller's stream); [8]: last exchange done (exchange stream)
     char* stage_send = nullptr;  // allgather_c staging (allocated on first use)
@@ -394,10 +473,8 @@ int gemmul8_comm_rccl_id_from_env(void* id128, int* rank_out, int* world_out) {
             port = (mp0 ? std::atoi(mp0) : 29500) + 17;
         }
         const char* mp = std::getenv("MASTER_PORT");
-        uint32_t nonce = (uint32_t)(mp ? std::atoi(mp) : 29500);
-        if (const char* sec = std::getenv("GEMMUL8_DIST_SECRET"))  // FNV-1a of the job secret, folded into the hello's nonce
-            for (uint32_t h = 2166136261u; *sec; ++sec) nonce ^= (h = (h ^ (unsigned char)*sec) * 16777619u);
-        OZ2_RC(exchange_id_tcp(addr ? addr : "127.0.0.1", port, rank, world, nonce, &id));
+        const IdKey key = id_key_from_env(mp ? std::atoi(mp) : 29500);
+        OZ2_RC(exchange_id_tcp(addr ? addr : "127.0.0.1", port, rank, world, key, &id));
     }
     std::memcpy(id128, &id, sizeof id);
     if (rank_out) *rank_out = rank;
@@ -481,12 +558,17 @@ int gemmul8_dist_create(const gemmul8_comm* comm, const gemmul8_dist_engine* eng
         ok = P->work && gemmul8_get_layout(dtype, backend, P->em, P->en, k, N, P->work, nullptr, nullptr, 0, 0, &P->L) == GEMMUL8_OK;
     }
     if (ok && kind == GEMMUL8_DIST_BLOCKS && !P->fast && world > 1) ok = (P->mx = (int32_t*)P->alloc(4 * (m + n))) != nullptr;
-    if (ok && kind == GEMMUL8_DIST_MODULI) ok = (P->recv = (char*)P->alloc(std::max<size_t>(1, (size_t)N * P->cols.size() * P->L.mp * P->mid))) != nullptr;
+    if (ok && kind == GEMMUL8_DIST_MODULI) ok = (P->recv = (char*)P->alloc(std::max<size_t>(8, (size_t)N * P->cols.size() * P->L.mp * P->mid))) != nullptr;
     if (ok && kind == GEMMUL8_DIST_MODULI_FP64SUM) {
         P->blk = 2 * P->cw * P->L.mp * P->comps;
         P->part = (double*)P->alloc((size_t)world * P->blk * 8);
         P->red = world > 1 ? (double*)P->alloc(P->blk * 8) : nullptr;
         ok = P->part && (world == 1 || P->red);
+    }
+    if (ok && kind == GEMMUL8_DIST_MODULI && P->hip_engine && world > 1 && P->groups > 1) {
+        // two-stream state of the pipelined exchange: all of it here or none of it (a partial set is released by gemmul8_dist_destroy below)
+        ok = hipStreamCreateWithFlags(&P->xstream, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; ok && i < 9; ++i) ok = hipEventCreateWithFlags(&P->xev[i], hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) {  // the arguments were valid: what failed is an allocation (or the layout of an allocated workspace)
         std::fprintf(stderr, "[GEMMUL8 DIST] rank %d: plan workspace allocation failed (%zu bytes held so far)\n", rank, P->bytes);
@@ -634,11 +716,30 @@ int gemmul8_dist_gemm(gemmul8_dist_plan* P, void* stream, const void* alpha, con
         // sequence on its one stream.
         const size_t slot = ncols * mp * mid;
         const int NG = world > 1 ? P->groups : 1;
-        const bool two_streams = P->hip_engine && world > 1 && NG > 1;
-        if (two_streams && !P->xstream) {
-            if (hipStreamCreateWithFlags(&P->xstream, hipStreamNonBlocking) != hipSuccess) return GEMMUL8_E_INTERNAL;
-            for (int i = 0; i < 9; ++i)
-                if (hipEventCreateWithFlags(&P->xev[i], hipEventDisableTiming) != hipSuccess) return GEMMUL8_E_INTERNAL;
+        const bool two_streams = P->hip_engine && world > 1 && NG > 1;  // stream + events exist since gemmul8_dist_create
+        if (world > 1 && !P->groups_agreed) {
+            // GEMMUL8_DIST_GROUPS is read per rank; a mismatch would give unequal grouped send / recv counts per pair = a silent RCCL hang.
+            // First call only: all-reduce(MAX) of {groups, -groups} (the first bytes of the receive buffer serve as scratch), one stream
+            // synchronisation, and a clear error on every rank instead.
+            int32_t v[2] = {P->groups, -P->groups};
+            if (P->hip_engine) {
+                if (hipMemcpyAsync(P->recv, v, sizeof v, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) return GEMMUL8_E_INTERNAL;
+            } else {
+                std::memcpy(P->recv, v, sizeof v);
+            }
+            OZ2_RC(X.allreduce_max_i32(X.ctx, P->recv, 2, stream));
+            if (P->hip_engine) {
+                if (hipMemcpyAsync(v, P->recv, sizeof v, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+                    return GEMMUL8_E_INTERNAL;
+            } else {
+                std::memcpy(v, P->recv, sizeof v);
+            }
+            if (v[0] != -v[1]) {
+                std::fprintf(stderr, "[GEMMUL8 DIST] rank %d: GEMMUL8_DIST_GROUPS differs between ranks (here %d, elsewhere %d ... %d): export the same value to every rank\n",
+                             rank, P->groups, -v[1], v[0]);
+                return GEMMUL8_E_ARG;
+            }
+            P->groups_agreed = true;
         }
         void* xs = two_streams ? (void*)P->xstream : stream;
         if (P->ev_begin && P->hip_engine) (void)hipEventRecord((hipEvent_t)P->ev_begin, (hipStream_t)stream);

@@ -82,6 +82,14 @@ typedef struct gemmul8_layout {
 GEMMUL8_API int gemmul8_get_layout(int dtype, int backend, size_t m, size_t n, size_t k, unsigned num_moduli, void *work, void *workA,
                        void *workB, int enable_skip_scalA, int enable_skip_scalB, gemmul8_layout *out);
 
+/* ABI guard.  gemmul8_get_layout fills sizeof(gemmul8_layout) bytes of the CALLER's struct: a binding compiled against an older header
+ * (the struct grew by lo_format in version 5) would be overrun.  GEMMUL8_ABI_VERSION is bumped whenever a struct of this header grows or a
+ * signature changes; a binding checks gemmul8_abi_version() == GEMMUL8_ABI_VERSION (C / C++) or gemmul8_layout_bytes() against the size of
+ * its own mirror of the struct (ctypes: gemmul8_amd/__init__.py does) before it calls anything else. */
+#define GEMMUL8_ABI_VERSION 6
+GEMMUL8_API int gemmul8_abi_version(void);
+GEMMUL8_API size_t gemmul8_layout_bytes(void);
+
 /* ---- phase-level entry points (one per kernel family) -------------------------------------- */
 
 /* Shifts + residue planes of both operands for moduli [t_begin, t_end).  fastmode=0 runs the

@@ -118,7 +118,11 @@ GEMMUL8_API int gemmul8_dist_allgather_c(gemmul8_dist_plan *plan, void *stream, 
 GEMMUL8_API int gemmul8_dist_set_events(gemmul8_dist_plan *plan, void *ev_begin, void *ev_end);
 /* The same for the plan's collectives: ev[0], ev[1] around the all-reduce(MAX) of the bound maxima (accurate mode, world > 1),
  * ev[2], ev[3] around the bulk exchange (moduli: grouped send/recv of residue blocks; fp64sum: reduce-scatter; blocks: none).
- * ev = NULL clears; entries may be NULL.  An event that the call does not reach is left untouched. */
+ * ev = NULL clears; entries may be NULL.  An event that the call does not reach is left untouched.
+ * Moduli plan with GEMMUL8_DIST_GROUPS > 1: the exchange runs on the plan's own stream BESIDE the GEMMs of the later groups, so
+ * ev[2] .. ev[3] (first group's exchange begins .. last group's ends) spans GEMM time as well and must not be added to the GEMM phase;
+ * the EXPOSED exchange time is elapsed(ev_end of gemmul8_dist_set_events, ev[3]).  The first call of such a plan synchronises `stream`
+ * once to cross-check GEMMUL8_DIST_GROUPS between the ranks (a mismatch is GEMMUL8_E_ARG on every rank, not a hang). */
 GEMMUL8_API int gemmul8_dist_set_exchange_events(gemmul8_dist_plan *plan, void *const ev[4]);
 /* Bytes this rank moves per gemmul8_dist_gemm call: the all-reduce payload (bytes of the reduced vector), and what the bulk exchange
  * sends to / receives from other ranks (fp64sum: the (world - 1) / world share of the reduce-scatter input / its output). */

@@ -21,3 +21,19 @@ def _fresh_knobs():
     import gemmul8_amd as g
     if g._lib is not None:
         g._lib.gemmul8_reload_knobs()
+
+
+@pytest.fixture(autouse=True)
+def _fp8_bound_mode_under_test(request):
+    """FP8 accurate mode: the ORACLE's default inflation of the bound GEMM is the reference's (k+1)*2^-24 (src/find_max.hpp:82-96), the
+    PRODUCT's default is its engine-safe formula (include/gemmul8_c.h gemmul8_set_fp8_bound_mode: gfx950's FP8 MFMA truncates).  Every
+    -m gpu test therefore starts with the product's safe mode selected EXPLICITLY ON BOTH SIDES (gpu_util.select_fp8_bound_mode); tests of
+    the reference formula select mode 1 on both sides themselves (parity_case(..., bound_mode=REFERENCE)).  Afterwards each side is back on
+    its own default."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import gpu_util as gu
+    gu.select_fp8_bound_mode(gu.SAFE)
+    yield
+    gu.restore_fp8_bound_defaults()

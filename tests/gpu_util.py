@@ -11,6 +11,21 @@ NP2T = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64
         np.dtype(np.complex64): torch.complex64, np.dtype(np.complex128): torch.complex128}
 
 
+SAFE, REFERENCE = ol.FP8_BOUND_SAFE, ol.FP8_BOUND_REFERENCE
+
+
+def select_fp8_bound_mode(mode):
+    """Select the FP8 accurate-mode bound inflation on BOTH sides: the product (gemmul8_set_fp8_bound_mode) and the oracle.  SAFE = the
+    product's default (engine-safe), REFERENCE = the oracle's default, (k+1)*2^-24 of src/find_max.hpp:82-96."""
+    assert g.lib().gemmul8_set_fp8_bound_mode(int(mode)) >= 0
+    ol.set_fp8_bound_mode(int(mode))
+
+
+def restore_fp8_bound_defaults():
+    g.lib().gemmul8_set_fp8_bound_mode(SAFE)
+    ol.set_fp8_bound_mode(REFERENCE)
+
+
 def setknob(monkeypatch, name, value):
     """Set (value=None: unset) one of the library's testing knobs for the rest of the test.  The library parses its knobs once
     (csrc/oz2_knobs.hpp), so the environment change is followed by gemmul8_reload_knobs; tests/conftest.py reloads again after the
@@ -97,24 +112,11 @@ def e4m3_of_ints(v):
     return byte.astype(np.uint8)
 
 
-def hip_gemm(A, B, N, fastmode=False, backend=g.INT8, opA="N", opB="N", alpha=1.0, beta=0.0, C0=None, want_intermediates=False,
-             timers=False):
-    """A, B: numpy arrays as stored (before op), like oracle_lib.gemm.  Returns C (numpy m x n) [, intermediates]."""
-    dA, dB = to_dev(A), to_dev(B)
-    dC = to_dev(C0.copy()) if C0 is not None else None
-    m, k = (A.shape if opA == "N" else A.shape[::-1])
-    n = B.shape[1] if opB == "N" else B.shape[0]
-    cplx = A.dtype.kind == "c"
-    tot, _, _ = g.work_size(cplx, backend, m, n, k, N)
-    work = torch.zeros(tot, dtype=torch.uint8, device="cuda")
-    Cd, tm, work = g.gemm(dA, dB, N, fastmode=fastmode, backend=backend, opA=opA, opB=opB, alpha=alpha, beta=beta, C_out=dC,
-                          work=work, timers=timers)
-    torch.cuda.synchronize()
-    Cn = from_dev(Cd)
-    if not want_intermediates:
-        return (Cn, tm) if timers else Cn
+def read_intermediates(work, code, backend, m, n, k, N):
+    """Shifts, operand planes (decoded to one byte per element) and C_mid of a finished call, read from its workspace through gemmul8_get_layout."""
+    cplx = code >= 2
     L = g.Layout()
-    g.check(g.lib().gemmul8_get_layout(g._dtype_code(dA.dtype), backend, m, n, k, N, work.data_ptr(), None, None, 0, 0, C.byref(L)))
+    g.check(g.lib().gemmul8_get_layout(code, backend, m, n, k, N, work.data_ptr(), None, None, 0, 0, C.byref(L)))
     w = work.cpu().numpy()
     base = work.data_ptr()
     parts, nm = L.parts, L.num_mat
@@ -151,7 +153,26 @@ def hip_gemm(A, B, N, fastmode=False, backend=g.INT8, opA="N", opB="N", alpha=1.
         Cm[t] = pc[:, :m, :]
     if not cplx:
         Cm = Cm[..., 0]
-    inter = dict(sftA=sftA, sftB=sftB, A_lo=A_lo, B_lo=B_lo, C_mid=Cm, lo_format=int(L.lo_format))
+    return dict(sftA=sftA, sftB=sftB, A_lo=A_lo, B_lo=B_lo, C_mid=Cm, lo_format=int(L.lo_format))
+
+
+def hip_gemm(A, B, N, fastmode=False, backend=g.INT8, opA="N", opB="N", alpha=1.0, beta=0.0, C0=None, want_intermediates=False,
+             timers=False):
+    """A, B: numpy arrays as stored (before op), like oracle_lib.gemm.  Returns C (numpy m x n) [, intermediates]."""
+    dA, dB = to_dev(A), to_dev(B)
+    dC = to_dev(C0.copy()) if C0 is not None else None
+    m, k = (A.shape if opA == "N" else A.shape[::-1])
+    n = B.shape[1] if opB == "N" else B.shape[0]
+    cplx = A.dtype.kind == "c"
+    tot, _, _ = g.work_size(cplx, backend, m, n, k, N)
+    work = torch.zeros(tot, dtype=torch.uint8, device="cuda")
+    Cd, tm, work = g.gemm(dA, dB, N, fastmode=fastmode, backend=backend, opA=opA, opB=opB, alpha=alpha, beta=beta, C_out=dC,
+                          work=work, timers=timers)
+    torch.cuda.synchronize()
+    Cn = from_dev(Cd)
+    if not want_intermediates:
+        return (Cn, tm) if timers else Cn
+    inter = read_intermediates(work, g._dtype_code(dA.dtype), backend, m, n, k, N)
     return (Cn, inter, tm) if timers else (Cn, inter)
 
 
@@ -171,13 +192,16 @@ def shifts_close(dev, orc, what=""):
     return nd
 
 
-def bounds_case(A, B, N, opA="N", opB="N", backend=g.INT8, skip_layout=False):
+def bounds_case(A, B, N, opA="N", opB="N", backend=g.INT8, skip_layout=False, bound_mode=SAFE):
     """Accurate-mode scaling phase, first half, BIT-EXACT against the oracle (rows a3 / a4 of SURVEY.md section 8):
     the 7-bit (INT8) / e4m3 round-up (FP8) bound planes of both operands, the preliminary shifts sft0 = maxUFP - ilogb(amax)
     and the row / column maxima of the bound product (int32; FP8: inflated floats), read from the workspace right after
     gemmul8_scale_bounds (scaling_accu_real.hpp:23-136,415-432, scaling.hpp:3-94, find_max.hpp:67-114).
     skip_layout: carve the workspace with enable_skip_scalA/B = 1, where the bound planes have their own slot behind the
-    residue planes (gemmul8_real.hpp:101-104) instead of aliasing plane 0."""
+    residue planes (gemmul8_real.hpp:101-104) instead of aliasing plane 0.
+    bound_mode (FP8 backend): SAFE = the product's engine-safe inflation, REFERENCE = (k+1)*2^-24 of find_max.hpp:82-96; selected on both sides."""
+    if backend == g.FP8:
+        select_fp8_bound_mode(bound_mode)
     dA, dB = to_dev(A), to_dev(B)
     m, k = (A.shape if opA == "N" else A.shape[::-1])
     n = B.shape[1] if opB == "N" else B.shape[0]
@@ -233,6 +257,13 @@ def bounds_case(A, B, N, opA="N", opB="N", backend=g.INT8, skip_layout=False):
     # tools/f8_bound_stress_dbg.py prints such cases).  The product's default inflation
     # ku = 7*2^-13 + 4(k+1)*2^-24 (gemmul8_set_fp8_bound_mode) covers that loss; what is asserted for real types is the GUARANTEE:
     # exact un-inflated maximum <= device value <= the oracle's inflated value of the exactly accumulated sum (+ one ulp per K-step).
+    if bound_mode == REFERENCE:
+        # the reference's formula on this engine: nothing is guaranteed one-sidedly (that is why it is not the product's default) -- the device's
+        # maxima sit within the engine's accumulation loss (1.2e-3 seen; 2^-9 allowed) of the oracle's inflated exactly-accumulated values
+        for d, o, what in ((rmax, orm, "row"), (cmax, ocm, "column")):
+            d64, o64 = d.astype(np.float64), o.astype(np.float64)
+            assert np.all(np.abs(d64 - o64) <= 2.0 ** -9 * np.abs(o64)), f"{what} maxima of the FP8 bound GEMM (reference formula) off by {np.max(np.abs(d64 - o64) / np.maximum(np.abs(o64), 1e-300))}"
+        return int((rmax != orm).sum() + (cmax != ocm).sum())
     if not cplx:
         ex_r, ex_c = ol.bound_maxima_f8_exact(oA, oB)
         for d, o, ex, what in ((rmax, orm, ex_r, "row"), (cmax, ocm, ex_c, "column")):
@@ -252,11 +283,14 @@ def bounds_case(A, B, N, opA="N", opB="N", backend=g.INT8, skip_layout=False):
     return int((rmax != orm).sum() + (cmax != ocm).sum())
 
 
-def parity_case(A, B, N, fastmode, opA="N", opB="N", alpha=1.0, beta=0.0, C0=None, backend=g.INT8):
+def parity_case(A, B, N, fastmode, opA="N", opB="N", alpha=1.0, beta=0.0, C0=None, backend=g.INT8, bound_mode=SAFE):
     """Full bit-exact parity of one case: accurate mode's bound planes / sft0 / bound maxima (exact), shifts (tolerant),
-    planes, C_mid, C (exact given the device's shifts)."""
+    planes, C_mid, C (exact given the device's shifts).  FP8 backend: `bound_mode` is selected on BOTH sides (SAFE = the product's
+    default inflation, REFERENCE = the reference's formula = the oracle's default)."""
+    if backend == g.FP8:
+        select_fp8_bound_mode(bound_mode)
     if not fastmode:
-        bounds_case(A, B, N, opA=opA, opB=opB, backend=backend)
+        bounds_case(A, B, N, opA=opA, opB=opB, backend=backend, bound_mode=bound_mode)
     Cd, it = hip_gemm(A, B, N, fastmode=fastmode, backend=backend, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0, want_intermediates=True)
     # oracle with its own shifts -> compare shifts
     _, ito = ol.gemm(A, B, N, fastmode=fastmode, backend=backend, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0, want_intermediates=True)
@@ -273,3 +307,76 @@ def parity_case(A, B, N, fastmode, opA="N", opB="N", alpha=1.0, beta=0.0, C0=Non
     assert np.array_equal(it["C_mid"], ito["C_mid"]), "C_mid planes differ"
     assert bits_equal(Cd, Co), f"final C differs in {np.sum(Cd != Co)} elements"
     return nd
+
+
+def embed(M, ld_extra, base_off, rng, tail=5):
+    """Column-major matrix M (numpy rows x cols) placed inside a larger 1-D buffer of its element type: base offset `base_off` ELEMENTS
+    (so the base pointer is only element-aligned), leading dimension rows + ld_extra, `tail` elements behind the last column; every element outside the window holds
+    random finite garbage.  Returns (buffer, ld)."""
+    rows, cols = M.shape
+    ld = rows + ld_extra
+    size = base_off + ld * cols + tail
+    buf = (rng.random(size) * 1e3 - 500).astype(M.dtype)
+    if M.dtype.kind == "c":
+        buf = (buf + 1j * (rng.random(size) * 1e3 - 500)).astype(M.dtype)
+    win = buf[base_off:base_off + ld * cols].reshape(cols, ld)
+    win[:, :rows] = M.T
+    return buf, ld
+
+
+def window_mask(size, base_off, ld, rows, cols):
+    """Boolean mask over a buffer of `embed`: True inside the rows x cols window."""
+    mk = np.zeros(size, bool)
+    mk[base_off:base_off + ld * cols].reshape(cols, ld)[:, :rows] = True
+    return mk
+
+
+def parity_case_embedded(A, B, C0, N, fastmode, opA, opB, alpha, beta, backend, ld_extra, base_off, rng, bound_mode=SAFE):
+    """`parity_case` on sub-matrix views: A, B, C0 (numpy, as stored) are embedded in larger buffers with ld = rows + ld_extra and a base
+    pointer `base_off` elements into the allocation; the HIP path (C ABI, explicit lda / ldb / ldc) and the oracle
+    (oracle_lib.gemm_embedded) run on the same bytes.  Asserted: shifts (tolerant), then with the device's shifts planes / C_mid and
+    the WHOLE C buffer bit for bit -- i.e. the m x n window equals the oracle's and every byte outside it is untouched; A's and B's
+    buffers unchanged.  beta != 0 updates C in place inside the larger matrix."""
+    if backend == g.FP8:
+        select_fp8_bound_mode(bound_mode)
+    m, k = (A.shape if opA == "N" else A.shape[::-1])
+    n = B.shape[1] if opB == "N" else B.shape[0]
+    exa, exb, exc = (ld_extra if np.ndim(ld_extra) else (ld_extra,) * 3)
+    offa, offb, offc = (base_off if np.ndim(base_off) else (base_off,) * 3)
+    bufA, lda = embed(A, exa, offa, rng)
+    bufB, ldb = embed(B, exb, offb, rng)
+    bufC, ldc = embed(C0, exc, offc, rng)
+    dt = A.dtype
+    cplx = dt.kind == "c"
+    code = ol.DT[dt]
+    dA, dB, dC = (torch.from_numpy(x.copy()).cuda() for x in (bufA, bufB, bufC))
+    tot, _, _ = g.work_size(cplx, backend, m, n, k, N)
+    work = torch.zeros(tot, dtype=torch.uint8, device="cuda")
+    al, be = np.array([alpha], dtype=dt), np.array([beta], dtype=dt)
+    isz = dt.itemsize
+    rc = g.lib().gemmul8_gemm(torch.cuda.current_stream().cuda_stream, code, backend, g.OPS[opA], g.OPS[opB], m, n, k, al.ctypes.data,
+                              dA.data_ptr() + offa * isz, lda, dB.data_ptr() + offb * isz, ldb, be.ctypes.data, dC.data_ptr() + offc * isz, ldc, N,
+                              int(fastmode), work.data_ptr(), None, None, 0, 0, 0, 0, None)
+    g.check(rc, "gemmul8_gemm")
+    torch.cuda.synchronize()
+    it = read_intermediates(work, code, backend, m, n, k, N)
+    assert bits_equal(dA.cpu().numpy(), bufA) and bits_equal(dB.cpu().numpy(), bufB), "an operand buffer was written"
+    Cdev = dC.cpu().numpy()
+    # the oracle with its own shifts (shift comparison), then with the device's (everything downstream bit-exact)
+    oC = bufC.copy()
+    ito = ol.gemm_embedded(bufA, offa, lda, bufB, offb, ldb, oC, offc, ldc, m, n, k, N, fastmode, backend, opA, opB, alpha, beta)
+    nd = shifts_close(it["sftA"], ito["sftA"], "sftA") + shifts_close(it["sftB"], ito["sftB"], "sftB")
+    oC = bufC.copy()
+    ito = ol.gemm_embedded(bufA, offa, lda, bufB, offb, ldb, oC, offc, ldc, m, n, k, N, fastmode, backend, opA, opB, alpha, beta,
+                           sftA_in=it["sftA"], sftB_in=it["sftB"])
+    if it["lo_format"] == 1:
+        for key in ("A_lo", "B_lo"):
+            ito[key] = np.where(ito[key] == 0x80, 0, ito[key]).astype(np.uint8)
+    assert np.array_equal(it["A_lo"], ito["A_lo"]), "A_lo planes differ"
+    assert np.array_equal(it["B_lo"], ito["B_lo"]), "B_lo planes differ"
+    assert np.array_equal(it["C_mid"], ito["C_mid"]), "C_mid planes differ"
+    mk = window_mask(bufC.size, offc, ldc, m, n)
+    assert bits_equal(Cdev[~mk], bufC[~mk]), "bytes of the enclosing C buffer outside the m x n window were written"
+    assert bits_equal(oC[~mk], bufC[~mk])
+    assert bits_equal(Cdev[mk], oC[mk]), f"final C differs in {np.sum(Cdev[mk] != oC[mk])} elements"
+    return nd, it["lo_format"]

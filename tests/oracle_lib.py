@@ -115,6 +115,33 @@ def gemm(A, B, N, fastmode=False, backend=INT8, opA="N", opB="N", alpha=1.0, bet
     return Cout
 
 
+def gemm_embedded(bufA, offA, lda, bufB, offB, ldb, bufC, offC, ldc, m, n, k, N, fastmode=False, backend=INT8, opA="N", opB="N", alpha=1.0,
+                  beta=0.0, sftA_in=None, sftB_in=None):
+    """The oracle pipeline on SUB-MATRIX VIEWS: op(A), op(B), C live inside larger column-major buffers (1-D numpy arrays of the element
+    type) at element offsets off* with leading dimensions ld* >= their row counts -- the calling pattern of the hook's LU / QR trailing
+    updates (src/hook.cu:609-730 forwards the caller's lda / ldb / ldc; include/gemmul8.hpp:107-112).  bufC is updated IN PLACE.
+    Returns the intermediates dict of `gemm`."""
+    dt = bufA.dtype
+    assert bufB.dtype == dt and bufC.dtype == dt and bufA.ndim == bufB.ndim == bufC.ndim == 1
+    cplx = dt.kind == "c"
+    parts = 3 if cplx else 1
+    nm = num_mat(backend, N)
+    al, be = np.array([alpha], dtype=dt), np.array([beta], dtype=dt)
+    sA, sB = np.zeros(m, np.int16), np.zeros(n, np.int16)
+    Alo = np.zeros((parts, nm, m, k), np.uint8)
+    Blo = np.zeros((parts, nm, n, k), np.uint8)
+    Cmid = np.zeros((N, n, m, 2) if cplx else (N, n, m), np.int8 if backend == INT8 else np.int16)
+    if sftA_in is not None:
+        sftA_in = np.ascontiguousarray(sftA_in, np.int16)
+    if sftB_in is not None:
+        sftB_in = np.ascontiguousarray(sftB_in, np.int16)
+    isz = dt.itemsize
+    rc = lib().oz2_gemm(DT[dt], backend, OPS[opA], OPS[opB], m, n, k, _p(al), bufA.ctypes.data + offA * isz, lda, bufB.ctypes.data + offB * isz, ldb,
+                        _p(be), bufC.ctypes.data + offC * isz, ldc, N, int(fastmode), 0, _p(sftA_in), _p(sftB_in), _p(sA), _p(sB), _p(Alo), _p(Blo), _p(Cmid))
+    assert rc == 0
+    return dict(sftA=sA, sftB=sB, A_lo=Alo, B_lo=Blo, C_mid=Cmid)
+
+
 def accurate_shifts(A, B, N, backend=INT8):
     """Accurate-mode shifts only (extract + bound GEMM + finalize, no modular planes): A (m x k), B (k x n) as stored for
     op N/N.  Returns (sftA[m], sftB[n]) NEGATED like the workspace holds them.  Cheap for thin A or thin B."""
@@ -189,9 +216,17 @@ def bound_maxima_f8_exact_cplx(Abar, Bbar):
     return P.max(axis=1), P.max(axis=0)
 
 
+FP8_BOUND_SAFE, FP8_BOUND_REFERENCE = 0, 1
+
+
 def set_fp8_bound_mode(mode):
-    """0 = the product's engine-safe inflation (default), 1 = the reference's (k+1)*2^-24 (find_max.hpp:82-96), 2 = round-3 default."""
+    """1 = the reference's (k+1)*2^-24 (find_max.hpp:82-96) -- THE ORACLE'S DEFAULT; 0 = the product's engine-safe inflation (the product's
+    default: a test comparing it with the oracle selects 0 on both sides), 2 = the product's round-3 default."""
     lib().oz2_set_fp8_bound_mode(int(mode))
+
+
+def get_fp8_bound_mode():
+    return int(lib().oz2_get_fp8_bound_mode())
 
 
 def fp8_bound_ku(k, mode=0):

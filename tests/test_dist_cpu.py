@@ -284,3 +284,84 @@ def test_transport_selftest_over_gloo(world, break_it):
             assert not ok and "reduce-scatter" in msg and "rank 1" in msg, msg
         else:
             assert ok and msg == "ok", (rank, msg)
+
+
+def _id_worker_env(rank, world, port, env, q):
+    import ctypes as C
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), GEMMUL8_DIST_PORT=str(port), MASTER_PORT=str(port - 17))
+    os.environ.update(env)
+    from gemmul8_amd import dist as gd
+    buf = C.create_string_buffer(128)
+    r, w = C.c_int(-1), C.c_int(-1)
+    rc = gd._lib().gemmul8_comm_rccl_id_from_env(buf, C.byref(r), C.byref(w))
+    q.put((rank, rc, buf.raw))
+
+
+def _run_id_rendezvous(envs, timeout=60):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_id_worker_env, args=(r, len(envs), port, envs[r], q)) for r in range(len(envs))]
+    _start_and_reap(procs, timeout)
+    return sorted(q.get(timeout=10) for _ in range(len(envs)))
+
+
+def test_unique_id_rendezvous_when_master_addr_is_the_debian_hostname_alias():
+    """on rank 0, MASTER_ADDR may resolve to 127.0.1.1 (Debian / Ubuntu map the host's own name there); every 127/8
+    address is locally bindable, so binding the resolved address 'works' and listens on loopback only -- ranks on other nodes never get
+    through.  Rank 0 must listen on all interfaces in that case: a peer that reaches the host through a DIFFERENT address (here 127.0.0.1
+    stands in for the NIC address) gets the id."""
+    got = _run_id_rendezvous([{"MASTER_ADDR": "127.0.1.1"}, {"MASTER_ADDR": "127.0.0.1"}])
+    assert all(rc == 0 for _, rc, _ in got), got
+    assert got[0][2] == got[1][2] and any(got[0][2])
+
+
+def test_unique_id_rendezvous_refuses_a_rank_with_the_wrong_job_secret():
+    """Hand-off protocol 2 (csrc/oz2_dist.cpp): rank 0 sends a fresh salt, the client answers SipHash-2-4(key(GEMMUL8_DIST_SECRET); salt | rank |
+    world | port).  A rank holding another secret is never served: both sides end with an error after GEMMUL8_DIST_TIMEOUT instead of a
+    communicator id in the wrong hands (or a hang)."""
+    base = {"MASTER_ADDR": "127.0.0.1", "GEMMUL8_DIST_TIMEOUT": "3"}
+    got = _run_id_rendezvous([dict(base, GEMMUL8_DIST_SECRET="job-4711"), dict(base, GEMMUL8_DIST_SECRET="job-4712")])
+    assert all(rc != 0 for _, rc, _ in got), got
+    good = _run_id_rendezvous([dict(base, GEMMUL8_DIST_SECRET="job-4711"), dict(base, GEMMUL8_DIST_SECRET="job-4711")])
+    assert all(rc == 0 for _, rc, _ in good) and good[0][2] == good[1][2]
+
+
+def _groups_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GEMMUL8_DIST_GROUPS"] = "2" if rank == 0 else "3"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gemmul8_amd as g
+        from gemmul8_amd import dist as gd
+        from dist_cpu_engine import OracleEngine
+        rng = np.random.default_rng(1)
+        m, n, k, N = 12, 10, 16, 8
+        A, B = _rand((m, k), np.float64, rng), _rand((k, n), np.float64, rng)
+        Cbuf = np.zeros((n, m))
+        eng = OracleEngine()
+        comm = gd.TorchTransport(device=False)
+        pl = gd.DistGemm(comm, "moduli", ol.DT[np.dtype(np.float64)], g.INT8, m, n, k, N, fastmode=True, engine=eng.table)
+        try:
+            pl.run_ptr(A.ctypes.data, m, B.ctypes.data, k, Cbuf.ctypes.data, m)
+            q.put((rank, "ran"))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+        pl.close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_moduli_plan_refuses_ranks_that_disagree_on_the_group_count():
+    """GEMMUL8_DIST_GROUPS is read per rank; a mismatch would give unequal grouped send / recv counts per pair -- a silent
+    hang with RCCL.  The first call cross-checks it with one small all-reduce and fails on EVERY rank with GEMMUL8_E_ARG."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_groups_worker, args=(r, 2, port, q)) for r in range(2)]
+    codes = _start_and_reap(procs, 120)
+    got = sorted(q.get(timeout=10) for _ in range(2))
+    assert codes == [0, 0], codes
+    assert all("failed with status" in msg for _, msg in got), got

@@ -109,10 +109,14 @@ def test_fullsize_subblock_parity_with_oracle(name, fast):
     assert err < tol, (name, err)
 
 
-@pytest.mark.parametrize("name", list(CONFIGS))
-def test_fullsize_accurate_mode_shifts_match_oracle(name):
-    """Accurate-mode shifts of sampled rows of A (they depend on ALL of B through the bound GEMM) and sampled columns of B."""
+@pytest.mark.parametrize("name,bound_mode", [(c, "safe") for c in CONFIGS] + [(c, "reference") for c in CONFIGS if CONFIGS[c][3] == g.FP8])
+def test_fullsize_accurate_mode_shifts_match_oracle(name, bound_mode):
+    """Accurate-mode shifts of sampled rows of A (they depend on ALL of B through the bound GEMM) and sampled columns of B.  The FP8
+    configuration runs twice: with the product's default (engine-safe) bound inflation and with the reference's (k+1)*2^-24
+    (src/find_max.hpp:82-96 = the oracle's default), the mode selected on both sides."""
+    import gpu_util as gu
     n, N, dt, be = CONFIGS[name]
+    gu.select_fp8_bound_mode(gu.REFERENCE if bound_mode == "reference" else gu.SAFE)
     A, B = make_inputs(n, dt)
     # uneven row / column magnitudes so that the shifts are not all the same number
     A = (A * (1.7 ** (torch.arange(n, device=DEV) % 7)).to(A.dtype)[None, :]).contiguous()

@@ -65,7 +65,10 @@ def test_random_case_bit_exact(seed, monkeypatch):
     if cplx and rng.integers(0, 2):
         alpha, beta = alpha + 0.5j, beta - 0.25j
     C0 = _rand((m, n), dtype, rng, 0.0) if beta != 0 else None
-    gu.parity_case(A, B, N, fast, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0, backend=backend)
+    # FP8 accurate mode: once with the product's default (engine-safe) bound inflation and once with the reference's (k+1)*2^-24
+    # (src/find_max.hpp:82-96), each selected on BOTH sides
+    for bound_mode in ((gu.SAFE, gu.REFERENCE) if backend == g.FP8 and not fast else (gu.SAFE,)):
+        gu.parity_case(A, B, N, fast, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0, backend=backend, bound_mode=bound_mode)
 
 
 N_SEEDS_LARGE_K = int(os.environ.get("GEMMUL8_FUZZ_LARGEK_SEEDS", "12"))
@@ -114,7 +117,10 @@ def test_random_case_large_k_bit_exact(seed, monkeypatch):
     B = _rand((k, n) if opB == "N" else (n, k), dtype, rng, phi)
     alpha, beta = [(1.0, 0.0), (1.0, 1.0), (-1.0, 0.0), (0.75, -0.5)][int(rng.integers(0, 4))]
     C0 = _rand((m, n), dtype, rng, 0.0) if beta != 0 else None
-    gu.parity_case(A, B, N, fast, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0, backend=backend)
+    # FP8 accurate mode: once with the product's default (engine-safe) bound inflation and once with the reference's (k+1)*2^-24
+    # (src/find_max.hpp:82-96), each selected on BOTH sides
+    for bound_mode in ((gu.SAFE, gu.REFERENCE) if backend == g.FP8 and not fast else (gu.SAFE,)):
+        gu.parity_case(A, B, N, fast, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0, backend=backend, bound_mode=bound_mode)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32, np.complex128])

@@ -650,16 +650,10 @@ def test_fp8_reference_bound_formula_end_to_end(dtype, N, shape):
             x = x + 1j * (0.25 + 0.25 * rng.random(sh)) * rng.choice([-1.0, 1.0], sh)
         return x.astype(dtype)
     A, B = one_binade((m, k)), one_binade((k, n))
-    lib = g.lib()
-    try:
-        assert lib.gemmul8_set_fp8_bound_mode(1) >= 0
-        ol.set_fp8_bound_mode(1)
-        assert gu.bounds_case(A, B, N, backend=g.FP8) == 0, "mode 1: inflated bound maxima differ from the oracle's bits"
-        nd = gu.parity_case(A, B, N, False, backend=g.FP8)     # bound planes / maxima / planes / C_mid / C bit-exact inside
-        assert nd == 0, f"mode 1 with exact bound sums: {nd} shifts differ from the oracle"
-    finally:
-        lib.gemmul8_set_fp8_bound_mode(0)
-        ol.set_fp8_bound_mode(0)
+    assert gu.bounds_case(A, B, N, backend=g.FP8, bound_mode=gu.REFERENCE) == 0, "mode 1: inflated bound maxima differ from the oracle's bits"
+    nd = gu.parity_case(A, B, N, False, backend=g.FP8, bound_mode=gu.REFERENCE)     # bound planes / maxima / planes / C_mid / C bit-exact inside
+    assert nd == 0, f"mode 1 with exact bound sums: {nd} shifts differ from the oracle"
+    assert ol.get_fp8_bound_mode() == ol.FP8_BOUND_REFERENCE and g.lib().gemmul8_set_fp8_bound_mode(1) == 1   # both sides really ran the reference formula
 
 
 @pytest.mark.parametrize("backend,dtype,N", [("INT8", np.float64, 14), ("INT8", np.complex64, 9), ("FP8", np.float32, 6), ("FP8", np.complex128, 13)])

@@ -208,7 +208,7 @@ def test_fp8_bound_maxima_against_numpy(mode):
     try:
         rmax, cmax = ol.bound_maxima(oA, oB, ol.FP8)
     finally:
-        ol.set_fp8_bound_mode(0)
+        ol.set_fp8_bound_mode(ol.FP8_BOUND_REFERENCE)   # the oracle's default
     ku = ol.fp8_bound_ku(k, mode)
     assert ku == ((k + 1) * 2.0 ** -24 if mode == 1 else 7 * 2.0 ** -13 + 4 * (k + 1) * 2.0 ** -24)   # exact in float32 at this k
     prod = (e4m3(oA[0]) @ e4m3(oB[0]).T).astype(np.float32).astype(np.float64)   # [m][n], exact in double
@@ -220,3 +220,59 @@ def test_fp8_bound_maxima_against_numpy(mode):
         kabs = 7.0 * ((k + 255) // 256 * 256) * 2.0 ** -14
         up = ru32(up.astype(np.float64) + kabs)                                  # second rounding up, like the device's __fadd_ru
     assert np.array_equal(rmax, up.max(axis=1)) and np.array_equal(cmax, up.max(axis=0))
+
+
+@pytest.mark.parametrize("dtype,backend,N", [(np.float64, 0, 14), (np.complex64, 0, 7), (np.float32, 1, 6), (np.complex128, 1, 12)])
+def test_oracle_on_submatrix_views_equals_the_contiguous_call(dtype, backend, N):
+    """oracle_lib.gemm_embedded (explicit lda / ldb / ldc > rows, element-offset base pointers, C updated in place) against the same
+    operands stored contiguously: identical planes, C_mid and window of C; nothing outside the window written (the checker of tests/test_gpu_ld.py)."""
+    import oracle_lib as ol
+    rng = np.random.default_rng(77)
+    m, n, k = 13, 9, 21
+    dt = np.dtype(dtype)
+
+    def rnd(shape):
+        x = rng.standard_normal(shape)
+        if dt.kind == "c":
+            x = x + 1j * rng.standard_normal(shape)
+        return np.asfortranarray(x.astype(dt))
+    for opA, opB, fast in (("N", "N", False), ("T", "C", True), ("C", "N", False)):
+        A = rnd((m, k) if opA == "N" else (k, m))
+        B = rnd((k, n) if opB == "N" else (n, k))
+        C0 = rnd((m, n))
+        alpha, beta = (0.75, -0.5)
+        Cref, itr = ol.gemm(A, B, N, fastmode=fast, backend=backend, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0, want_intermediates=True)
+        bufs = []
+        for M, ex, off in ((A, 7, 1), (B, 1, 3), (C0, 64, 1)):
+            ld = M.shape[0] + ex
+            buf = np.full(off + ld * M.shape[1] + 5, 123.25, dt)
+            buf[off:off + ld * M.shape[1]].reshape(M.shape[1], ld)[:, :M.shape[0]] = M.T
+            bufs.append((buf, off, ld))
+        (bA, oA, lda), (bB, oB, ldb), (bC, oC, ldc) = bufs
+        before = bC.copy()
+        it = ol.gemm_embedded(bA, oA, lda, bB, oB, ldb, bC, oC, ldc, m, n, k, N, fast, backend, opA, opB, alpha, beta)
+        for key in ("sftA", "sftB", "A_lo", "B_lo", "C_mid"):
+            assert np.array_equal(it[key], itr[key]), key
+        win = bC[oC:oC + ldc * n].reshape(n, ldc)
+        assert np.array_equal(np.ascontiguousarray(win[:, :m].T).view(np.uint8), np.ascontiguousarray(Cref).view(np.uint8))
+        win[:, :m] = before[oC:oC + ldc * n].reshape(n, ldc)[:, :m]
+        assert np.array_equal(bC.view(np.uint8), before.view(np.uint8)), "the oracle wrote outside the m x n window"
+
+
+def test_oracle_fp8_bound_default_is_the_reference_formula():
+    """the oracle's DEFAULT FP8 accurate-mode inflation is the reference's (k+1)*2^-24 (find_max.hpp:82-96), not the
+    product's engine-safe one; out of the box it reproduces the numpy statement of the reference formula bit for bit."""
+    assert ol.get_fp8_bound_mode() == ol.FP8_BOUND_REFERENCE
+    rng = np.random.default_rng(40)
+    m, n, k = 7, 5, 300
+    A = (rng.random((m, k)) - 0.5).astype(np.float32)
+    B = (rng.random((k, n)) - 0.5).astype(np.float32)
+    oA, _ = ol.extract_bounds(A, "N", True, ol.FP8)
+    oB, _ = ol.extract_bounds(B, "N", False, ol.FP8)
+    rmax, _ = ol.bound_maxima(oA, oB, ol.FP8)
+    prod = (ol.e4m3_decode(oA[0]) @ ol.e4m3_decode(oB[0]).T).astype(np.float32)
+    ku = np.float32((k + 1) * 2.0 ** -24)
+    exact = prod.astype(np.float64) * (1.0 + float(ku))          # ku * t + t in double, then rounded UP to float
+    up = exact.astype(np.float32)
+    up = np.where(up.astype(np.float64) < exact, np.nextafter(up, np.float32(np.inf)), up)
+    assert np.array_equal(rmax, up.max(axis=1))
