@@ -96,6 +96,10 @@ static Knobs parse_knobs() {
     if (const int c = num("GEMMUL8_GEMM_CUS", 0); c >= 8) k.gemm_cus = c & ~7;
     if (const char* e = getenv("GEMMUL8_FP8_FUSED"); e && e[0] == '0') k.fp8_fused = 0;
     if (const char* e = getenv("GEMMUL8_FP8_PLANES")) k.fp8_planes = e[0] == 'e' ? 1 : 0;
+    if (const char* e = getenv("GEMMUL8_CRT_PANELS"); e && atoi(e) > 1) {
+        k.crt_panels = std::min(atoi(e), 256);
+        k.crt_panels_ring = e[strlen(e) - 1] == 'r';
+    }
     if (const char* e = getenv("GEMMUL8_MAP_COLBLOCK"); e && *e) k.map_colblock = atoi(e) > 0 ? atoi(e) : 0;
     return k;
 }
@@ -529,11 +533,30 @@ int gemmul8_gemm(void* stream_, int dtype, int backend, int op_A, int op_B, size
     rc = gemmul8_scale(stream, dtype, backend, op_A, op_B, m, n, k, A, lda, B, ldb, N, fastmode, 0, N, &L, skipA, skipB);
     if (rc) return rc;
     if (T) OZ2_HIP(hipEventRecord(T->ev[1], stream));
-    rc = gemmul8_lowprec_gemm(stream, dtype, backend, m, n, k, N, 0, N, &L);
-    if (rc) return rc;
-    if (T) OZ2_HIP(hipEventRecord(T->ev[2], stream));
-    rc = gemmul8_crt(stream, dtype, backend, N, m, n, L.C_mid, L.mp, L.sizeC, L.sftA, L.sftB, alpha, beta, C, ldc);
-    if (rc) return rc;
+    // Column panels (testing knob GEMMUL8_CRT_PANELS; SURVEY 8 f3 "by cache residency", measured in profiles/r06_panel_crt*.txt): residue GEMMs of panel p,
+    // then its CRT, so that a panel's C_mid could stay in the Infinity Cache in between.  Real INT8 only; panel edges on tile columns.
+    const int P = (backend == kINT8 && !is_complex(dtype) && g_batch.batch <= 1) ? std::min<int>(knobs().crt_panels, (int)((n + 255) / 256)) : 0;
+    if (P > 1) {
+        const size_t tiles = (n + 255) / 256, esz = is_f32(dtype) ? 4 : 8;
+        for (int p = 0; p < P; ++p) {
+            const size_t c0 = std::min(n, tiles * p / P * 256), c1 = std::min(n, tiles * (p + 1) / P * 256);
+            if (c1 <= c0) continue;
+            gemmul8_layout Lp = L;
+            Lp.B_lo = (char*)L.B_lo + c0 * L.kp;
+            if (!knobs().crt_panels_ring) Lp.C_mid = (char*)L.C_mid + c0 * L.mp;
+            rc = gemmul8_lowprec_gemm(stream, dtype, backend, m, c1 - c0, k, N, 0, N, &Lp);
+            if (rc) return rc;
+            rc = gemmul8_crt(stream, dtype, backend, N, m, c1 - c0, Lp.C_mid, L.mp, L.sizeC, L.sftA, L.sftB + c0, alpha, beta, (char*)C + c0 * ldc * esz, ldc);
+            if (rc) return rc;
+        }
+        if (T) OZ2_HIP(hipEventRecord(T->ev[2], stream));  // the phases interleave: everything is booked under the low-precision GEMMs
+    } else {
+        rc = gemmul8_lowprec_gemm(stream, dtype, backend, m, n, k, N, 0, N, &L);
+        if (rc) return rc;
+        if (T) OZ2_HIP(hipEventRecord(T->ev[2], stream));
+        rc = gemmul8_crt(stream, dtype, backend, N, m, n, L.C_mid, L.mp, L.sizeC, L.sftA, L.sftB, alpha, beta, C, ldc);
+        if (rc) return rc;
+    }
     if (T) {
         OZ2_HIP(hipEventRecord(T->ev[3], stream));
         OZ2_HIP(hipEventSynchronize(T->ev[3]));

@@ -15,6 +15,8 @@ struct Knobs {
     int fp8_planes = 0;            // GEMMUL8_FP8_PLANES=e4m3|fp6: FP8 backend's residue planes as e4m3 bytes (1) / FP6 panel images where they fit (0, default)
     int fp8_fused = 1;             // GEMMUL8_FP8_FUSED=0: FP6 planes, but the three products of a modulus as two or three launches with int16 partial-residue planes (the round-4 structure) instead of one three-segment tile loop
     int gemm_cus = 0;              // GEMMUL8_GEMM_CUS=<n>: workgroups (= CUs) of the persistent INT8 residue-GEMM launches, a multiple of 8 (0: every CU); the phase-overlap measurements leave CUs to a second stream with it
+    int crt_panels = 0;            // GEMMUL8_CRT_PANELS=<P>[r]: real INT8 whole call as P column panels, gemm(p) crt(p) back to back (SURVEY 8 f3 by cache residency); suffix r: every panel's residues go to panel 0's columns of C_mid (0: one GEMM launch, one CRT launch)
+    int crt_panels_ring = 0;
     int map_colblock = -1;         // GEMMUL8_MAP_COLBLOCK=<w>: tile-columns per column block of the GEMM tile walk, 0 = full width (-1: map_colblock's rule)
 };
 const Knobs& knobs();  // oz2_driver.hip

@@ -37,3 +37,29 @@ def _fp8_bound_mode_under_test(request):
     gu.select_fp8_bound_mode(gu.SAFE)
     yield
     gu.restore_fp8_bound_defaults()
+
+
+# ---- per-file wall time of the -m gpu suite (the driver's step limit is 1200 s; keep `pytest -m gpu` under 600 s and SEE where it goes):
+# written to gpurun_out/gpu_suite_durations.json at the end of any session that ran GPU tests; the round's copy lives in profiles/.
+_DUR = {}
+
+
+def pytest_runtest_logreport(report):
+    if report.when in ("setup", "call", "teardown"):
+        f = report.nodeid.split("::")[0]
+        d = _DUR.setdefault(f, [0.0, 0])
+        d[0] += report.duration
+        d[1] += report.when == "call"
+
+
+def pytest_sessionfinish(session, exitstatus):
+    gpu = {f: v for f, v in _DUR.items() if os.path.basename(f).startswith("test_gpu_")}
+    if not gpu or sum(v[1] for v in gpu.values()) < 20:   # a full (or nearly full) GPU run only
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    rec = {"total_s": round(sum(v[0] for v in gpu.values()), 1), "exitstatus": int(exitstatus),
+           "files": {f: {"seconds": round(v[0], 1), "tests": v[1]} for f, v in sorted(gpu.items(), key=lambda kv: -kv[1][0])}}
+    with open(os.path.join(out, "gpu_suite_durations.json"), "w") as fh:
+        json.dump(rec, fh, indent=1)

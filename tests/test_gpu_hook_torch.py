@@ -13,7 +13,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM = os.path.join(ROOT, "gemmul8_amd", "lib", "libgemmul8_preload.so")
 
 
+_RUNS = {}
+
+
 def _run(extra_env):
+    """One run of tools/hook_torch_demo.py under `extra_env`; a configuration that already ran in this session (the un-hooked native run is wanted by
+    three tests) is answered from its record: every run is a fresh Python + torch start-up, ~10 s of the GPU suite's budget each."""
+    key = tuple(sorted(extra_env.items()))
+    if key in _RUNS:
+        (_run.sgemm_err, _run.sbmm_err, _run.lin_err), res = _RUNS[key]
+        return res
+    res = _run_once(extra_env)
+    _RUNS[key] = ((_run.sgemm_err, _run.sbmm_err, _run.lin_err), res)
+    return res
+
+
+def _run_once(extra_env):
     env = dict(os.environ)
     env.setdefault("GEMMUL8_MIN_FLOPS", "0")   # small demo matrices: emulate every call (default would be the automatic size floor)
     env.update(extra_env)

@@ -885,3 +885,20 @@ def test_fp8_skip_scaling_cached_planes_meet_a_partner_of_another_width():
     C2, sA2, sB2 = call(dB2, n2, 1)
     assert np.array_equal(sA1, sA2)
     assert gu.bits_equal(C2, ol.gemm(A, B2, N, fastmode=True, backend=g.FP8, sftA_in=sA2, sftB_in=sB2))
+
+
+@pytest.mark.parametrize("panels", ["3", "3r", "64"])
+def test_crt_panels_knob_is_bit_identical(panels, monkeypatch):
+    """GEMMUL8_CRT_PANELS=<P>[r] (csrc/oz2_driver.hip; SURVEY 8 f3 by cache residency, measured negative in profiles/r06_panel_crt_cache_residency.txt):
+    the real INT8 call as P column panels gemm(p) -> crt(p), optionally all through panel 0's columns of C_mid.  Same bits as the one-launch order, also
+    with beta != 0, ragged edges and more panels asked for than there are tile columns."""
+    import gpu_util as gu
+    rng = np.random.default_rng(31)
+    m, n, k = 300, 1000, 260
+    A, B, C0 = rand((m, k), np.float64, rng), rand((k, n), np.float64, rng), rand((m, n), np.float64, rng)
+    ref = gu.hip_gemm(A, B, 14, alpha=-1.5, beta=0.5, C0=C0)
+    gu.setknob(monkeypatch, "GEMMUL8_CRT_PANELS", panels)
+    got = gu.hip_gemm(A, B, 14, alpha=-1.5, beta=0.5, C0=C0)
+    assert gu.bits_equal(got, ref)
+    if not panels.endswith("r"):
+        gu.parity_case(A, B, 14, True, alpha=-1.5, beta=0.5, C0=C0)   # every panel wrote its own columns: C_mid is the oracle's, too
