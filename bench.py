@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--moduli", type=int, default=14)
     ap.add_argument("--fast", action="store_true", help="fast mode (14 GEMMs) instead of accurate (15)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines (profiling runs)")
+    ap.add_argument("--lean", action="store_true", help="configs 3 / 5: only the configuration itself (no more_moduli / bound-mode comparison calls): "
+                                                        "profiling runs, so that every launch of the dominant kernel under rocprofv3 is the workload's")
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
                     help="BASELINE.json config: 2 = DGEMM 8192^3 N=14 INT8 (headline, default); 3 = SGEMM 16384^3 N=6 FP8; "
                          "4 = DGEMM 16384^3 N=16 INT8 (same code path as 2 at that size; meant for --gpus 8 under torch.distributed.run); "
@@ -194,7 +196,16 @@ def run_other_config(args):
            "max_rel_err": err,
            "native_same_gpu": {"lib": f"rocBLAS/hipBLASLt {name} via torch.matmul", "value": cflops * 2.0 * n ** 3 / nat_ms * 1e-9,
                                "unit": "TFLOPS", "ms": nat_ms, "max_rel_err": errn}}
-    if args.config == 3:
+    if args.config == 3 and n == 16384 and N == 6 and f6 and not mode:
+        # fabric-side bytes of ONE launch of the dominant kernel (the 6-moduli gemm_f6_kernel<7>), from the committed PMC passes named in profiles/MANIFEST.json
+        # (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes of `bench.py --config 3 --lean`); algorithmic bytes = 2 x 12 plane images + 6 int16 residue planes
+        tr = traffic_manifest_entry(n, N, "sgemm_16384_moduli6_fp8")
+        if tr:
+            out["roofline"]["traffic"] = tr["hbm_side_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = tr["source"]
+            out["roofline"]["traffic_kernel"] = tr["kernel"]
+            out["roofline"]["algorithmic_bytes_per_launch"] = 2 * 12 * n * n * 0.75 + 6 * n * n * 2.0
+    if args.config == 3 and not args.lean:
         # the accuracy axis: 6 moduli (BASELINE's count) leave the emulated SGEMM ~9x less accurate than the native one on this sampled block; the same call
         # with 7 / 8 moduli (the reference sweeps up to 12 for S: testing/common.hpp:38-43), timed the same way, beside it
         more = []
@@ -216,7 +227,7 @@ def run_other_config(args):
                          "max_rel_err": float(np.max(np.abs(got2 - ref) / np.abs(ref)))})
             del work2
         out["more_moduli"] = more
-    if be == g.FP8 and not mode:
+    if be == g.FP8 and not mode and not args.lean:
         # how far is the default (engine-safe) FP8 accurate-mode bound from the reference's formula (k+1)*2^-24
         # (src/find_max.hpp:82-96) on THESE inputs?  Same call in both modes: rows / columns whose shift differs, elements of C that differ.
         import ctypes as C_
@@ -224,9 +235,8 @@ def run_other_config(args):
         g.check(g.lib().gemmul8_get_layout(g._dtype_code(dt), be, n, n, n, N, work.data_ptr(), None, None, 0, 0, C_.byref(L)))
         base = work.data_ptr()
         def shifts():
-            w16 = work.view(torch.int16)
-            a0, b0 = (L.sftA - base) // 2, (L.sftB - base) // 2
-            return w16[a0:a0 + n].clone(), w16[b0:b0 + n].clone()
+            a0, b0 = L.sftA - base, L.sftB - base
+            return work[a0:a0 + 2 * n].view(torch.int16).clone(), work[b0:b0 + 2 * n].view(torch.int16).clone()
         prev = g.lib().gemmul8_set_fp8_bound_mode(0)
         g.gemm(A, B, N, fastmode=False, backend=be, C_out=Cm, work=work)
         torch.cuda.synchronize()
@@ -267,12 +277,12 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def traffic_manifest_entry(n, N):
-    """profiles/MANIFEST.json -> the committed PMC traffic record of the dominant kernel for DGEMM n^3 with N moduli (None if the manifest
-    has no entry for this workload, or the file / kernel it names is missing)."""
+def traffic_manifest_entry(n, N, workload=None):
+    """profiles/MANIFEST.json -> the committed PMC traffic record of the dominant kernel of a workload (default: DGEMM n^3 with N moduli, INT8);
+    None if the manifest has no entry for it, or the file / kernel it names is missing."""
     try:
         man = json.load(open(os.path.join(ROOT, "profiles", "MANIFEST.json")))
-        ent = man["workloads"][f"dgemm_{n}_moduli{N}_int8"]
+        ent = man["workloads"][workload or f"dgemm_{n}_moduli{N}_int8"]
         recs = json.load(open(os.path.join(ROOT, "profiles", ent["pmc_traffic"])))
         rec = recs[ent["kernel"]]
         return {"hbm_side_bytes_per_launch": rec["hbm_side_bytes_per_launch"], "source": "profiles/" + ent["pmc_traffic"], "kernel": ent["kernel"]}
@@ -340,8 +350,34 @@ def single_gpu_phases(args, n, N, A, B, dev, stream):
         torch.cuda.synchronize()
         if it:
             acc += np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(4)])
+    ph = dict(zip(("bounds", "quantise", "lowprec_gemm", "crt"), (acc / 3).tolist()))
+    # The persistent residue GEMM holds every CU it runs on: an RCCL point-to-point / reduce-scatter kernel on the plan's exchange stream only overlaps
+    # on CUs the GEMM gives up (GEMMUL8_GEMM_CUS, csrc/oz2_knobs.hpp).  What giving up 8 / 16 CUs COSTS the GEMM is measurable on one GPU, today:
+    # the same launch on 256 / 248 / 240 CUs (mean of 3), so that the first multi-GPU run can choose its exchange schedule against measured numbers.
+    by_cus = {}
+    try:
+        for cus in (0, 248, 240):
+            if cus:
+                os.environ["GEMMUL8_GEMM_CUS"] = str(cus)
+            else:
+                os.environ.pop("GEMMUL8_GEMM_CUS", None)
+            lib.gemmul8_reload_knobs()
+            ts = []
+            for it in range(4):
+                e0, e1 = event_pair()
+                e0.record(stream)
+                g.check(lib.gemmul8_lowprec_gemm(st, g.D, g.INT8, n, n, n, N, 0, N, C.byref(L)))
+                e1.record(stream)
+                torch.cuda.synchronize()
+                if it:
+                    ts.append(e0.elapsed_time(e1))
+            by_cus[str(cus or 256)] = float(np.mean(ts))
+    finally:
+        os.environ.pop("GEMMUL8_GEMM_CUS", None)
+        lib.gemmul8_reload_knobs()
+    ph["lowprec_gemm_by_cus"] = by_cus
     del work, Cmat
-    return dict(zip(("bounds", "quantise", "lowprec_gemm", "crt"), (acc / 3).tolist()))
+    return ph
 
 
 def plan_model(name, world, N, n, ph, grid):
@@ -377,7 +413,20 @@ def plan_model(name, world, N, n, ph, grid):
         terms = {"bounds": b * (0.30 + 0.17 / G + 0.53 / G), "quantise": q * mr / N, "lowprec_gemm": gm * mr / N,
                  "crt": part_bytes / 5.0e12 * 1e3 + cr / G * 0.5, "allreduce": ar,
                  "exchange": rs_bytes / (link * max(1, min(G - 1, 7))) * 1e3 if G > 1 else 0.0}
-    return {"model_ms": float(sum(terms.values())), "model_terms_ms": {k_: float(v) for k_, v in terms.items()}}
+    out = {"model_ms": float(sum(terms.values())), "model_terms_ms": {k_: float(v) for k_, v in terms.items()}}
+    # the same model if the GEMM leaves 8 / 16 CUs to the exchange kernels (measured single-GPU GEMM cost on 248 / 240 CUs, same run) and the
+    # exchange then overlaps completely (moduli plan) -- the other corner of the trade; the truth of an 8-GPU node lies between the two
+    by = ph.get("lowprec_gemm_by_cus") or {}
+    if name == "moduli" and G > 1 and by.get("256"):
+        alt = {}
+        for cus in ("248", "240"):
+            if by.get(cus):
+                t = dict(terms)
+                t["lowprec_gemm"] = terms["lowprec_gemm"] * by[cus] / by["256"]
+                t["exchange"] = (out_bytes / max(1, G - 1)) / link * 1e3 / 2 if mr >= 2 else terms["exchange"]   # only the last group's exchange stays exposed
+                alt[cus] = float(sum(t.values()))
+        out["model_ms_if_gemm_leaves_cus"] = alt
+    return out
 
 
 def run_plans(args, n, N, A, B, dev, stream, backend, rank, world):

@@ -10,7 +10,7 @@ the GEMM kernels (all reads are global_load_lds_dwordx4, 16 B per lane) take the
 kernels only, which left the quantise (32 B per lane) and CRT (8 B per lane, 512 B per wave and plane) kernels a factor 2 low
 (VERDICT r01).  WRITE_SIZE matched the known byte counts of every kernel and is used as reported.
 
-usage: tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> [n=8192] [N=14]
+usage: tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> [n=8192] [N=14] [fp8]   (fp8: config 3, SGEMM n^3 on the FP8 backend)
 """
 import collections
 import csv
@@ -47,11 +47,25 @@ known_reads = {  # bytes a launch reads exactly once (config 2: DGEMM n^3, N mod
     "oz2::stage_strided_kernel<double, 1>": operand,
     "oz2::stage_kmajor_kernel<double, 1>": operand,
 }
+if len(sys.argv) > 6 and sys.argv[6] == "fp8":   # config 3: SGEMM n^3, N moduli, FP8 backend (float operands, int16 residue planes)
+    op32 = n * n * 4.0
+    known_reads = {
+        "oz2::amax_strided_kernel<float>": op32,
+        "oz2::extract_strided_kernel<float>": op32,
+        "oz2::extract_kmajor_kernel<float>": op32,
+        "oz2::quantise_f6_pair_kernel<float>": 2 * op32,
+        "oz2::quantise_pair_kernel<float>": 2 * op32,
+        "oz2::fast_shift_pair_kernel<float>": 2 * op32,
+    }
 out = {}
 for k in sorted(set(fetch) | set(write)):
     f_kib, w_kib = fetch.get(k, 0.0), write.get(k, 0.0)
-    if "gemm_i8_kernel" in k or "gemm_f8_kernel" in k:
+    if "gemm_i8_kernel" in k or "gemm_f8_kernel" in k or "gemm_f6_kernel" in k:
         corr, why = 2.0, "16 B/lane LDS-DMA reads (guide)"
+    elif "crt_kernel<float" in k and f_kib > 0 and len(sys.argv) > 6:   # the N int16 residue planes, read once (beta = 0)
+        ratio = N * n * n * 2.0 / (f_kib * 1024.0)
+        corr = 2.0 if ratio > 1.5 else 1.0
+        why = f"calibrated: reads {N * n * n * 2.0 / 2**20:.0f} MiB once, counter says {f_kib / 1024:.0f} MiB (ratio {ratio:.2f})"
     elif k in known_reads and f_kib > 0:
         ratio = known_reads[k] / (f_kib * 1024.0)
         corr = 2.0 if ratio > 1.5 else 1.0
