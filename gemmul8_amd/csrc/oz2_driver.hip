@@ -96,6 +96,7 @@ static Knobs parse_knobs() {
     if (const int c = num("GEMMUL8_GEMM_CUS", 0); c >= 8) k.gemm_cus = c & ~7;
     if (const char* e = getenv("GEMMUL8_FP8_FUSED"); e && e[0] == '0') k.fp8_fused = 0;
     if (const char* e = getenv("GEMMUL8_FP8_PLANES")) k.fp8_planes = e[0] == 'e' ? 1 : 0;
+    if (const char* e = getenv("GEMMUL8_SCALE_FOLD"); e && e[0] == '0') k.scale_fold = 0;
     if (const char* e = getenv("GEMMUL8_CRT_PANELS"); e && atoi(e) > 1) {
         k.crt_panels = std::min(atoi(e), 256);
         k.crt_panels_ring = e[strlen(e) - 1] == 'r';
@@ -203,14 +204,18 @@ int gemmul8_get_layout(int dtype, int backend, size_t m, size_t n, size_t k, uns
     return GEMMUL8_OK;
 }
 
-// scratch carving shared by the two halves of the scaling phase: rowmax int32[mp] | colmax int32[pad(n)] | amax bits
-static int scale_scratch(const gemmul8_layout* L, size_t n, int** rowmax, int** colmax, void** amax) {
+// scratch carving shared by the two halves of the scaling phase: rowmax int32[mp] | colmax int32[pad(n)] | amax bits | sft0 copies int16[mp] | int16[pad(n)]
+// (the copies of the preliminary shifts are what the shift finalize folded into the quantise launch reads: L->sftA / sftB receive the final values there)
+static inline size_t scale_scratch_bytes(size_t mp, size_t np) { return 4 * mp + 4 * np + 8 * std::max(mp, np) + 2 * (mp + np); }
+static int scale_scratch(const gemmul8_layout* L, size_t n, int** rowmax, int** colmax, void** amax, int16_t** s0A = nullptr, int16_t** s0B = nullptr) {
     const size_t np = padding256(n);
-    const size_t need = 4 * L->mp + 4 * np + 8 * std::max(L->mp, np);
-    if (L->scratch_bytes < need) return GEMMUL8_E_ARG;
+    if (L->scratch_bytes < scale_scratch_bytes(L->mp, np)) return GEMMUL8_E_ARG;
     *rowmax = (int*)L->scratch;
     *colmax = *rowmax + L->mp;
     *amax = (void*)(*colmax + np);
+    int16_t* s0 = (int16_t*)((char*)*amax + 8 * std::max(L->mp, np));
+    if (s0A) *s0A = s0;
+    if (s0B) *s0B = s0 + L->mp;
     return GEMMUL8_OK;
 }
 
@@ -230,18 +235,31 @@ int gemmul8_scale_bounds(void* stream_, int dtype, int backend, int op_A, int op
     const bool conjA = cplx && op_A == 2, conjB = cplx && op_B == 2;
     int *rowmax, *colmax;
     void* amax;
-    int rc = scale_scratch(L, n, &rowmax, &colmax, &amax);
+    int16_t *s0A, *s0B;
+    int rc = scale_scratch(L, n, &rowmax, &colmax, &amax, &s0A, &s0B);
     if (rc) return rc;
     const size_t np = padding256(n);
     const size_t bstrideA = cplx ? L->sizeA : 0, bstrideB = cplx ? L->sizeB : 0;
-    // one zero-fill launch for the maxima arrays AND the amax scratch of the first row-strided extract (they are adjacent)
-    OZ2_HIP(launch_zero(stream, rowmax, 4 * (L->mp + np) + 8 * std::max(L->mp, np)));
+    // The maxima arrays AND the amax scratch of the first row-strided extract (they are adjacent) start at zero.  The fill rides on the first K-MAJOR
+    // extract of the call (that operand then goes first; every kernel that accumulates into the words is launched after it); only when there is none --
+    // both operands row-strided, or the K-major one skipped -- does it cost a launch of its own (4-5 us of a launch-bound call).
+    const size_t zero_bytes = 4 * (L->mp + np) + 8 * std::max(L->mp, np);
+    const bool runA = !skipA, runB = !skipB;
+    const int zero_on = !knobs().scale_fold ? -1 : (runA && kmajA) ? 0 : (runB && kmajB) ? 1 : -1;
+    if (zero_on < 0) OZ2_HIP(launch_zero(stream, rowmax, zero_bytes));
     bool amax_zero = true;
-    if (!skipA) {
-        OZ2_HIP(launch_extract(stream, dtype, backend, kmajA, conjA, m, k, A, lda, (int8_t*)L->A_bound, bstrideA, L->kp, L->sftA, amax, amax_zero, g_batch.sa));
-        if (!kmajA) amax_zero = false;
-    }
-    if (!skipB) OZ2_HIP(launch_extract(stream, dtype, backend, kmajB, conjB, n, k, B, ldb, (int8_t*)L->B_bound, bstrideB, L->kp, L->sftB, amax, amax_zero, g_batch.sb));
+    auto extract = [&](int which) -> int {
+        const bool isA = which == 0;
+        if (!(isA ? runA : runB)) return 0;
+        const bool km = isA ? kmajA : kmajB;
+        OZ2_HIP(launch_extract(stream, dtype, backend, km, isA ? conjA : conjB, isA ? m : n, k, isA ? A : B, isA ? lda : ldb, (int8_t*)(isA ? L->A_bound : L->B_bound),
+                               isA ? bstrideA : bstrideB, L->kp, isA ? L->sftA : L->sftB, amax, amax_zero, isA ? g_batch.sa : g_batch.sb, isA ? s0A : s0B,
+                               which == zero_on ? (void*)rowmax : nullptr, which == zero_on ? zero_bytes : 0));
+        if (!km) amax_zero = false;  // (a second row-strided operand clears the shared amax scratch itself)
+        return 0;
+    };
+    if (int e = extract(zero_on == 1 ? 1 : 0)) return e;
+    if (int e = extract(zero_on == 1 ? 0 : 1)) return e;
     if (col_end > col_begin) {
         const int8_t* Ab = (const int8_t*)L->A_bound;
         const int8_t* Bb = (const int8_t*)L->B_bound + col_begin * L->kp;
@@ -252,7 +270,7 @@ int gemmul8_scale_bounds(void* stream_, int dtype, int backend, int op_A, int op
             // products ArBi, AiBr and (Ar-Ai)(Br-Bi) combined with round-up additions; the first two pass through a float
             // scratch plane [ncols][mp] behind the maxima arrays.
             const size_t ncols = col_end - col_begin;
-            const size_t used = 4 * L->mp + 4 * np + 8 * std::max(L->mp, np);
+            const size_t used = scale_scratch_bytes(L->mp, np);
             const size_t foff = (used + 255) / 256 * 256;
             if (L->scratch_bytes < foff + 4 * L->mp * ncols) return GEMMUL8_E_ARG;
             float* fbuf = (float*)((char*)L->scratch + foff);
@@ -306,9 +324,18 @@ int gemmul8_scale_finish(void* stream_, int dtype, int backend, int op_A, int op
     } else {
         int *rowmax, *colmax;
         void* amax;
-        int rc = scale_scratch(L, n, &rowmax, &colmax, &amax);
+        int16_t *s0A, *s0B;
+        int rc = scale_scratch(L, n, &rowmax, &colmax, &amax, &s0A, &s0B);
         if (rc) return rc;
-        OZ2_HIP(launch_shift_finalize(stream, backend, N, skipA ? 0 : m, rowmax, L->sftA, skipB ? 0 : n, colmax, L->sftB));
+        if (t_end > t_begin && knobs().scale_fold) {
+            // the finalize rides on the quantise launch below (one dispatch less: 4-5 us of a launch-bound call): every workgroup derives its rows' final
+            // shifts from the extract's preliminary ones (scratch copy) and the bound maxima, the first k chunk of a row publishes them to L->sftA / sftB
+            const float log2P = backend == kINT8 ? GEMMUL8_LOG2P_INT8[N - 2] : GEMMUL8_LOG2P_FP8[N - 2];
+            oa.fin_sft0 = s0A, oa.fin_max = rowmax, oa.fin_log2P = log2P;
+            ob.fin_sft0 = s0B, ob.fin_max = colmax, ob.fin_log2P = log2P;
+        } else {  // no plane to write (a rank without moduli): the shifts are still wanted by the CRT
+            OZ2_HIP(launch_shift_finalize(stream, backend, N, skipA ? 0 : m, rowmax, L->sftA, skipB ? 0 : n, colmax, L->sftB));
+        }
     }
     OZ2_HIP(launch_quantise_pair(stream, dtype, backend, (int)t_begin, (int)t_end, k, L->kp, oa, ob));
     return GEMMUL8_OK;

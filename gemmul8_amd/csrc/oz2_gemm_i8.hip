@@ -58,6 +58,9 @@ namespace oz2 {
 #ifndef OZ2_KBAR_MAX_KP
 #define OZ2_KBAR_MAX_KP 5120  // padded k up to which the K-step-barrier schedule is used (see launch<EPI>); 0 = never, 1 << 30 = always.  Round 4 (after the epilogue / tile-prologue work): +1.0 / +1.3 % at k = 4608 / 5120 on 8192^2 x 14 planes, +0.5 % at 5120 on 16384^2 x 6; at 6144 +0.9 % / -1.1 %, at 7168 0 / -1.3 %, at 8192 -1.3 % (profiles/archive/r04_gemm_ab_kbar_threshold.txt)
 #endif
+#ifndef OZ2_KBAR_PEEL_FIRST
+#define OZ2_KBAR_PEEL_FIRST 0
+#endif
 #ifndef OZ2_SLEEP_A
 #define OZ2_SLEEP_A 4  // s_sleep units (64 clocks) between the A producers' 8 groups of 2 LDS-DMA instructions
 #endif
@@ -84,6 +87,27 @@ struct NoCrt {
 #ifdef OZ2_LAB_FUSED_CRT
 #include OZ2_LAB_FUSED_CRT  // i8_crt_tail, i8_producer_crt
 #endif
+// Re-initialisation of the accumulators by the (idle) matrix pipe, sub-block by sub-block BEHIND the epilogue's reads (round 6): as soon as the residue
+// epilogue has reduced the four accumulator tiles of a sub-block (hook phase 0), four MFMAs on all-zero fragments with C = the start value rewrite them --
+// 32 matrix instructions per wave and tile on a pipe that has nothing else to do, instead of 128 v_mov_b32 at the head of the next tile on the vector
+// ALU that the two waves' epilogues (~650 instructions each) are bound by.
+#ifndef OZ2_KBAR_MFMA_REINIT
+#define OZ2_KBAR_MFMA_REINIT 1
+#endif
+template <bool ZERO> struct MfmaReinitHook {  // ZERO: the start value is 0 (short-K launches): the C operand is the inline constant
+    v4i (*acc)[4];
+    int acc0;
+    __device__ __forceinline__ void operator()(int sb, int phase) const {
+        if (phase != 0) return;
+        const int tj = sb >> 1, tg = sb & 1;
+        const v4i z = {0, 0, 0, 0};
+        const v4i c = ZERO ? v4i{0, 0, 0, 0} : v4i{acc0, acc0, acc0, acc0};
+        __builtin_amdgcn_sched_barrier(0);  // not above the reduction's last read of these registers (a hoisted definition needs a second register set)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)  // B = the dead accumulator tile itself (times an all-zero A): four DISTINCT instructions -- on identical operands the
+            acc[tg * 4 + ti][tj] = __builtin_amdgcn_mfma_i32_16x16x64_i8(z, acc[tg * 4 + ti][tj], c, 0, 0, 0);  // compiler keeps one and copies its result three times
+    }
+};
 // SMALLK: the launch has K <= 512 (accumulators start at 0, three-instruction residue); the epilogue form is a compile-time property of the kernel
 template <int EPI, bool KBAR, int FUSE, bool SMALLK = false>
 __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args, const std::conditional_t<FUSE != 0, CrtArgs, NoCrt> crt) {
@@ -206,18 +230,33 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     // the whole persistent loop is instantiated once per half (WM1 = lagging half) so that each gets its own register allocation
     auto run = [&]<bool WM1>() {
         int sA = 0;  // slot of A(g); B(g) sits in the next slot (mod 5)
+        // MFMA_REINIT: the accumulators live across the tile loop; the v_mov initialisation runs once, every later tile finds them rewritten by
+        // the matrix pipe behind the previous epilogue (MfmaReinitHook)
+        constexpr bool MFMA_REINIT = OZ2_KBAR_MFMA_REINIT && SMALLK && EPI == EPI_MOD && FUSE == 0;  // SMALLK only: with a register C operand (start value -2^31) the form measured -0.6 ... -1.6 % at k = 1024 / 2048 (profiles/r06_short_k_epilogue_ab.txt)
+        v4i acc[8][4];
+        if constexpr (MFMA_REINIT) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = v4i{args.acc0, args.acc0, args.acc0, args.acc0};
+        }
         for (int vb = blockIdx.x; vb < total; vb += G) {
             const TileMap tmap = map_tile(vb, total, args.map);
             const PlaneRef pref = (FUSE || EPI == EPI_MAX) ? PlaneRef{0, 0} : plane_ref(args, tmap.plane);  // (the bound GEMM looks its plane up at the epilogue: one value less across its K loop)
             const PlaneConsts pcon = (FUSE || EPI == EPI_MAX) ? PlaneConsts{} : plane_consts(args, pref);  // fetched here: the latency passes behind the K loop
             for (int pl = 0; pl < planes_per_tile; ++pl) {
-            v4i acc[8][4];
             v4i af[4], bf[4];
+            // PEEL_FIRST (round 6, NOT enabled: -DOZ2_KBAR_PEEL_FIRST=1): SMALLK (k <= 512: accumulators start at 0) without the 128 v_mov_b32 per wave and
+            // tile -- the first K-step's MFMAs take the inline constant 0 as their C operand.  The compiler then moves seven accumulator quads through
+            // scratch INSIDE the peeled K-step (140 bytes; the peeled copy's results and the loop's registers do not coalesce), as with round 4's attempt.
+            constexpr bool PEEL_FIRST = OZ2_KBAR_PEEL_FIRST && SMALLK && EPI == EPI_MOD && FUSE == 0;
+            if constexpr (!PEEL_FIRST && !MFMA_REINIT) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = v4i{EPI == EPI_MAX ? 0 : args.acc0, EPI == EPI_MAX ? 0 : args.acc0, EPI == EPI_MAX ? 0 : args.acc0, EPI == EPI_MAX ? 0 : args.acc0};
+            }
 // The fragment reads of a segment are issued in the order the MFMAs use them (pinned: the scheduler otherwise issues the first-used fragment last) and the
 // waits in front of the MFMAs are the compiler's own per-fragment lgkmcnt(3..0): the first four MFMAs of a segment start when THEIR fragment has landed.  No
 // barrier covers the read latency in this schedule (in the ping-pong schedule one does: there the same change is neutral).  8192^2 x 14 planes, interleaved,
@@ -232,14 +271,17 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
         }                                                                                                                    \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) { af[i] = *(const v4i*)(curA + (((seg_) & 1) * 4 + i) * 16 * BK + coff_); OZ2_KBAR_PIN(); } \
     } while (0)
-#define OZ2_MMA_SEG(seg_)                                                                                                    \
+#define OZ2_MMA_SEG(seg_, first_)                                                                                            \
     do {                                                                                                                     \
         OZ2_KBAR_WAIT();                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
         __builtin_amdgcn_s_setprio(1);                                                                                       \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                     \
             const int j = (i & 1) ? 3 - jj : jj; /* serpentine: see the ping-pong branch */                                   \
-            acc[((seg_) & 1) * 4 + i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[((seg_) & 1) * 4 + i][j], 0, 0, 0); \
+            if ((first_) && (seg_) < 2) /* the K-step's first touch of these accumulators: C = 0 */                          \
+                acc[((seg_) & 1) * 4 + i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], v4i{0, 0, 0, 0}, 0, 0, 0); \
+            else                                                                                                             \
+                acc[((seg_) & 1) * 4 + i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[((seg_) & 1) * 4 + i][j], 0, 0, 0); \
         }                                                                                                                    \
         __builtin_amdgcn_s_setprio(0);                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                                   \
@@ -254,7 +296,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
             const int nph = (EPI == EPI_MAX && args.kt_mid > 0) ? 2 : 1;
             for (int ph = 0; ph < nph; ++ph) {
             const int kt_end = (EPI == EPI_MAX && ph + 1 < nph) ? args.kt_mid : KT;
-            for (; kt < kt_end; ++kt) {
+            auto kstep = [&]<bool FIRST>() {
                 OZ2_SET_PANELS();
 #pragma unroll
                 for (int seg = 0; seg < 4; ++seg) {
@@ -267,13 +309,18 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
                         __builtin_amdgcn_s_barrier();
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    OZ2_MMA_SEG(seg);
+                    OZ2_MMA_SEG(seg, FIRST);
                 }
                 if (!WM1) {
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            };
+            if constexpr (PEEL_FIRST) {  // (one phase, kt == 0 here, KT >= 2)
+                kstep.template operator()<true>();
+                ++kt;
             }
+            for (; kt < kt_end; ++kt) kstep.template operator()<false>();
 #undef OZ2_SET_PANELS
 #undef OZ2_LOAD_SEG
 #undef OZ2_MMA_SEG
@@ -286,10 +333,23 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #pragma unroll
                 for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-            if constexpr (FUSE != 0) i8_epilogue<EPI, NoHook, -1>(acc, args, PlaneRef{0, pl}, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane);
-            else if constexpr (EPI == EPI_MAX) i8_epilogue<EPI, NoHook, 0>(acc, args, plane_ref(args, tmap.plane), PlaneConsts{}, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane);
-            else i8_epilogue<EPI, NoHook, (int)SMALLK>(acc, args, pref, pcon, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane);
+#ifndef OZ2_KBAR_EPI_LANE_LIVE
+#define OZ2_KBAR_EPI_LANE_LIVE 0
+#endif
+            int lane_e = lane;
+            if constexpr (!OZ2_KBAR_EPI_LANE_LIVE && EPI == EPI_MOD) {  // (the complex combine keeps the live lane id: recomputed there, 116 bytes of accumulator spills appear in its K loop)
+            // The lane id of the epilogue is RECOMPUTED here (two v_mbcnt behind an opaque asm, so that it is not hoisted): kept live across the K loop it was
+            // spilled (12 bytes of scratch), and the reload's vmcnt(0) made every tile wait for the PREVIOUS tile's residue stores to be acknowledged --
+            // free behind a long K loop, a stall of the order of the store latency at k <= 1024 where the K loop is 2-8 us (round 6).  The consumer waves
+            // issue no other VMEM loads, so no vmcnt wait is left on their path at all.
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+            } else {
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+            }
+            if constexpr (FUSE != 0) i8_epilogue<EPI, NoHook, -1>(acc, args, PlaneRef{0, pl}, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane_e);
+            else if constexpr (EPI == EPI_MAX) i8_epilogue<EPI, NoHook, 0>(acc, args, plane_ref(args, tmap.plane), PlaneConsts{}, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane_e);
+            else if constexpr (MFMA_REINIT) i8_epilogue<EPI, MfmaReinitHook<SMALLK>, (int)SMALLK>(acc, args, pref, pcon, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane_e, MfmaReinitHook<SMALLK>{acc, args.acc0});
+            else i8_epilogue<EPI, NoHook, (int)SMALLK>(acc, args, pref, pcon, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane_e);
 #endif
             }  // phase
             }

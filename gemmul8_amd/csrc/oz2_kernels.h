@@ -69,7 +69,7 @@ hipError_t launch_gemm_f8_bound_cplx(hipStream_t stream, int stage, const int8_t
 hipError_t launch_zero(hipStream_t stream, void* p, size_t bytes);
 hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajor, bool conj, size_t rows, size_t k, const void* X,
                           size_t ld, int8_t* lo, size_t part_stride, size_t kp, int16_t* sft0, void* scratch_amax, bool amax_is_zero = false,
-                          size_t xstride = 0);
+                          size_t xstride = 0, int16_t* sft0_keep = nullptr, void* zero_p = nullptr, size_t zero_bytes = 0);
 hipError_t launch_shift_finalize(hipStream_t stream, int backend, unsigned N, size_t rowsA, const int* maxA, int16_t* sftA, size_t rowsB,
                                  const int* maxB, int16_t* sftB);
 // one operand of the quantise / fast-shift launches; rows == 0 = absent (skip-scaling: the cached planes and shifts are kept)
@@ -83,6 +83,11 @@ struct QuantOperand {
     size_t plane_stride = 0, part_stride = 0;
     size_t xstride = 0;       // batched launch: bytes between the items' operands
     size_t f6_rows = 0;       // FP8 backend: > 0 = write FP6 panel images (oz2_gemm_f6.hip) of a plane with this many image rows (A: mp, B: n)
+    // accurate mode, quantise only: fin_max != nullptr folds the shift finalize into the launch -- the final shifts are derived from the preliminary
+    // ones (fin_sft0: the scratch copy the extract kept) and the bound maxima, and published to `sft` by the launch itself
+    const int16_t* fin_sft0 = nullptr;
+    const int* fin_max = nullptr;
+    float fin_log2P = 0.0f;
 };
 // FP8 backend: the residue planes are FP6 panel images whenever B's last row block fits its share of the reference's plane size
 // (16-row granules at 3/4 byte per element: n >= 45; 64 keeps whole wave tiles); GEMMUL8_FP8_PLANES=e4m3 keeps the e4m3 byte planes

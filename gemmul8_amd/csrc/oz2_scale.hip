@@ -161,6 +161,17 @@ struct StageArgs {
     size_t part_stride;   // bytes between Re / Im / Re+Im plane sets
     const int16_t* sft;   // MODE_MOD: negated final shifts
     int16_t* sft0;        // MODE_BOUND: written (maxUFP - ilogb(amax))
+    unsigned* zero_p;     // MODE_BOUND, K-major: the launch also zero-fills zero_words 32-bit words from here (the maxima arrays + amax scratch of the bounds
+    unsigned zero_words;  //   phase: the bound GEMM's and the row-strided partner's atomicMax targets) -- instead of a launch of its own
+    int16_t* sft0_keep;   // MODE_BOUND: a second copy of sft0 in the scratch region (never overwritten by the final shifts: what the fused finalize reads)
+    // MODE_MOD, accurate mode: the shift finalize (scaling_accu_real.hpp:6-18) folded into the quantise launch -- fin_max != nullptr: every workgroup
+    // derives its rows' final shifts from (fin_sft0, fin_max) itself, the workgroup of a row's first k chunk stores the negated value to fin_out (= the
+    // workspace's sft array, which `sft` then does not have to hold yet).  One launch less per accurate-mode call (4-5 us at launch-bound sizes).
+    const int16_t* fin_sft0;
+    const int* fin_max;
+    int16_t* fin_out;
+    float fin_log2P;
+    int fin_float_max;
     const void* amax;     // MODE_BOUND, strided: per-row amax bit patterns (U-sized unsigned)
     int backend;
     int conj;
@@ -178,6 +189,23 @@ struct StageArgs {
 // slower that way).
 #define OZ2_ZW ((size_t)blockIdx.z * a.bw)
 #define OZ2_ZX ((size_t)blockIdx.z * a.bx)
+__device__ __forceinline__ int fused_final_shift(const StageArgs& a, size_t row, bool writer, size_t zw) {
+    const int s0 = ((const int16_t*)((const char*)a.fin_sft0 + zw))[row];
+    const int amax = ((const int*)((const char*)a.fin_max + zw))[row];  // INT8: int32 maximum; FP8: bit pattern of a non-negative float
+    int f = 0;
+    if (amax > 0) {
+        const float l = __log2f(a.fin_float_max ? __int_as_float(amax) : __int2float_rn(amax));
+        f = __float2int_rd(__fmaf_rd(-0x1.000006p-1f, l, a.fin_log2P));
+    }
+    const int16_t neg = (int16_t)(-(s0 + f));
+    if (writer) ((int16_t*)((char*)a.fin_out + zw))[row] = neg;
+    return -(int)neg;
+}
+
+// MODE_MOD: the (positive) shift of a row.  Plain form: the workspace's negated final shifts.  Fused finalize (a.fin_max): the same arithmetic as
+// shift_finalize_kernel below on (sft0, bound maximum); `writer` (exactly one thread per row over the whole grid) publishes the negated final shift.
+#define OZ2_ROW_SHIFT(a_, row_, writer_)                                                                                        \
+    ((a_).fin_max == nullptr ? -(int)((const int16_t*)((const char*)(a_).sft + OZ2_ZW))[(row_)] : fused_final_shift((a_), (row_), (writer_), OZ2_ZW))
 
 #ifndef OZ2_BOUND_FLOAT
 #define OZ2_BOUND_FLOAT 1
@@ -691,6 +719,12 @@ template <typename T, int MODE>
 __device__ __forceinline__ void stage_kmajor_body(const StageArgs& a, const unsigned bid) {
     using E = ET<T>;
     using U = typename E::U;
+    if constexpr (MODE == MODE_BOUND) {
+        if (a.zero_words) {  // the zero-fill of the bounds phase rides on this launch (every kernel that accumulates into the words runs after it)
+            unsigned* zp = (unsigned*)((char*)a.zero_p + OZ2_ZW);
+            for (unsigned i = bid * 256u + threadIdx.x; i < a.zero_words; i += gridDim.x * 256u) zp[i] = 0u;
+        }
+    }
     if constexpr (MODE == MODE_MOD) {
         if (a.f6) {
             // FP6 panel images: one workgroup per (8 rows, one 128-element K-step), the K-step index fastest: the eight rows' 16-byte X slots and
@@ -702,7 +736,7 @@ __device__ __forceinline__ void stage_kmajor_body(const StageArgs& a, const unsi
             const size_t k0 = (size_t)(bid - rg * nks) * 128 + (size_t)(threadIdx.x & 31) * 4;
             if (row >= a.rows) return;  // (uniform over the 32 lanes of a row)
             const T* x = (const T*)((const char*)a.X + OZ2_ZX) + row * a.ld;
-            const int s = -(int)((const int16_t*)((const char*)a.sft + OZ2_ZW))[row];
+            const int s = OZ2_ROW_SHIFT(a, row, bid == rg * nks && (threadIdx.x & 31) == 0);
             T v[4];
             load4<T>(x, k0, a.k, v);
             emit4<T, MODE>(a, row, k0, v, s);
@@ -717,7 +751,7 @@ __device__ __forceinline__ void stage_kmajor_body(const StageArgs& a, const unsi
         const size_t k0 = (size_t)(bid - row * nch) * 1024 + (size_t)threadIdx.x * 4;
         if (k0 >= a.kp) return;
         const T* x = (const T*)((const char*)a.X + OZ2_ZX) + row * a.ld;
-        const int s = -(int)((const int16_t*)((const char*)a.sft + OZ2_ZW))[row];
+        const int s = OZ2_ROW_SHIFT(a, row, k0 == 0);
         T v[4];
         load4<T>(x, k0, a.k, v);
         emit4<T, MODE>(a, row, k0, v, s);
@@ -752,7 +786,10 @@ __device__ __forceinline__ void stage_kmajor_body(const StageArgs& a, const unsi
             am = sm[2] > am ? sm[2] : am;
             am = sm[3] > am ? sm[3] : am;
             s = (a.backend == kINT8 ? 5 : 7) - ilogb0(am);
-            if (threadIdx.x == 0) ((int16_t*)((char*)a.sft0 + OZ2_ZW))[row] = (int16_t)s;
+            if (threadIdx.x == 0) {
+                ((int16_t*)((char*)a.sft0 + OZ2_ZW))[row] = (int16_t)s;
+                if (a.sft0_keep) ((int16_t*)((char*)a.sft0_keep + OZ2_ZW))[row] = (int16_t)s;
+            }
 #pragma unroll
             for (int it = 0; it < NC; ++it) {
                 const size_t k0 = (size_t)threadIdx.x * 4 + (size_t)it * 1024;
@@ -788,9 +825,12 @@ __device__ __forceinline__ void stage_kmajor_body(const StageArgs& a, const unsi
         am = sm[2] > am ? sm[2] : am;
         am = sm[3] > am ? sm[3] : am;
         s = (a.backend == kINT8 ? 5 : 7) - ilogb0(am);
-        if (threadIdx.x == 0) ((int16_t*)((char*)a.sft0 + OZ2_ZW))[row] = (int16_t)s;
+        if (threadIdx.x == 0) {
+            ((int16_t*)((char*)a.sft0 + OZ2_ZW))[row] = (int16_t)s;
+            if (a.sft0_keep) ((int16_t*)((char*)a.sft0_keep + OZ2_ZW))[row] = (int16_t)s;
+        }
     } else {
-        s = -(int)((const int16_t*)((const char*)a.sft + OZ2_ZW))[row];
+        s = OZ2_ROW_SHIFT(a, row, threadIdx.x == 0);
     }
     for (size_t k0 = (size_t)threadIdx.x * 4; k0 < a.kp; k0 += 1024) {
         T v[4];
@@ -894,9 +934,12 @@ __device__ __forceinline__ void stage_strided_body(const StageArgs& a, const uns
             U am;
             __builtin_memcpy(&am, &bits, sizeof(U));
             s = (a.backend == kINT8 ? 5 : 7) - ilogb0(am);
-            if (kt == 0 && c == 0) ((int16_t*)((char*)a.sft0 + OZ2_ZW))[row] = (int16_t)s;
+            if (kt == 0 && c == 0) {
+                ((int16_t*)((char*)a.sft0 + OZ2_ZW))[row] = (int16_t)s;
+                if (a.sft0_keep) ((int16_t*)((char*)a.sft0_keep + OZ2_ZW))[row] = (int16_t)s;
+            }
         } else {
-            s = -(int)((const int16_t*)((const char*)a.sft + OZ2_ZW))[row];
+            s = OZ2_ROW_SHIFT(a, row, kt == 0 && c == 0);
         }
         T v[4];
 #pragma unroll
@@ -994,7 +1037,7 @@ template <typename T> __device__ __forceinline__ void stage_f6_body(const StageA
         }
     }
     if (row >= a.rows) return;
-    const int s = -(int)((const int16_t*)((const char*)a.sft + OZ2_ZW))[row];
+    const int s = OZ2_ROW_SHIFT(a, row, k0 == 0);   // (k0 == 0: K-step 0, fragment column 0 -- one lane per row over the grid)
     // xs = trunc(x 2^s): exact; a float operand's xs is a float again (24 significant bits), kept in 32 registers and widened pair by pair
     using XS = typename std::conditional<sizeof(T) == 4, float, double>::type;
     XS xs[32];
@@ -1245,7 +1288,7 @@ hipError_t launch_zero(hipStream_t stream, void* p, size_t bytes) {
 #endif
 hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajor, bool conj, size_t rows, size_t k, const void* X,
                           size_t ld, int8_t* lo, size_t part_stride, size_t kp, int16_t* sft0, void* scratch_amax, bool amax_is_zero,
-                          size_t xstride) {
+                          size_t xstride, int16_t* sft0_keep, void* zero_p, size_t zero_bytes) {
     if (rows == 0) return hipSuccess;
     StageArgs a{};
     a.bx = xstride;
@@ -1258,6 +1301,8 @@ hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajo
     a.lo = lo;
     a.part_stride = part_stride;
     a.sft0 = sft0;
+    a.sft0_keep = sft0_keep;
+    if (kmajor && zero_p && zero_bytes) a.zero_p = (unsigned*)zero_p, a.zero_words = (unsigned)(zero_bytes / 4);
     a.amax = scratch_amax;
     a.backend = backend;
     a.conj = conj;
@@ -1302,6 +1347,7 @@ hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajo
         b.rows = nr;
         b.lo = lo + r0 * kp;
         b.sft0 = sft0 + r0;
+        b.sft0_keep = sft0_keep ? sft0_keep + r0 : nullptr;
         b.amax = amax_b;
         e = dispatch_extract_stage(stream, dtype, kmajor, b);
         if (e != hipSuccess) return e;
@@ -1322,6 +1368,13 @@ static StageArgs quantise_args(int backend, int t_begin, int t_end, size_t k, si
     a.plane_stride = o.plane_stride;
     a.part_stride = o.part_stride;
     a.sft = o.sft;
+    if (o.fin_max) {  // accurate mode: shift finalize folded into this launch
+        a.fin_sft0 = o.fin_sft0;
+        a.fin_max = o.fin_max;
+        a.fin_out = o.sft;
+        a.fin_log2P = o.fin_log2P;
+        a.fin_float_max = backend == kFP8 ? 1 : 0;
+    }
     a.backend = backend;
     a.conj = o.conj;
     a.t_begin = t_begin;

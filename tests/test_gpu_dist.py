@@ -255,7 +255,14 @@ def _check_multi_line(d, ranks, rccl):
     assert d["roofline"]["traffic_measured_in_run"] is False
     # round 4: transport self-test before timing, single-GPU phase times and the per-plan time model they feed
     assert d["dist_selftest"].startswith("ok"), d["dist_selftest"]
-    assert set(d["single_gpu_phase_ms"]) == {"bounds", "quantise", "lowprec_gemm", "crt"} and d["single_gpu_phase_ms"]["lowprec_gemm"] > 0
+    assert set(d["single_gpu_phase_ms"]) == {"bounds", "quantise", "lowprec_gemm", "crt", "lowprec_gemm_by_cus"} and d["single_gpu_phase_ms"]["lowprec_gemm"] > 0
+    # round 6: what leaving 8 / 16 CUs to an exchange kernel costs the persistent GEMM, measured on this GPU (the moduli plan's alternative model uses it)
+    by = d["single_gpu_phase_ms"]["lowprec_gemm_by_cus"]
+    assert set(by) == {"256", "248", "240"} and all(v > 0 for v in by.values())
+    if ranks > 1:
+        alt = d["plans"]["moduli"].get("model_ms_if_gemm_leaves_cus")
+        assert alt and set(alt) == {"248", "240"} and all(v > 0 for v in alt.values())
+    assert "exchange_exposed_ms_rank0" in d["plans"]["moduli"]
     for name, p in d["plans"].items():
         assert p["model_ms"] > 0 and abs(sum(p["model_terms_ms"].values()) - p["model_ms"]) < 1e-9, name
 

@@ -902,3 +902,29 @@ def test_crt_panels_knob_is_bit_identical(panels, monkeypatch):
     assert gu.bits_equal(got, ref)
     if not panels.endswith("r"):
         gu.parity_case(A, B, 14, True, alpha=-1.5, beta=0.5, C0=C0)   # every panel wrote its own columns: C_mid is the oracle's, too
+
+
+@pytest.mark.parametrize("ops", ["NN", "TN", "NT", "TT"])
+@pytest.mark.parametrize("backend,dtype,N", [("INT8", np.float64, 14), ("INT8", np.complex64, 7), ("FP8", np.float32, 6), ("FP8", np.complex128, 12)])
+def test_scale_launch_folds_are_bit_identical(backend, dtype, N, ops, monkeypatch):
+    """Round 6: in accurate mode the zero-fill of the maxima / amax scratch rides on the first K-MAJOR extract (which then goes first) and the shift
+    finalize (scaling_accu_real.hpp:6-18) on the quantise launch -- 7 launches instead of 9.  Every operand orientation (both K-major, one, none: the
+    zero-fill keeps its own launch there), both backends incl. the FP6 lane-per-fragment writer: same shifts, planes, C_mid and C as the unfolded sequence
+    (GEMMUL8_SCALE_FOLD=0) and as the oracle."""
+    import gemmul8_amd as g
+    import gpu_util as gu
+    be = getattr(g, backend)
+    opA, opB = ops
+    rng = np.random.default_rng(500 + N)
+    m, n, k = 150, 130, 1100
+    A = rand((m, k) if opA == "N" else (k, m), dtype, rng)
+    B = rand((k, n) if opB == "N" else (n, k), dtype, rng)
+    A[3 if opA == "N" else slice(None), slice(None) if opA == "N" else 3] = 0          # an all-zero row of op(A): amax = 0, f(0) = 0
+    Cf, itf = gu.hip_gemm(A, B, N, backend=be, opA=opA, opB=opB, want_intermediates=True)
+    gu.setknob(monkeypatch, "GEMMUL8_SCALE_FOLD", "0")
+    Cu, itu = gu.hip_gemm(A, B, N, backend=be, opA=opA, opB=opB, want_intermediates=True)
+    gu.setknob(monkeypatch, "GEMMUL8_SCALE_FOLD", None)
+    for key in ("sftA", "sftB", "A_lo", "B_lo", "C_mid"):
+        assert np.array_equal(itf[key], itu[key]), key
+    assert gu.bits_equal(Cf, Cu)
+    gu.parity_case(A, B, N, False, opA=opA, opB=opB, backend=be)
