@@ -112,7 +112,17 @@ struct NoHook {
 // store addresses of the complex combine went to scratch (64-144 bytes), and every reload in between is a vector-memory wait that serialises the
 // epilogue's loads (see the EPI_CPLX branch below).  The waitcnt pass does not see the store; hidden stores only make its vmcnt waits conservative.
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
+#ifndef OZ2_HOOK_SKIP_STORES
+#define OZ2_HOOK_SKIP_STORES 0  // timing probe (lab_hooks.hpp, OZ2_PROBE & 64): the epilogue's arithmetic without its stores
+#endif
+#if defined(OZ2_PRODUCT_BUILD) && OZ2_HOOK_SKIP_STORES
+#error "timing probes (OZ2_HOOK_SKIP_*) compute something else: not allowed in the product build of libgemmul8.so"
+#endif
 template <bool NT> __device__ __forceinline__ void store16_cols(void* ptr, v4u d, int col, int n) {
+#if OZ2_HOOK_SKIP_STORES
+    asm volatile("" ::"v"(ptr), "v"(d), "v"(col), "s"(n));
+    return;
+#endif
     unsigned long long saved;
     if constexpr (NT)
         asm volatile("s_mov_b64 %0, exec\n\tv_cmp_gt_i32_e32 vcc, %1, %2\n\ts_and_b64 exec, exec, vcc\n\tglobal_store_dwordx4 %3, %4, off nt\n\ts_mov_b64 exec, %0"

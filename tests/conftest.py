@@ -9,6 +9,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# GEMMUL8_TEST_SOAK=1: the long forms of the GPU grids (every size of the reference's debug/test.cu sweep, every op pair for the real types in the sub-matrix
+# grid, the extra shapes of the heaviest parity cases).  The default run hits every configuration, kernel path and op pair at least once and stays inside
+# half of the driver's step limit (profiles/r06_gpu_suite_durations.json); the soak forms are for one-off runs.
+SOAK = os.environ.get("GEMMUL8_TEST_SOAK", "0") == "1"
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

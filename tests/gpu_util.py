@@ -64,8 +64,9 @@ def f6_plane_values(buf, rows, rows_img, kp):
             X = panel[:64 * rp].reshape(4, rp, 16)
             Y = panel[64 * rp:].reshape(2, rp, 2, 8)
             frag = np.concatenate([X, np.stack([Y[0, :, 0], Y[0, :, 1], Y[1, :, 0], Y[1, :, 1]])], axis=2)  # [q][r][24]
-            bits = np.unpackbits(frag, axis=2, bitorder="little").reshape(4, rp, 32, 6).astype(np.int16)
-            codes = (bits << np.arange(6, dtype=np.int16)).sum(axis=3)
+            # four 6-bit codes per three bytes, little-endian bit order (c0 = b0[5:0], c1 = b1[3:0] b0[7:6], c2 = b2[1:0] b1[7:4], c3 = b2[7:2])
+            b = frag.reshape(4, rp, 8, 3).astype(np.uint16)
+            codes = np.stack([b[..., 0] & 63, (b[..., 0] >> 6 | b[..., 1] << 2) & 63, (b[..., 1] >> 4 | b[..., 2] << 4) & 63, b[..., 2] >> 2], axis=3).reshape(4, rp, 32).astype(np.int16)
             vals = np.where(codes & 32, -(codes & 31), codes & 31).astype(np.int8)  # [q][r][32]
             vals = vals.transpose(1, 0, 2).reshape(rp, 128)
             r0, r1 = 256 * tb, min(rows, 256 * tb + rp)

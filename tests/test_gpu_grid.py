@@ -9,7 +9,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SIZES = range(32, 48)
+from conftest import SOAK  # noqa: E402
+
+SIZES = range(32, 48) if SOAK else (32, 37, 41, 47)   # debug/test.cu sweeps every size 32..47: GEMMUL8_TEST_SOAK=1 does too (4x the time)
 AB_REAL = [(1.0, 0.0), (1.0, 1.0), (-1.0, 0.0), (-1.0, 1.0), (-1.5, 1.5)]
 AB_CPLX = [(1.0, 0.0), (1.0, 1.0), (-1.0, 0.0), (-1.0, 1.0), (-1.5 + 1.2j, 1.5 + 1.2j)]
 REAL_OPS = [("N", "N"), ("T", "N"), ("N", "T"), ("T", "T")]
@@ -66,18 +68,18 @@ def run_grid(dtype, opA, opB, backend_name, n_list):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_reference_grid_real_int8(dtype, opA, opB):
     n_list = range(2, 21) if dtype == np.float64 else range(2, 14)
-    assert run_grid(dtype, opA, opB, "INT8", n_list) == 16 * len(n_list) * 2
+    assert run_grid(dtype, opA, opB, "INT8", n_list) == len(SIZES) * len(n_list) * 2
 
 
 @pytest.mark.parametrize("opA,opB", CPLX_OPS)
 @pytest.mark.parametrize("dtype", [np.complex128, np.complex64])
 def test_reference_grid_complex_int8(dtype, opA, opB):
     n_list = range(2, 21) if dtype == np.complex128 else range(2, 14)
-    assert run_grid(dtype, opA, opB, "INT8", n_list) == 16 * len(n_list) * 2
+    assert run_grid(dtype, opA, opB, "INT8", n_list) == len(SIZES) * len(n_list) * 2
 
 
 @pytest.mark.parametrize("dtype,opA,opB", [(np.float64, "N", "N"), (np.float32, "T", "T"), (np.complex128, "C", "N"), (np.complex64, "N", "C")])
 def test_reference_grid_fp8(dtype, opA, opB):
     """the same grid with -DUseFP8 (debug/test.cu:29-33): one op pair per type"""
     n_list = range(2, 21) if dtype in (np.float64, np.complex128) else range(2, 14)
-    assert run_grid(dtype, opA, opB, "FP8", n_list) == 16 * len(n_list) * 2
+    assert run_grid(dtype, opA, opB, "FP8", n_list) == len(SIZES) * len(n_list) * 2

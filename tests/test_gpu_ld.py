@@ -41,7 +41,10 @@ def stored(rows, cols, op):
 def test_submatrix_views_bit_exact(variant, dtype, ops, monkeypatch):
     import gemmul8_amd as g
     import gpu_util as gu
+    from conftest import SOAK
     opA, opB = ops
+    if not SOAK and dtype.startswith("float") and "C" in ops and ops != "CC":
+        pytest.skip("real types: op C is op T (one C/C case kept per type and backend); GEMMUL8_TEST_SOAK=1 runs all nine")
     dt = np.dtype(dtype)
     backend = g.INT8 if variant == "int8" else g.FP8
     if variant != "int8":

@@ -114,7 +114,8 @@ def test_parity_complex_ops_axpby(opA, opB):
 def test_parity_complex_shapes():
     import gpu_util as gu
     rng = np.random.default_rng(99)
-    for (m, n, k) in [(256, 256, 256), (300, 520, 700), (1, 1, 1), (513, 255, 1025)]:
+    from conftest import SOAK
+    for (m, n, k) in [(256, 256, 256), (300, 520, 700), (1, 1, 1)] + ([(513, 255, 1025)] if SOAK else []):   # (the largest: 18 s of scalar oracle; real types run it always)
         A, B = rand((m, k), np.complex128, rng), rand((k, n), np.complex128, rng)
         gu.parity_case(A, B, 20, False)
         gu.parity_case(A, B, 9, True)
@@ -316,12 +317,15 @@ def test_bound_gemm_both_tile_sizes(dtype, tile, monkeypatch):
     with ragged tile edges, several tiles per dimension, K-major and strided operands, and the complex K-concatenated products."""
     import gemmul8_amd as g
     import gpu_util as gu
+    from conftest import SOAK
     gu.setknob(monkeypatch, "GEMMUL8_BOUND_TILE", tile)
     rng = np.random.default_rng(11)
     for (m, n, k), (opA, opB) in [((37, 41, 300), ("N", "N")), ((300, 520, 700), ("T", "N")), ((513, 255, 1025), ("N", "T")),
                                   ((129, 385, 520), ("T", "T")), ((1, 1, 1), ("N", "N"))]:
         if np.dtype(dtype).kind == "c" and opA == "T":
             opA = "C"
+        if np.dtype(dtype).kind == "c" and m == 513 and not SOAK:
+            continue
         A = rand((m, k) if opA == "N" else (k, m), dtype, rng, phi=2.0)
         B = rand((k, n) if opB == "N" else (n, k), dtype, rng, phi=2.0)
         gu.bounds_case(A, B, 14, opA=opA, opB=opB, backend=g.INT8)

@@ -5,6 +5,7 @@
 //   4   the LDS-DMA is issued during a workgroup's first tile only (what the L2 -> LDS operand path costs: DESIGN.md 3.1)
 //   8   no epilogue, the accumulators stay live
 //   16  operands come from the first 8 K-steps of a panel only (every fetch an L2 hit: what the L2 misses cost)
+//   64  the epilogue without its stores (what the store path costs at short k)
 //   32  dose-response of the operand path: after a workgroup's first tile the LDS-DMA of every OZ2_DMA_SKIP-th K-step is left out
 //       (OZ2_DMA_SKIP = 6: -16.7 % of the L2 -> LDS bytes per MAC, what a 384 x 256 CU tile would save; 2: -50 %)
 // OZ2_KSTAG=<1..4> staggers the K-step a workgroup starts from (1: XCD x starts at x KT1 / 8; 2: plus (CU & 3) K-steps; 3: (CU & 7)
@@ -27,6 +28,9 @@
 #endif
 #if OZ2_PROBE & 8
 #define OZ2_HOOK_SKIP_EPILOGUE 1
+#endif
+#if OZ2_PROBE & 64
+#define OZ2_HOOK_SKIP_STORES 1  // round 6: the residue epilogue's arithmetic, transposes and address work, but no global_store
 #endif
 #if OZ2_PROBE & 16
 #define OZ2_HOOK_KSTEP(kin) ((kin) & 7)
