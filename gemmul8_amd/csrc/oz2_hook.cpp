@@ -466,12 +466,12 @@ struct FloorModel {
     double e[6];  // ms: 1, (m+n)k, N(m+n)k, mn, N mn, N mnk
     double n[3];  // ms: 1, mn, mnk
 };
-// generated by tools/fit_floor.py from profiles/sweeps/r04b_floor_scan_*.csv (the final round-4 kernels: emulation is 3-8 % faster at k <= 2048 than at the round-3 fit)
+// generated by tools/fit_floor.py from profiles/sweeps/r06_floor_scan_*.csv (the round-6 kernels: accurate mode two launches shorter, short-k epilogue +3-5 %; round 4's fit: r04b_floor_scan_*.csv)
 static const FloorModel kFloor[4][2] = {  // [S, D, C, Z][accurate, fast]
-    {{{0.05902, 1.84e-09, 4.091e-10, 1.833e-09, 3.493e-10, 6.125e-13}, {0.02192, 4.685e-10, 1.377e-11}}, {{0.04339, 9.451e-10, 4.161e-10, 1.02e-09, 3.69e-10, 5.764e-13}, {0.02192, 4.685e-10, 1.377e-11}}},
-    {{{0.05264, 3.467e-09, 4.163e-10, 1.434e-09, 4.826e-10, 5.827e-13}, {0.01186, 6.009e-10, 2.791e-11}}, {{0.03959, 1.777e-09, 4.192e-10, 6e-10, 4.747e-10, 5.815e-13}, {0.01186, 6.009e-10, 2.791e-11}}},
-    {{{0.07382, 6.651e-09, 1.168e-09, 3.558e-09, 1.815e-09, 1.753e-12}, {0.01502, 3.243e-10, 5.563e-11}}, {{0.05627, 3.32e-09, 1.161e-09, 2.038e-09, 1.791e-09, 1.716e-12}, {0.01502, 3.243e-10, 5.563e-11}}},
-    {{{0.08236, 1.225e-08, 1.263e-09, 2.257e-09, 2.11e-09, 1.717e-12}, {0.01278, 2.34e-10, 1.085e-10}}, {{0.06348, 7.741e-09, 1.238e-09, 1.24e-09, 2.148e-09, 1.635e-12}, {0.01278, 2.34e-10, 1.085e-10}}},
+    {{{0.0528, 2.43e-09, 3.744e-10, 1.811e-09, 3.499e-10, 5.918e-13}, {0.01988, 5.614e-10, 1.318e-11}}, {{0.04183, 1.137e-09, 3.872e-10, 1.045e-09, 3.596e-10, 5.634e-13}, {0.01988, 5.614e-10, 1.318e-11}}},
+    {{{0.04782, 3.915e-09, 3.807e-10, 1.729e-09, 4.399e-10, 5.737e-13}, {0.009298, 7.301e-10, 2.73e-11}}, {{0.03784, 1.884e-09, 3.954e-10, 7.854e-10, 4.495e-10, 5.699e-13}, {0.009298, 7.301e-10, 2.73e-11}}},
+    {{{0.06839, 7.064e-09, 1.107e-09, 3.484e-09, 1.75e-09, 1.696e-12}, {0.01251, 4.119e-10, 5.43e-11}}, {{0.05451, 3.132e-09, 1.153e-09, 1.843e-09, 1.757e-09, 1.686e-12}, {0.01251, 4.119e-10, 5.43e-11}}},
+    {{{0.07595, 1.291e-08, 1.186e-09, 2.128e-09, 2.04e-09, 1.747e-12}, {0.009309, 2.677e-10, 1.067e-10}}, {{0.0617, 8.163e-09, 1.162e-09, 1.052e-09, 2.083e-09, 1.678e-12}, {0.009309, 2.677e-10, 1.067e-10}}},
 };
 static bool floor_model_declines(int dtype, double m, double n, double k, unsigned N, bool fast, int backend, double batch) {
     const FloorModel& fm = kFloor[dtype][fast ? 1 : 0];

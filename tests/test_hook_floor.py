@@ -1,8 +1,8 @@
 """The hook's opt-in automatic floor (oz2_hook.cpp below_floor, exported as gemmul8_hook_would_emulate): with GEMMUL8_MIN_FLOPS=auto a
 hooked call is emulated only where the fitted cost model predicts a win over the native routine; UNSET (the default) every selected
 call is emulated, as the reference's hook does.  Checked here, without a GPU, against the measurements the model was fitted to
-(profiles/sweeps/r04b_floor_scan_*.csv, tools/floor_scan.py on one MI355X with the final round-4 kernels; rounds 3's scans of two other boxes
-with the round-3 kernels serve as cross-validation)."""
+(profiles/sweeps/r06_floor_scan_*.csv, tools/floor_scan.py on one MI355X with the round-6 kernels; round 4's scan and round 3's scans of two
+other boxes serve as cross-validation)."""
 import csv
 import os
 
@@ -86,6 +86,25 @@ def test_bad_arguments():
 
 
 @pytest.mark.parametrize("dt", ["d", "s", "z", "c"])
+def test_rule_on_the_round4_scan(dt):
+    """The round-4 scan (another box, round-4 kernels: accurate mode two launches longer) as cross-validation of the round-6 fit."""
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "sweeps", f"r04b_floor_scan_{dt}.csv"))))
+    t_rule = t_best = t_native = 0.0
+    worst = 0.0
+    for r in rows:
+        te, tn = float(r["emulated_ms"]), float(r["native_ms"])
+        em = would(dt, int(r["m"]), int(r["n"]), int(r["k"]), int(r["N"]), int(r["fast"]))
+        t_rule += te if em else tn
+        t_best += min(te, tn)
+        t_native += tn
+        if em:
+            worst = max(worst, te / tn)
+    assert worst <= 1.45, worst
+    assert t_rule <= 1.15 * t_best, (t_rule, t_best)
+    assert t_rule <= 0.90 * t_native, (t_rule, t_native)
+
+
+@pytest.mark.parametrize("dt", ["d", "s", "z", "c"])
 def test_rule_on_a_second_box(dt):
     """Cross-validation: the same scan on ANOTHER MI355X box with the round-3 binaries (r03_floor_scan2_*.csv; the model is fitted to
     r04b_floor_scan_*.csv: other box AND 3-8 % slower emulation at small k).  The rule must hold up on data it was not fitted to: summed time within 15 % of always picking the
@@ -112,7 +131,7 @@ def test_rule_on_a_second_box(dt):
 def test_rule_against_the_measurements(dt):
     """On every measured shape the rule emulates, the emulation must not have lost by more than a few per cent (one known outlier:
     SGEMM 1024^2 x 16384 with 5 moduli, 1.19x); and the rule must keep most of the time the better choice would have saved."""
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "sweeps", f"r04b_floor_scan_{dt}.csv"))))
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "sweeps", f"r06_floor_scan_{dt}.csv"))))   # what the model is fitted to since round 6
     assert len(rows) >= 150
     t_rule = t_best = t_native = 0.0
     worst = 0.0
