@@ -37,7 +37,7 @@ EXPORTS = ["gemmul8_version", "gemmul8_work_size", "gemmul8_gemm", "gemmul8_get_
            "gemmul8_scale_bounds", "gemmul8_scale_finish", "gemmul8_lowprec_gemm", "gemmul8_crt", "gemmul8_set_fp8_bound_mode",
            "gemmul8_hook_would_emulate", "gemmul8_reload_knobs", "gemmul8_abi_version", "gemmul8_layout_bytes"]
 
-ABI_VERSION = 6  # GEMMUL8_ABI_VERSION of include/gemmul8_c.h this module's struct mirrors were written against
+ABI_VERSION = 7  # GEMMUL8_ABI_VERSION of include/gemmul8_c.h this module's struct mirrors were written against
 
 
 def _bind_hip_runtime():
@@ -124,6 +124,8 @@ def bind(L):
     L.gemmul8_hook_would_emulate.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint, C.c_int, C.c_size_t]
     L.gemmul8_reload_knobs.restype = None
     L.gemmul8_reload_knobs.argtypes = []
+    L.gemmul8_add_f64.restype = C.c_int
+    L.gemmul8_add_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.gemmul8_add_row_bias.restype = C.c_int
     L.gemmul8_add_row_bias.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     return L

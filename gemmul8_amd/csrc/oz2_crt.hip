@@ -636,6 +636,24 @@ template <typename U> __global__ void __launch_bounds__(256) row_bias_kernel(U* 
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < m) D[(size_t)blockIdx.y * ldd + i] += bias[i];
 }
+// dst[i] += src[i] on doubles: the running sum of the reduced FP64 partial planes of the pipelined fp64sum plan (oz2_dist.cpp)
+__global__ void __launch_bounds__(256) add_f64_kernel(double* dst, const double* src, size_t count) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i + 1 < count) {
+        double2 d = *(double2*)(dst + i);
+        const double2 s = *(const double2*)(src + i);
+        d.x += s.x, d.y += s.y;
+        *(double2*)(dst + i) = d;
+    } else if (i < count) {
+        dst[i] += src[i];
+    }
+}
+hipError_t launch_add_f64(hipStream_t stream, double* dst, const double* src, size_t count) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(add_f64_kernel, dim3((unsigned)((count + 511) / 512)), dim3(256), 0, stream, dst, src, count);
+    return hipGetLastError();
+}
+
 hipError_t launch_row_bias(hipStream_t stream, int dtype, size_t m, size_t n, void* D, size_t ldd, const void* bias) {
     if (m == 0 || n == 0) return hipSuccess;
     if (n > 65535) return hipErrorInvalidValue;

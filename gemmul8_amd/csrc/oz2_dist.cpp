@@ -339,7 +339,7 @@ int hip_copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t 
     return width && height ? (int)hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, (hipStream_t)stream) : 0;
 }
 const gemmul8_dist_engine kHipEngine = {hip_alloc,           hip_release,          hip_zero,    hip_copy,           hip_copy2d,        gemmul8_scale_bounds,
-                                        gemmul8_scale_finish, gemmul8_lowprec_gemm, gemmul8_crt, gemmul8_crt_partial, gemmul8_crt_finish};
+                                        gemmul8_scale_finish, gemmul8_lowprec_gemm, gemmul8_crt, gemmul8_crt_partial, gemmul8_crt_finish, gemmul8_add_f64};
 
 // ------------------------------------------------------------------------------------------------ partition arithmetic
 struct Range {
@@ -391,6 +391,13 @@ struct gemmul8_dist_plan {
     char* recv = nullptr;    // moduli: [N][cols][mp] residue blocks of this rank's columns
     double* part = nullptr;  // fp64sum: [world][hi | lo][cw][mp] partial sums
     double* red = nullptr;   //          [hi | lo][cw][mp] reduced block of this rank
+    // fp64sum in moduli groups (GEMMUL8_DIST_FP64_GROUPS = 2 .. 8, round 6): the rank's planes are multiplied group by group; the partial sums of group j
+    // go through their own reduce-scatter on the exchange stream while group j + 1 multiplies, and the reduced blocks are added up (hi parts: exact
+    // integers, any order; lo parts: one more rounding per group than the single collective -- the same kind of difference the plan already has against
+    // one GPU).  Twice the partial-sum buffers, (groups - 1) more passes over the reduced block; what it buys is xGMI time behind matrix time.
+    int fgroups = 1;
+    double* part2 = nullptr;  // second partial buffer (groups alternate)
+    double* red2 = nullptr;   // reduce-scatter target of groups >= 1 before it is added to `red`
     size_t cw = 0, blk = 0;
     void *ev_begin = nullptr, *ev_end = nullptr;  // optional hipEvent_t pair recorded around the low-precision GEMM launch
     void* ev_x[4] = {nullptr, nullptr, nullptr, nullptr};  // optional: around the bounds all-reduce / around the bulk exchange
@@ -564,8 +571,15 @@ int gemmul8_dist_create(const gemmul8_comm* comm, const gemmul8_dist_engine* eng
         P->part = (double*)P->alloc((size_t)world * P->blk * 8);
         P->red = world > 1 ? (double*)P->alloc(P->blk * 8) : nullptr;
         ok = P->part && (world == 1 || P->red);
+        if (const char* e = getenv("GEMMUL8_DIST_FP64_GROUPS"); ok && e && *e && world > 1 && P->eng.add_f64)
+            P->fgroups = std::max(1, std::min(8, atoi(e)));  // (a rank with fewer planes than groups runs empty groups: the number of collectives is what must agree)
+        if (ok && P->fgroups > 1) {
+            P->part2 = (double*)P->alloc((size_t)world * P->blk * 8);
+            P->red2 = (double*)P->alloc(P->blk * 8);
+            ok = P->part2 && P->red2;
+        }
     }
-    if (ok && kind == GEMMUL8_DIST_MODULI && P->hip_engine && world > 1 && P->groups > 1) {
+    if (ok && ((kind == GEMMUL8_DIST_MODULI && P->groups > 1) || (kind == GEMMUL8_DIST_MODULI_FP64SUM && P->fgroups > 1)) && P->hip_engine && world > 1) {
         // two-stream state of the pipelined exchange: all of it here or none of it (a partial set is released by gemmul8_dist_destroy below)
         ok = hipStreamCreateWithFlags(&P->xstream, hipStreamNonBlocking) == hipSuccess;
         for (int i = 0; ok && i < 9; ++i) ok = hipEventCreateWithFlags(&P->xev[i], hipEventDisableTiming) == hipSuccess;
@@ -581,7 +595,7 @@ int gemmul8_dist_create(const gemmul8_comm* comm, const gemmul8_dist_engine* eng
 
 void gemmul8_dist_destroy(gemmul8_dist_plan* P) {
     if (!P) return;
-    for (void* p : {(void*)P->work, (void*)P->mx, (void*)P->recv, (void*)P->part, (void*)P->red, (void*)P->stage_send, (void*)P->stage_recv})
+    for (void* p : {(void*)P->work, (void*)P->mx, (void*)P->recv, (void*)P->part, (void*)P->red, (void*)P->part2, (void*)P->red2, (void*)P->stage_send, (void*)P->stage_recv})
         if (p) P->eng.release(p);
     if (P->xstream) (void)hipStreamDestroy(P->xstream);
     for (hipEvent_t e : P->xev)
@@ -776,16 +790,68 @@ int gemmul8_dist_gemm(gemmul8_dist_plan* P, void* stream, const void* alpha, con
         return E.crt(stream, P->dtype, P->backend, N, P->m, ncols, P->recv, mp, ncols * mp, L->sftA, L->sftB + P->cols.b, alpha, beta, Cs, ldc);
     }
 
+    const size_t half = P->cw * mp * P->comps;  // doubles per (hi | lo) plane of one rank's column block
+    if (!P->part_clean) {
+        OZ2_RC(E.zero(P->part, (size_t)world * P->blk * 8, stream));
+        if (P->part2) OZ2_RC(E.zero(P->part2, (size_t)world * P->blk * 8, stream));
+        P->part_clean = true;
+    }
+    if (P->fgroups > 1) {
+        // ---- FP64 partial sums in moduli groups: GEMMs(j) -> partial sums(j) on the caller's stream; reduce-scatter(j) [+ add into the running block]
+        // on the exchange stream beside GEMMs(j + 1).  The partial buffers alternate; group j + 2 may only overwrite a buffer once reduce-scatter(j) has
+        // read it (xev[4 + (j & 1)] recorded on the exchange stream).  Every rank cuts its own planes into the same NUMBER of groups (a rank
+        // with fewer planes than groups contributes zeros in its empty groups: the collective count is what must agree).
+        const int NG = P->fgroups;
+        const bool two_streams = P->hip_engine && P->xstream != nullptr;
+        void* xs = two_streams ? (void*)P->xstream : stream;
+        if (!P->groups_agreed) {  // the group count is a collective property (see the moduli plan): one small all-reduce on the first call
+            int32_t v[2] = {NG, -NG};
+            if (P->hip_engine) {
+                if (hipMemcpyAsync(P->red2, v, sizeof v, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) return GEMMUL8_E_INTERNAL;
+            } else {
+                std::memcpy(P->red2, v, sizeof v);
+            }
+            OZ2_RC(X.allreduce_max_i32(X.ctx, P->red2, 2, stream));
+            if (P->hip_engine) {
+                if (hipMemcpyAsync(v, P->red2, sizeof v, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+                    return GEMMUL8_E_INTERNAL;
+            } else {
+                std::memcpy(v, P->red2, sizeof v);
+            }
+            if (v[0] != -v[1]) {
+                std::fprintf(stderr, "[GEMMUL8 DIST] rank %d: the fp64sum plan's group count differs between ranks (here %d, elsewhere %d ... %d): export the same "
+                                     "GEMMUL8_DIST_FP64_GROUPS to every rank\n", rank, NG, -v[1], v[0]);
+                return GEMMUL8_E_ARG;
+            }
+            P->groups_agreed = true;
+        }
+        if (P->ev_begin && P->hip_engine) (void)hipEventRecord((hipEvent_t)P->ev_begin, (hipStream_t)stream);
+        for (int j = 0; j < NG; ++j) {
+            const Range gj = split_range(P->mods.size(), NG, j);
+            const unsigned a = t0 + (unsigned)gj.b, b = t0 + (unsigned)gj.e;
+            double* pj = (j & 1) ? P->part2 : P->part;
+            if (b > a) OZ2_RC(E.lowprec_gemm(stream, P->dtype, P->backend, P->m, P->n, P->k, N, a, b, L));
+            if (j == NG - 1 && P->ev_end && P->hip_engine) (void)hipEventRecord((hipEvent_t)P->ev_end, (hipStream_t)stream);
+            if (two_streams && j >= 2 && hipStreamWaitEvent((hipStream_t)stream, P->xev[4 + (j & 1)], 0) != hipSuccess) return GEMMUL8_E_INTERNAL;  // buffer free again
+            OZ2_RC(E.crt_partial(stream, P->dtype, P->backend, N, a, b, P->m, P->n, Cmid + (size_t)a * L->sizeC * mid, mp, L->sizeC, pj, pj + half, mp, P->cw, P->blk));
+            if (two_streams && (hipEventRecord(P->xev[j & 3], (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(P->xstream, P->xev[j & 3], 0) != hipSuccess))
+                return GEMMUL8_E_INTERNAL;
+            if (j == 0) P->mark(2, xs);
+            OZ2_RC(X.reduce_scatter_sum_f64(X.ctx, pj, j == 0 ? P->red : P->red2, P->blk, xs));
+            if (two_streams && hipEventRecord(P->xev[4 + (j & 1)], P->xstream) != hipSuccess) return GEMMUL8_E_INTERNAL;
+            if (j > 0) OZ2_RC(E.add_f64(xs, P->red, P->red2, P->blk));
+            if (j == NG - 1) P->mark(3, xs);
+        }
+        if (two_streams && (hipEventRecord(P->xev[8], P->xstream) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, P->xev[8], 0) != hipSuccess)) return GEMMUL8_E_INTERNAL;
+        if (!ncols) return GEMMUL8_OK;
+        return E.crt_finish(stream, P->dtype, P->backend, N, P->m, ncols, P->red, P->red + half, mp, L->sftA, L->sftB + P->cols.b, alpha, beta, Cs, ldc);
+    }
+
     if (P->ev_begin && P->hip_engine) (void)hipEventRecord((hipEvent_t)P->ev_begin, (hipStream_t)stream);
     OZ2_RC(E.lowprec_gemm(stream, P->dtype, P->backend, P->m, P->n, P->k, N, t0, t1, L));
     if (P->ev_end && P->hip_engine) (void)hipEventRecord((hipEvent_t)P->ev_end, (hipStream_t)stream);
 
     // ---- FP64 partial sums + reduce-scatter(sum)
-    const size_t half = P->cw * mp * P->comps;  // doubles per (hi | lo) plane of one rank's column block
-    if (!P->part_clean) {
-        OZ2_RC(E.zero(P->part, (size_t)world * P->blk * 8, stream));
-        P->part_clean = true;
-    }
     OZ2_RC(E.crt_partial(stream, P->dtype, P->backend, N, t0, t1, P->m, P->n, Cmid + (size_t)t0 * L->sizeC * mid, mp, L->sizeC, P->part,
                          P->part + half, mp, P->cw, P->blk));
     const double* red = P->part;

@@ -599,6 +599,12 @@ int gemmul8_gemm(void* stream_, int dtype, int backend, int op_A, int op_B, size
     return GEMMUL8_OK;
 }
 
+int gemmul8_add_f64(void* stream_, double* dst, const double* src, size_t count) {
+    if (!dst || !src || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) return GEMMUL8_E_ARG;
+    OZ2_HIP(launch_add_f64((hipStream_t)stream_, dst, src, count));
+    return GEMMUL8_OK;
+}
+
 int gemmul8_add_row_bias(void* stream_, int dtype, size_t m, size_t n, void* D, size_t ldd, const void* bias) {
     if (!D || !bias) return GEMMUL8_E_ARG;
     if (dtype != kF32 && dtype != kF64) return GEMMUL8_E_UNSUPPORTED;

@@ -103,6 +103,7 @@ hipError_t launch_crt(hipStream_t stream, int dtype, int backend, unsigned N, si
                       bool scalars_on_device, void* C, size_t ldc);
 
 hipError_t launch_row_bias(hipStream_t stream, int dtype, size_t m, size_t n, void* D, size_t ldd, const void* bias);
+hipError_t launch_add_f64(hipStream_t stream, double* dst, const double* src, size_t count);  // dst += src (16-byte aligned arrays)
 
 // multi-GPU exchange variant (A): per-rank FP64 partial CRT sums + the finish on the summed partials (oz2_crt.hip)
 hipError_t launch_crt_partial(hipStream_t stream, int dtype, int backend, unsigned N, unsigned t_begin, unsigned t_end, size_t m, size_t n,

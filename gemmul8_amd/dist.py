@@ -59,6 +59,7 @@ ENGINE_FIELDS = [
                                 C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t)),
     ("crt_finish", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)),
+    ("add_f64", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)),   # ABI 7: dst += src on doubles (pipelined fp64sum)
 ]
 
 
@@ -476,8 +477,10 @@ class DistGemm:
         if self.kind == MODULI:
             return (f"moduli sharded x{self.comm.world} ({self.my_planes} of {self.N} moduli on this rank; grouped point-to-point exchange of INT8 "
                     f"residue blocks over RCCL, column-block CRT); A, B replicated on every rank")
+        fg = os.environ.get("GEMMUL8_DIST_FP64_GROUPS", "")
+        how = f"ncclReduceScatter(sum) per moduli group, {fg} groups, behind the next group's GEMMs" if fg.isdigit() and int(fg) > 1 and self.comm.world > 1 else "ncclReduceScatter(sum)"
         return (f"moduli sharded x{self.comm.world} ({self.my_planes} of {self.N} moduli on this rank; FP64 partial CRT sums, "
-                f"ncclReduceScatter(sum)); A, B replicated on every rank")
+                f"{how}); A, B replicated on every rank")
 
 
 def make_plan(comm, dtype_code, backend, m, n, k, N, mode=None, **kw):

@@ -86,7 +86,7 @@ GEMMUL8_API int gemmul8_get_layout(int dtype, int backend, size_t m, size_t n, s
  * (the struct grew by lo_format in version 5) would be overrun.  GEMMUL8_ABI_VERSION is bumped whenever a struct of this header grows or a
  * signature changes; a binding checks gemmul8_abi_version() == GEMMUL8_ABI_VERSION (C / C++) or gemmul8_layout_bytes() against the size of
  * its own mirror of the struct (ctypes: gemmul8_amd/__init__.py does) before it calls anything else. */
-#define GEMMUL8_ABI_VERSION 6
+#define GEMMUL8_ABI_VERSION 7   /* 7: gemmul8_add_f64; gemmul8_dist_engine grew by add_f64 */
 GEMMUL8_API int gemmul8_abi_version(void);
 GEMMUL8_API size_t gemmul8_layout_bytes(void);
 
@@ -155,6 +155,10 @@ GEMMUL8_API int gemmul8_crt_partial(void *stream, int dtype, int backend, unsign
 GEMMUL8_API int gemmul8_crt_finish(void *stream, int dtype, int backend, unsigned num_moduli, size_t m, size_t n, const double *in_hi,
                        const double *in_lo, size_t ld_in, const int16_t *sftA, const int16_t *sftB, const void *alpha,
                        const void *beta, void *C, size_t ldc);
+
+/* dst[i] += src[i], i < count, on FP64 arrays (16-byte aligned): the running sum of reduced partial planes when the fp64sum plan of
+ * include/gemmul8_dist.h exchanges its partial sums in moduli groups (GEMMUL8_DIST_FP64_GROUPS).  No counterpart in the reference. */
+GEMMUL8_API int gemmul8_add_f64(void *stream, double *dst, const double *src, size_t count);
 
 /* FP8 backend, accurate mode: inflation of the bound GEMM's sums before the row / column maxima are taken.
  *   0 (default)  ku = 7 * 2^-13 + 4 (k+1) * 2^-24: covers how gfx950's v_mfma_scale_f32_16x16x128_f8f6f4 accumulates (products aligned

@@ -93,6 +93,9 @@ typedef struct gemmul8_dist_engine {
     int (*crt_finish)(void *stream, int dtype, int backend, unsigned num_moduli, size_t m, size_t n, const double *in_hi,
                       const double *in_lo, size_t ld_in, const int16_t *sftA, const int16_t *sftB, const void *alpha, const void *beta,
                       void *C, size_t ldc);
+    /* ABI version 7: dst += src on doubles (gemmul8_add_f64).  May be NULL: the fp64sum plan then exchanges its partial sums in one
+     * collective whatever GEMMUL8_DIST_FP64_GROUPS says. */
+    int (*add_f64)(void *stream, double *dst, const double *src, size_t count);
 } gemmul8_dist_engine;
 
 typedef struct gemmul8_dist_plan gemmul8_dist_plan;

@@ -208,6 +208,12 @@ class OracleEngine:
             print("OracleEngine.crt_partial:", repr(e))
             return 1
 
+    def _add_f64(self, stream, dst, src, count):
+        self.calls.append(("add_f64", count))
+        d = _view(dst, 8 * count).view(np.float64)
+        d += _view(src, 8 * count).view(np.float64)
+        return 0
+
     def _crt_finish(self, stream, dtype, backend, N, m, n, in_hi, in_lo, ld_in, sftA, sftB, alpha, beta, Cp, ldc):
         try:
             self.calls.append(("crt_finish", m, n))

@@ -93,7 +93,7 @@ def _worker(rank, world, port, plan, N, fast, m, n, k, typ, opA, opB, grid_rows,
                                              ol._p(ref), m, 0, world, ol._p(bounds))
                 single = ol.gemm(A, B, N, fastmode=fast, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0)
                 q.put(("fp64sum", full.tobytes() == np.ascontiguousarray(ref).tobytes(), int((full != single).sum()), full.size,
-                       float(np.max(np.abs(full - single) / np.maximum(np.abs(single), 1e-300)))))
+                       float(np.max(np.abs(full - single) / np.maximum(np.abs(single), 1e-300))), sum(c[0] == "add_f64" for c in calls)))
             else:
                 ref = ol.gemm(A, B, N, fastmode=fast, opA=opA, opB=opB, alpha=alpha, beta=beta, C0=C0)
                 q.put((plan, full.tobytes() == np.ascontiguousarray(ref).tobytes(), calls))
@@ -187,7 +187,8 @@ def test_fp64sum_plan_world2_matches_grouped_oracle(N, fast, typ):
     possible order, so the result must equal the oracle's rank-grouped accumulation bit for bit; against the single-GPU result it
     may differ in the last bits of a few elements (the rounded lo chain -- or, for float outputs, the single chain -- is grouped
     differently): counted and bounded here, measured at full size on the GPU (tests/test_gpu_dist.py)."""
-    _, same, nbad, total, rel = _run(2, "fp64sum", N, fast, 19, 11, 37, typ=typ)
+    _, same, nbad, total, rel, nadd = _run(2, "fp64sum", N, fast, 19, 11, 37, typ=typ)
+    assert nadd == 0
     assert same, "FP64-sum plan differs from the oracle's grouped accumulation"
     eps = 2.0 ** -22 if typ == "s" else 2.0 ** -50
     assert rel <= eps, (nbad, total, rel)
@@ -196,7 +197,7 @@ def test_fp64sum_plan_world2_matches_grouped_oracle(N, fast, typ):
 def test_fp64sum_plan_world4_close_to_single():
     """Four ranks: the transport's summation order is not specified; integer intermediates are identical, the final values agree
     with the single-process result to the last bits."""
-    _, same, nbad, total, rel = _run(4, "fp64sum", 15, False, 19, 11, 37)
+    _, same, nbad, total, rel, _ = _run(4, "fp64sum", 15, False, 19, 11, 37)
     assert rel <= 2.0 ** -50, (nbad, total, rel)
 
 
@@ -365,3 +366,18 @@ def test_moduli_plan_refuses_ranks_that_disagree_on_the_group_count():
     got = sorted(q.get(timeout=10) for _ in range(2))
     assert codes == [0, 0], codes
     assert all("failed with status" in msg for _, msg in got), got
+
+
+@pytest.mark.parametrize("world,groups,N,typ", [(2, 2, 14, "d"), (2, 3, 15, "z"), (4, 2, 15, "d"), (3, 8, 13, "d"), (8, 2, 14, "d"), (2, 2, 12, "s")])
+def test_fp64sum_plan_in_moduli_groups(world, groups, N, typ, monkeypatch):
+    """GEMMUL8_DIST_FP64_GROUPS (round 6): the rank's planes are multiplied group by group, each group's FP64 partial sums go through their own
+    reduce-scatter (beside the next group's GEMMs on the HIP engine) and the reduced blocks are added up.  Integer intermediates are those of the
+    single collective; the hi parts add exactly in any order, the lo parts see one more rounding per group: the final values agree with the
+    single-process result to the last bits (same bound as the one-collective plan), with ranks that own fewer planes than there are groups
+    (world 8, N = 14: 2 or 1 planes; world 3 with 8 groups) contributing zeros in their empty groups."""
+    monkeypatch.setenv("GEMMUL8_DIST_FP64_GROUPS", str(groups))
+    _, same, nbad, total, rel, nadd = _run(world, "fp64sum", N, False, 19, 11, 37, typ=typ)
+    assert nadd == groups - 1, nadd     # the grouped schedule really ran: one running-sum pass per group after the first
+    eps = 2.0 ** -22 if typ == "s" else 2.0 ** -50
+    assert rel <= eps, (nbad, total, rel)
+    assert nbad <= max(1, 0.01 * total), (nbad, total)

@@ -407,3 +407,15 @@ def test_torch_nccl_transport_world1():
     assert _start_and_reap([p], 300) == [0]
     ok, msg = q.get(timeout=10)
     assert ok, msg
+
+
+@pytest.mark.parametrize("typ,N,groups", [("d", 14, 2), ("z", 15, 3), ("d", 13, 8)])
+def test_fp64sum_in_moduli_groups_two_ranks_one_gpu(typ, N, groups, monkeypatch):
+    """GEMMUL8_DIST_FP64_GROUPS on the HIP engine (round 6): group-wise GEMMs -> FP64 partial sums on the caller's stream, reduce-scatter + running sum
+    (gemmul8_add_f64) on the plan's exchange stream behind events, two alternating partial buffers.  Same bound against the single-GPU result as the
+    one-collective plan; 8 groups of 6-7 planes: empty groups contribute zeros."""
+    monkeypatch.setenv("GEMMUL8_DIST_FP64_GROUPS", str(groups))
+    nbad, total, rel = _run("fp64sum", 0, N, False, 300, 515, 1000, typ=typ)
+    print(f"fp64sum in {groups} groups, {typ} N={N}: {nbad} of {total} values differ from the single-GPU result, max rel {rel:.3e}")
+    assert rel <= 2.0 ** -50, (nbad, total, rel)
+    assert nbad <= 0.5 * total
