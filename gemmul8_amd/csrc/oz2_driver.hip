@@ -204,18 +204,20 @@ int gemmul8_get_layout(int dtype, int backend, size_t m, size_t n, size_t k, uns
     return GEMMUL8_OK;
 }
 
-// scratch carving shared by the two halves of the scaling phase: rowmax int32[mp] | colmax int32[pad(n)] | amax bits | sft0 copies int16[mp] | int16[pad(n)]
-// (the copies of the preliminary shifts are what the shift finalize folded into the quantise launch reads: L->sftA / sftB receive the final values there)
-static inline size_t scale_scratch_bytes(size_t mp, size_t np) { return 4 * mp + 4 * np + 8 * std::max(mp, np) + 2 * (mp + np); }
+// scratch carving shared by the two halves of the scaling phase: rowmax int32[mp] | colmax int32[pad(n)] | sft0 copies int16[mp] | int16[pad(n)] | (256-aligned)
+// the partial row-maxima arrays of the row-strided operands (dead once the extract launch has run: the complex FP8 bound's float plane reuses the space).
+// The copies of the preliminary shifts are what the shift finalize folded into the quantise launch reads: L->sftA / sftB receive the final values there.
+static inline size_t scale_fixed_bytes(size_t mp, size_t np) { return (4 * (mp + np) + 2 * (mp + np) + 255) / 256 * 256; }
+static inline size_t scale_scratch_bytes(size_t mp, size_t np) { return scale_fixed_bytes(mp, np) + 8 * (mp + np); }  // at least one partial array per operand
 static int scale_scratch(const gemmul8_layout* L, size_t n, int** rowmax, int** colmax, void** amax, int16_t** s0A = nullptr, int16_t** s0B = nullptr) {
     const size_t np = padding256(n);
     if (L->scratch_bytes < scale_scratch_bytes(L->mp, np)) return GEMMUL8_E_ARG;
     *rowmax = (int*)L->scratch;
     *colmax = *rowmax + L->mp;
-    *amax = (void*)(*colmax + np);
-    int16_t* s0 = (int16_t*)((char*)*amax + 8 * std::max(L->mp, np));
+    int16_t* s0 = (int16_t*)(*colmax + np);
     if (s0A) *s0A = s0;
     if (s0B) *s0B = s0 + L->mp;
+    *amax = (char*)L->scratch + scale_fixed_bytes(L->mp, np);
     return GEMMUL8_OK;
 }
 
@@ -240,26 +242,31 @@ int gemmul8_scale_bounds(void* stream_, int dtype, int backend, int op_A, int op
     if (rc) return rc;
     const size_t np = padding256(n);
     const size_t bstrideA = cplx ? L->sizeA : 0, bstrideB = cplx ? L->sizeB : 0;
-    // The maxima arrays AND the amax scratch of the first row-strided extract (they are adjacent) start at zero.  The fill rides on the first K-MAJOR
-    // extract of the call (that operand then goes first; every kernel that accumulates into the words is launched after it); only when there is none --
-    // both operands row-strided, or the K-major one skipped -- does it cost a launch of its own (4-5 us of a launch-bound call).
-    const size_t zero_bytes = 4 * (L->mp + np) + 8 * std::max(L->mp, np);
+    // Round 6: (1) row maxima of the row-strided operands, both in one launch, as per-k-split partial arrays (no atomics: nothing to zero for them);
+    // (2) the extract of BOTH operands in one launch, which also zero-fills the bound GEMM's maxima arrays.  GEMMUL8_SCALE_FOLD=0 (testing): the zero-fill
+    // and the two extracts as launches of their own (the round-5 launch count).
     const bool runA = !skipA, runB = !skipB;
-    const int zero_on = !knobs().scale_fold ? -1 : (runA && kmajA) ? 0 : (runB && kmajB) ? 1 : -1;
-    if (zero_on < 0) OZ2_HIP(launch_zero(stream, rowmax, zero_bytes));
-    bool amax_zero = true;
-    auto extract = [&](int which) -> int {
-        const bool isA = which == 0;
-        if (!(isA ? runA : runB)) return 0;
-        const bool km = isA ? kmajA : kmajB;
-        OZ2_HIP(launch_extract(stream, dtype, backend, km, isA ? conjA : conjB, isA ? m : n, k, isA ? A : B, isA ? lda : ldb, (int8_t*)(isA ? L->A_bound : L->B_bound),
-                               isA ? bstrideA : bstrideB, L->kp, isA ? L->sftA : L->sftB, amax, amax_zero, isA ? g_batch.sa : g_batch.sb, isA ? s0A : s0B,
-                               which == zero_on ? (void*)rowmax : nullptr, which == zero_on ? zero_bytes : 0));
-        if (!km) amax_zero = false;  // (a second row-strided operand clears the shared amax scratch itself)
-        return 0;
-    };
-    if (int e = extract(zero_on == 1 ? 1 : 0)) return e;
-    if (int e = extract(zero_on == 1 ? 0 : 1)) return e;
+    const size_t ub = is_f32(dtype) ? 4 : 8;  // bytes of a row maximum
+    const size_t srA = runA && !kmajA ? L->mp : 0, srB = runB && !kmajB ? np : 0;  // padded row counts of the operands that need the pass
+    const size_t room = (L->scratch_bytes - scale_fixed_bytes(L->mp, np)) / ub;
+    ExtractOperand ea, eb;
+    if (runA) {
+        ea = ExtractOperand{kmajA, conjA, m, A, lda, (int8_t*)L->A_bound, bstrideA, L->sftA, s0A, g_batch.sa, nullptr, 1, L->mp};
+        if (srA) ea.amax = amax, ea.parts = amax_parts_for(m, k, room * srA / (srA + srB) / srA);
+    }
+    if (runB) {
+        eb = ExtractOperand{kmajB, conjB, n, B, ldb, (int8_t*)L->B_bound, bstrideB, L->sftB, s0B, g_batch.sb, nullptr, 1, np};
+        if (srB) eb.amax = (char*)amax + (srA ? (size_t)ea.parts * srA * ub : 0), eb.parts = amax_parts_for(n, k, room * srB / (srA + srB) / srB);
+    }
+    if (srA + srB) OZ2_HIP(launch_amax_pair(stream, dtype, k, ea, eb));
+    const size_t zero_bytes = 4 * (L->mp + np);
+    if (knobs().scale_fold) {
+        OZ2_HIP(launch_extract_pair(stream, dtype, backend, k, L->kp, ea, eb, rowmax, zero_bytes));
+    } else {
+        OZ2_HIP(launch_zero(stream, rowmax, zero_bytes));
+        OZ2_HIP(launch_extract_pair(stream, dtype, backend, k, L->kp, ea, ExtractOperand{}, nullptr, 0));
+        OZ2_HIP(launch_extract_pair(stream, dtype, backend, k, L->kp, ExtractOperand{}, eb, nullptr, 0));
+    }
     if (col_end > col_begin) {
         const int8_t* Ab = (const int8_t*)L->A_bound;
         const int8_t* Bb = (const int8_t*)L->B_bound + col_begin * L->kp;
@@ -270,8 +277,7 @@ int gemmul8_scale_bounds(void* stream_, int dtype, int backend, int op_A, int op
             // products ArBi, AiBr and (Ar-Ai)(Br-Bi) combined with round-up additions; the first two pass through a float
             // scratch plane [ncols][mp] behind the maxima arrays.
             const size_t ncols = col_end - col_begin;
-            const size_t used = scale_scratch_bytes(L->mp, np);
-            const size_t foff = (used + 255) / 256 * 256;
+            const size_t foff = scale_fixed_bytes(L->mp, np);  // (the partial row maxima behind it are dead by now)
             if (L->scratch_bytes < foff + 4 * L->mp * ncols) return GEMMUL8_E_ARG;
             float* fbuf = (float*)((char*)L->scratch + foff);
             OZ2_HIP(launch_gemm_f8_bound_cplx(stream, 1, Ab, Bb + L->sizeB, L->kp, k, m, ncols, fbuf, L->mp, rowmax, colmax + col_begin));

@@ -67,9 +67,25 @@ hipError_t launch_gemm_f8_bound_cplx(hipStream_t stream, int stage, const int8_t
 // zero `bytes` (a multiple of 4, 4-byte aligned) with a kernel: hipMemsetAsync nodes misbehave under HIP-graph replay on ROCm 7.2
 // (tests/test_gpu_graph.py), and a kernel launch is cheaper on the host than the runtime's memset path
 hipError_t launch_zero(hipStream_t stream, void* p, size_t bytes);
-hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajor, bool conj, size_t rows, size_t k, const void* X,
-                          size_t ld, int8_t* lo, size_t part_stride, size_t kp, int16_t* sft0, void* scratch_amax, bool amax_is_zero = false,
-                          size_t xstride = 0, int16_t* sft0_keep = nullptr, void* zero_p = nullptr, size_t zero_bytes = 0);
+// one operand of the accurate mode's extract launches; rows == 0 = absent (skip-scaling)
+struct ExtractOperand {
+    bool kmajor = false, conj = false;
+    size_t rows = 0;
+    const void* X = nullptr;
+    size_t ld = 0;
+    int8_t* lo = nullptr;      // bound plane(s)
+    size_t part_stride = 0;    // complex: bytes between the |Re|, |Im|, |Re| - |Im| planes
+    int16_t* sft0 = nullptr;   // preliminary shifts (workspace array) ...
+    int16_t* sft0_keep = nullptr;  // ... and their scratch copy (what the finalize folded into the quantise launch reads)
+    size_t xstride = 0;        // batched launch: bytes between the items' operands
+    void* amax = nullptr;      // row-strided operand: `parts` partial row-maxima arrays, pstride elements apart
+    unsigned parts = 1;
+    size_t pstride = 0;
+};
+unsigned amax_parts_for(size_t rows, size_t k, size_t max_parts);
+hipError_t launch_amax_pair(hipStream_t stream, int dtype, size_t k, const ExtractOperand& A, const ExtractOperand& B);  // row-strided operands only
+hipError_t launch_extract_pair(hipStream_t stream, int dtype, int backend, size_t k, size_t kp, const ExtractOperand& A, const ExtractOperand& B, void* zero_p,
+                               size_t zero_bytes);
 hipError_t launch_shift_finalize(hipStream_t stream, int backend, unsigned N, size_t rowsA, const int* maxA, int16_t* sftA, size_t rowsB,
                                  const int* maxB, int16_t* sftB);
 // one operand of the quantise / fast-shift launches; rows == 0 = absent (skip-scaling: the cached planes and shifts are kept)

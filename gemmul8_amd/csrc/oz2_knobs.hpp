@@ -17,7 +17,7 @@ struct Knobs {
     int gemm_cus = 0;              // GEMMUL8_GEMM_CUS=<n>: workgroups (= CUs) of the persistent INT8 residue-GEMM launches, a multiple of 8 (0: every CU); the phase-overlap measurements leave CUs to a second stream with it
     int crt_panels = 0;            // GEMMUL8_CRT_PANELS=<P>[r]: real INT8 whole call as P column panels, gemm(p) crt(p) back to back (SURVEY 8 f3 by cache residency); suffix r: every panel's residues go to panel 0's columns of C_mid (0: one GEMM launch, one CRT launch)
     int crt_panels_ring = 0;
-    int scale_fold = 1;            // GEMMUL8_SCALE_FOLD=0: accurate mode's zero-fill and shift finalize as launches of their own (the round-5 sequence) instead of riding on the first K-major extract / the quantise launch
+    int scale_fold = 1;            // GEMMUL8_SCALE_FOLD=0: accurate mode's zero-fill, two extracts and shift finalize as launches of their own (9 launches) instead of the extract-pair launch that also zero-fills and the quantise launch that also finalizes (6)
     int map_colblock = -1;         // GEMMUL8_MAP_COLBLOCK=<w>: tile-columns per column block of the GEMM tile walk, 0 = full width (-1: map_colblock's rule)
 };
 const Knobs& knobs();  // oz2_driver.hip

@@ -161,8 +161,8 @@ struct StageArgs {
     size_t part_stride;   // bytes between Re / Im / Re+Im plane sets
     const int16_t* sft;   // MODE_MOD: negated final shifts
     int16_t* sft0;        // MODE_BOUND: written (maxUFP - ilogb(amax))
-    unsigned* zero_p;     // MODE_BOUND, K-major: the launch also zero-fills zero_words 32-bit words from here (the maxima arrays + amax scratch of the bounds
-    unsigned zero_words;  //   phase: the bound GEMM's and the row-strided partner's atomicMax targets) -- instead of a launch of its own
+    unsigned* zero_p;     // MODE_BOUND (first operand of extract_pair_kernel): the launch also zero-fills zero_words 32-bit words from here (the maxima arrays
+    unsigned zero_words;  //   of the bounds phase: the bound GEMM's atomicMax targets) -- instead of a launch of its own
     int16_t* sft0_keep;   // MODE_BOUND: a second copy of sft0 in the scratch region (never overwritten by the final shifts: what the fused finalize reads)
     // MODE_MOD, accurate mode: the shift finalize (scaling_accu_real.hpp:6-18) folded into the quantise launch -- fin_max != nullptr: every workgroup
     // derives its rows' final shifts from (fin_sft0, fin_max) itself, the workgroup of a row's first k chunk stores the negated value to fin_out (= the
@@ -172,7 +172,9 @@ struct StageArgs {
     int16_t* fin_out;
     float fin_log2P;
     int fin_float_max;
-    const void* amax;     // MODE_BOUND, strided: per-row amax bit patterns (U-sized unsigned)
+    const void* amax;     // MODE_BOUND, strided: per-row amax bit patterns (U-sized unsigned), amax_parts partial arrays amax_pstride elements apart
+    unsigned amax_parts;  //   (round 6: amax_pair_kernel writes one array per k split, no atomics and no zero-fill; the extract takes their maximum)
+    size_t amax_pstride;
     int backend;
     int conj;
     int t_begin, t_end;
@@ -719,12 +721,6 @@ template <typename T, int MODE>
 __device__ __forceinline__ void stage_kmajor_body(const StageArgs& a, const unsigned bid) {
     using E = ET<T>;
     using U = typename E::U;
-    if constexpr (MODE == MODE_BOUND) {
-        if (a.zero_words) {  // the zero-fill of the bounds phase rides on this launch (every kernel that accumulates into the words runs after it)
-            unsigned* zp = (unsigned*)((char*)a.zero_p + OZ2_ZW);
-            for (unsigned i = bid * 256u + threadIdx.x; i < a.zero_words; i += gridDim.x * 256u) zp[i] = 0u;
-        }
-    }
     if constexpr (MODE == MODE_MOD) {
         if (a.f6) {
             // FP6 panel images: one workgroup per (8 rows, one 128-element K-step), the K-step index fastest: the eight rows' 16-byte X slots and
@@ -862,6 +858,8 @@ __device__ __forceinline__ void stage_strided_body(const StageArgs& a, const uns
     constexpr int CH = TK / 4;                                          // 4-wide k chunks per row
     constexpr int RPP = 256 / CH;                                       // rows per pass
     __shared__ __attribute__((aligned(16))) T tile[TR][PITCH];
+    using UBm = typename std::conditional<sizeof(U) == 8, unsigned long long, unsigned>::type;
+    [[maybe_unused]] __shared__ UBm rowam[TR];
 #if OZ2_STAGE_RTFAST
     const unsigned nrt = (unsigned)((a.rows + TR - 1) / TR);
     const unsigned kt = bid / nrt, rt = bid - kt * nrt;
@@ -871,6 +869,26 @@ __device__ __forceinline__ void stage_strided_body(const StageArgs& a, const uns
 #endif
     const size_t r0 = (size_t)rt * TR;
     const size_t kb = (size_t)kt * TK;
+    if constexpr (MODE == MODE_BOUND) {
+        // row maxima of the tile's rows = the maximum over the k splits' partial arrays (amax_pair_kernel): 256 threads = TR rows x PL lanes, one
+        // load per lane and partial (non-negative IEEE patterns order like unsigned integers), published to the passes below by the tile's barrier
+        constexpr int PL = 256 / TR;
+        const int rr = threadIdx.x / PL, pp = threadIdx.x % PL;
+        UBm v = 0;
+        if (r0 + rr < a.rows) {
+            const UBm* am = (const UBm*)((const char*)a.amax + OZ2_ZW) + r0 + rr;
+            for (unsigned q = pp; q < a.amax_parts; q += PL) {
+                const UBm w = am[(size_t)q * a.amax_pstride];
+                v = w > v ? w : v;
+            }
+        }
+#pragma unroll
+        for (int d = PL / 2; d >= 1; d >>= 1) {
+            const UBm w = __shfl_xor(v, d);
+            v = w > v ? w : v;
+        }
+        if (pp == 0) rowam[rr] = v;
+    }
     if constexpr (OZ2_STAGE_PAIRLOAD && sizeof(T) <= 8) {
         // 4- and 8-byte elements: a lane fetches RPL = 4 / 2 consecutive rows with one 16-byte load (a half / a quarter of the load
         // instructions, 1 KiB per wave instruction) when the rows exist and the group is 16-byte aligned; all loads of the tile are in
@@ -929,8 +947,7 @@ __device__ __forceinline__ void stage_strided_body(const StageArgs& a, const uns
         if (row >= a.rows) continue;
         int s;
         if constexpr (MODE == MODE_BOUND) {
-            using UB = typename std::conditional<sizeof(U) == 8, unsigned long long, unsigned>::type;
-            const UB bits = ((const UB*)((const char*)a.amax + OZ2_ZW))[row];
+            const UBm bits = rowam[rl];
             U am;
             __builtin_memcpy(&am, &bits, sizeof(U));
             s = (a.backend == kINT8 ? 5 : 7) - ilogb0(am);
@@ -948,9 +965,22 @@ __device__ __forceinline__ void stage_strided_body(const StageArgs& a, const uns
     }
 }
 
-// accurate-mode extract (MODE_BOUND): one operand per launch (a row-strided operand needs its row maxima first)
-template <typename T> __global__ void __launch_bounds__(256) extract_kmajor_kernel(const StageArgs a) { stage_kmajor_body<T, MODE_BOUND>(a, blockIdx.x); }
-template <typename T> __global__ void __launch_bounds__(256) extract_strided_kernel(const StageArgs a) { stage_strided_body<T, MODE_BOUND>(a, blockIdx.x); }
+// accurate-mode extract (MODE_BOUND) of BOTH operands in one launch (round 6; workgroups [0, nA) work on a, the rest on b; either share may be empty).  The
+// row maxima of row-strided operands come from amax_pair_kernel's partial arrays (no atomics, hence nothing to zero for them); the zero-fill of the bound GEMM's
+// maxima arrays rides on this launch (zero_p / zero_words of `a`).
+template <typename T> __global__ void __launch_bounds__(256) extract_pair_kernel(const StageArgs a, const StageArgs b, const unsigned nA, const int kmA, const int kmB) {
+    if (a.zero_words) {
+        unsigned* zp = (unsigned*)((char*)a.zero_p + OZ2_ZW);
+        for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < a.zero_words; i += gridDim.x * 256u) zp[i] = 0u;
+    }
+    if (blockIdx.x < nA) {
+        if (kmA) stage_kmajor_body<T, MODE_BOUND>(a, blockIdx.x);
+        else stage_strided_body<T, MODE_BOUND>(a, blockIdx.x);
+    } else {
+        if (kmB) stage_kmajor_body<T, MODE_BOUND>(b, blockIdx.x - nA);
+        else stage_strided_body<T, MODE_BOUND>(b, blockIdx.x - nA);
+    }
+}
 // quantise (MODE_MOD) of BOTH operands in one launch: workgroups [0, nA) work on a, the rest on b; either share may be empty (skip-scaling,
 // single-operand callers).  The two halves are independent and at launch-bound sizes each of them is a ~5-10 us dispatch (1024^3: 12.7 + 9.5 us,
 // together ... see DESIGN.md 3.2); the form of each operand (K-major / row-strided) is a uniform run-time branch, registers and LDS are the
@@ -1158,22 +1188,32 @@ template <typename T> __global__ void __launch_bounds__(256) OZ2_F6_KATTR quanti
     else stage_f6_body<T>(b, blockIdx.x - nA, kmB != 0, mine);
 }
 
-// per-row amax of a row-strided operand: grid (ceil(rows/64), ksplit), 256 threads = 64 rows x 4 k-lanes
-template <typename T> __global__ void __launch_bounds__(256) amax_strided_kernel(const T* X, size_t ld, size_t rows, size_t k, void* amax, size_t bx, size_t bw) {
-    X = (const T*)((const char*)X + blockIdx.z * bx);  // batched launch: item blockIdx.z
-    amax = (char*)amax + blockIdx.z * bw;
+// per-row amax of row-strided operands, BOTH operands in one launch (round 6): workgroup = 64 rows x one of `parts` k splits, 256 threads = 64 rows x 4 k-lanes;
+// the maxima of split y go to the partial array y (amax + y * pstride): no atomics, nothing to zero; the extract takes the maximum over the splits.
+struct AmaxOperand {
+    const void* X;
+    size_t ld, rows, bx;
+    void* amax;
+    size_t pstride;
+    unsigned parts, row_groups;
+};
+template <typename T> __device__ __forceinline__ void amax_strided_body(const AmaxOperand& o, const unsigned bid, size_t k, size_t bw) {
+    const T* X = (const T*)((const char*)o.X + blockIdx.z * o.bx);  // batched launch: item blockIdx.z
     using E = ET<T>;
     using U = typename E::U;
     using UB = typename std::conditional<sizeof(U) == 8, unsigned long long, unsigned>::type;
+    UB* amax = (UB*)((char*)o.amax + blockIdx.z * bw);
+    const unsigned by = bid / o.row_groups, bxr = bid - by * o.row_groups;  // the row group is the fast index: the workgroups in flight read whole columns
+    const size_t rows = o.rows, ld = o.ld;
     // a lane owns RPL consecutive rows = 16 bytes of a column (one 16-byte load when they exist and are aligned); 64 rows per workgroup,
     // the remaining lanes spread over KL k-lanes
     constexpr int RPL = OZ2_STAGE_PAIRLOAD ? 16 / (int)sizeof(T) : 1;
     constexpr int LPC = 64 / RPL, KL = 256 / LPC;
     __shared__ U sm[KL][64];
     const int rl = threadIdx.x % LPC, ky = threadIdx.x / LPC;
-    const size_t row0 = (size_t)blockIdx.x * 64 + (size_t)rl * RPL;
-    const size_t kper = (k + gridDim.y - 1) / gridDim.y;
-    const size_t kbeg = (size_t)blockIdx.y * kper, kend = (kbeg + kper < k) ? kbeg + kper : k;
+    const size_t row0 = (size_t)bxr * 64 + (size_t)rl * RPL;
+    const size_t kper = (k + o.parts - 1) / o.parts;
+    const size_t kbeg = (size_t)by * kper, kend = (kbeg + kper < k) ? kbeg + kper : k;
     U am[RPL];
 #pragma unroll
     for (int j = 0; j < RPL; ++j) am[j] = 0;
@@ -1218,15 +1258,19 @@ template <typename T> __global__ void __launch_bounds__(256) amax_strided_kernel
 #pragma unroll
     for (int j = 0; j < RPL; ++j) sm[ky][rl * RPL + j] = am[j];
     __syncthreads();
-    const size_t row = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t row = (size_t)bxr * 64 + threadIdx.x;
     if (threadIdx.x < 64 && row < rows) {
         U m = sm[0][threadIdx.x];
 #pragma unroll
         for (int y = 1; y < KL; ++y) m = sm[y][threadIdx.x] > m ? sm[y][threadIdx.x] : m;
         UB bits;
         __builtin_memcpy(&bits, &m, sizeof(U));
-        if (bits) atomicMax((UB*)amax + row, bits);  // non-negative IEEE values order like unsigned integers
+        amax[(size_t)by * o.pstride + row] = bits;  // (an empty k split writes 0: the identity of the maximum)
     }
+}
+template <typename T> __global__ void __launch_bounds__(256) amax_pair_kernel(const AmaxOperand a, const AmaxOperand b, const unsigned nA, size_t k, size_t bw) {
+    if (blockIdx.x < nA) amax_strided_body<T>(a, blockIdx.x, k, bw);
+    else amax_strided_body<T>(b, blockIdx.x - nA, k, bw);
 }
 
 template <typename T, int MODE> static size_t stage_blocks(bool kmajor, const StageArgs& a) {
@@ -1234,23 +1278,6 @@ template <typename T, int MODE> static size_t stage_blocks(bool kmajor, const St
     if (kmajor && MODE == MODE_MOD && a.f6) return ((a.rows + 7) / 8) * (a.kp / 128);
     if (kmajor) return a.rows * ((MODE == MODE_MOD && OZ2_STAGE_KCHUNK && sizeof(T) <= 8) ? (a.kp + 1023) / 1024 : 1);
     return (a.kp / StageTile<T>::TK) * ((a.rows + StageTile<T>::TR - 1) / StageTile<T>::TR);
-}
-template <typename T> static hipError_t launch_extract_stage(hipStream_t stream, bool kmajor, const StageArgs& a) {
-    const size_t blocks = stage_blocks<T, MODE_BOUND>(kmajor, a);
-    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
-    dim3 grid((unsigned)blocks, 1, g_batch.batch);
-    if (kmajor) hipLaunchKernelGGL(extract_kmajor_kernel<T>, grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(extract_strided_kernel<T>, grid, dim3(256), 0, stream, a);
-    return hipGetLastError();
-}
-static hipError_t dispatch_extract_stage(hipStream_t stream, int dtype, bool kmajor, const StageArgs& a) {
-    switch (dtype) {
-    case kF32: return launch_extract_stage<float>(stream, kmajor, a);
-    case kF64: return launch_extract_stage<double>(stream, kmajor, a);
-    case kC32: return launch_extract_stage<float2>(stream, kmajor, a);
-    case kC64: return launch_extract_stage<double2>(stream, kmajor, a);
-    }
-    return hipErrorInvalidValue;
 }
 template <typename T> static hipError_t launch_quantise_stage(hipStream_t stream, bool kmA, const StageArgs& a, bool kmB, const StageArgs& b) {
     if constexpr (OZ2_F6_LANE_KERNEL && !ET<T>::cplx) {
@@ -1282,77 +1309,79 @@ hipError_t launch_zero(hipStream_t stream, void* p, size_t bytes) {
     return hipGetLastError();
 }
 
-#ifndef OZ2_EXTRACT_CHUNK_MB
-#define OZ2_EXTRACT_CHUNK_MB 0    // (measured SLOWER: bounds phase 725 -> 771 us at 128 MiB, 796 at 64 MiB, profiles/archive/r03_hbm_ab_extract_chunking.txt) row-strided extract: amax -> extract per row block of at most this many MiB of the operand, so that the
-                                  // extract's read of the block is served by the 256 MiB Infinity Cache instead of HBM; 0 = one pass each
-#endif
-hipError_t launch_extract(hipStream_t stream, int dtype, int backend, bool kmajor, bool conj, size_t rows, size_t k, const void* X,
-                          size_t ld, int8_t* lo, size_t part_stride, size_t kp, int16_t* sft0, void* scratch_amax, bool amax_is_zero,
-                          size_t xstride, int16_t* sft0_keep, void* zero_p, size_t zero_bytes) {
-    if (rows == 0) return hipSuccess;
+// k splits of the row-maxima pass of a row-strided operand: enough workgroups to fill the chip (~2048) -- the per-thread chain of dependent strided loads,
+// not bandwidth, bounds that kernel when the grid is small -- at least 16 k values per workgroup, at most 16 splits (the extract reduces them per tile)
+// and at most what the caller's scratch holds (max_parts).
+unsigned amax_parts_for(size_t rows, size_t k, size_t max_parts) {
+    const size_t row_groups = (rows + 63) / 64;
+    size_t ks = (2048 + row_groups - 1) / row_groups;
+    ks = std::min(ks, (k + 15) / 16);
+    ks = std::min<size_t>(ks, 16);
+    ks = std::min(ks, max_parts);
+    return (unsigned)std::max<size_t>(ks, 1);
+}
+
+static StageArgs extract_args(int backend, size_t k, size_t kp, const ExtractOperand& o) {
     StageArgs a{};
-    a.bx = xstride;
+    a.bx = o.xstride;
     a.bw = g_batch.ws;
-    a.X = X;
-    a.ld = ld;
-    a.rows = rows;
+    a.X = o.X;
+    a.ld = o.ld;
+    a.rows = o.rows;
     a.k = k;
     a.kp = kp;
-    a.lo = lo;
-    a.part_stride = part_stride;
-    a.sft0 = sft0;
-    a.sft0_keep = sft0_keep;
-    if (kmajor && zero_p && zero_bytes) a.zero_p = (unsigned*)zero_p, a.zero_words = (unsigned)(zero_bytes / 4);
-    a.amax = scratch_amax;
+    a.lo = o.lo;
+    a.part_stride = o.part_stride;
+    a.sft0 = o.sft0;
+    a.sft0_keep = o.sft0_keep;
+    a.amax = o.amax;
+    a.amax_parts = o.parts;
+    a.amax_pstride = o.pstride;
     a.backend = backend;
-    a.conj = conj;
-    if (kmajor) return dispatch_extract_stage(stream, dtype, kmajor, a);
-
-    const size_t ub = is_f32(dtype) ? 4 : 8;                        // bytes of an amax slot
-    const size_t esz = ub * (is_complex(dtype) ? 2 : 1);            // bytes of an element
-    hipError_t e = amax_is_zero ? hipSuccess : launch_zero(stream, scratch_amax, ub * rows);
-    if (e != hipSuccess) return e;
-    // The operand is read twice (row maxima, then the bound plane).  Row blocks small enough for the Infinity Cache make the second
-    // read an on-die hit: block = a multiple of 256 rows with at most OZ2_EXTRACT_CHUNK_MB MiB (the batch items of a batched launch
-    // count: they run side by side).
-    size_t rb = rows;
-    const size_t row_bytes = k * esz * g_batch.batch;
-    if (OZ2_EXTRACT_CHUNK_MB > 0 && rows * row_bytes > ((size_t)OZ2_EXTRACT_CHUNK_MB << 20) * 3 / 2) {
-        rb = ((size_t)OZ2_EXTRACT_CHUNK_MB << 20) / row_bytes / 256 * 256;
-        if (rb < 256) rb = 256;
+    a.conj = o.conj;
+    return a;
+}
+template <typename T> static hipError_t launch_amax_pair_t(hipStream_t stream, size_t k, const ExtractOperand& A, const ExtractOperand& B) {
+    auto mk = [](const ExtractOperand& o) {
+        AmaxOperand q{};
+        if (o.rows && !o.kmajor) q = AmaxOperand{o.X, o.ld, o.rows, o.xstride, o.amax, o.pstride, o.parts, (unsigned)((o.rows + 63) / 64)};
+        return q;
+    };
+    const AmaxOperand a = mk(A), b = mk(B);
+    const size_t nA = (size_t)a.row_groups * a.parts, nB = (size_t)b.row_groups * b.parts;
+    if (nA + nB == 0) return hipSuccess;
+    if (nA + nB > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(amax_pair_kernel<T>, dim3((unsigned)(nA + nB), 1, g_batch.batch), dim3(256), 0, stream, a, b, (unsigned)nA, k, g_batch.ws);
+    return hipGetLastError();
+}
+hipError_t launch_amax_pair(hipStream_t stream, int dtype, size_t k, const ExtractOperand& A, const ExtractOperand& B) {
+    switch (dtype) {
+    case kF32: return launch_amax_pair_t<float>(stream, k, A, B);
+    case kF64: return launch_amax_pair_t<double>(stream, k, A, B);
+    case kC32: return launch_amax_pair_t<float2>(stream, k, A, B);
+    case kC64: return launch_amax_pair_t<double2>(stream, k, A, B);
     }
-    for (size_t r0 = 0; r0 < rows; r0 += rb) {
-        const size_t nr = std::min(rb, rows - r0);
-        const char* Xb = (const char*)X + r0 * esz;
-        void* amax_b = (char*)scratch_amax + r0 * ub;
-        // enough workgroups to fill the chip at every size (~2048), at least 16 k values per workgroup: the per-thread chain of
-        // dependent strided loads, not bandwidth, bounds this kernel when the grid is small (42 us at 1024^2 with k/512 splits)
-        const size_t row_groups = (nr + 63) / 64;
-        size_t ks = (2048 + row_groups - 1) / row_groups;
-        const size_t ks_max = (k + 15) / 16;
-        if (ks > ks_max) ks = ks_max;
-        if (ks < 1) ks = 1;
-        if (ks > 65535) ks = 65535;
-        dim3 grid((unsigned)row_groups, (unsigned)ks, g_batch.batch);
-        switch (dtype) {
-        case kF32: hipLaunchKernelGGL(amax_strided_kernel<float>, grid, dim3(256), 0, stream, (const float*)Xb, ld, nr, k, amax_b, xstride, g_batch.ws); break;
-        case kF64: hipLaunchKernelGGL(amax_strided_kernel<double>, grid, dim3(256), 0, stream, (const double*)Xb, ld, nr, k, amax_b, xstride, g_batch.ws); break;
-        case kC32: hipLaunchKernelGGL(amax_strided_kernel<float2>, grid, dim3(256), 0, stream, (const float2*)Xb, ld, nr, k, amax_b, xstride, g_batch.ws); break;
-        case kC64: hipLaunchKernelGGL(amax_strided_kernel<double2>, grid, dim3(256), 0, stream, (const double2*)Xb, ld, nr, k, amax_b, xstride, g_batch.ws); break;
-        }
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        StageArgs b = a;
-        b.X = Xb;
-        b.rows = nr;
-        b.lo = lo + r0 * kp;
-        b.sft0 = sft0 + r0;
-        b.sft0_keep = sft0_keep ? sft0_keep + r0 : nullptr;
-        b.amax = amax_b;
-        e = dispatch_extract_stage(stream, dtype, kmajor, b);
-        if (e != hipSuccess) return e;
+    return hipErrorInvalidValue;
+}
+template <typename T> static hipError_t launch_extract_pair_t(hipStream_t stream, bool kmA, StageArgs a, bool kmB, const StageArgs& b, void* zero_p, size_t zero_bytes) {
+    const size_t nA = stage_blocks<T, MODE_BOUND>(kmA, a), nB = stage_blocks<T, MODE_BOUND>(kmB, b);
+    if (nA + nB == 0) return zero_bytes ? launch_zero(stream, zero_p, zero_bytes) : hipSuccess;
+    if (nA + nB > 0x7FFFFFFFull) return hipErrorInvalidConfiguration;
+    if (zero_p && zero_bytes) a.zero_p = (unsigned*)zero_p, a.zero_words = (unsigned)(zero_bytes / 4);
+    hipLaunchKernelGGL(extract_pair_kernel<T>, dim3((unsigned)(nA + nB), 1, g_batch.batch), dim3(256), 0, stream, a, b, (unsigned)nA, (int)kmA, (int)kmB);
+    return hipGetLastError();
+}
+// extract of both operands (rows == 0: absent) in ONE launch; zero_p / zero_bytes: words the launch also zero-fills (the bound GEMM's maxima arrays)
+hipError_t launch_extract_pair(hipStream_t stream, int dtype, int backend, size_t k, size_t kp, const ExtractOperand& A, const ExtractOperand& B, void* zero_p,
+                               size_t zero_bytes) {
+    const StageArgs a = extract_args(backend, k, kp, A), b = extract_args(backend, k, kp, B);
+    switch (dtype) {
+    case kF32: return launch_extract_pair_t<float>(stream, A.kmajor, a, B.kmajor, b, zero_p, zero_bytes);
+    case kF64: return launch_extract_pair_t<double>(stream, A.kmajor, a, B.kmajor, b, zero_p, zero_bytes);
+    case kC32: return launch_extract_pair_t<float2>(stream, A.kmajor, a, B.kmajor, b, zero_p, zero_bytes);
+    case kC64: return launch_extract_pair_t<double2>(stream, A.kmajor, a, B.kmajor, b, zero_p, zero_bytes);
     }
-    return hipSuccess;
+    return hipErrorInvalidValue;
 }
 
 static StageArgs quantise_args(int backend, int t_begin, int t_end, size_t k, size_t kp, const QuantOperand& o) {

@@ -911,9 +911,9 @@ def test_crt_panels_knob_is_bit_identical(panels, monkeypatch):
 @pytest.mark.parametrize("ops", ["NN", "TN", "NT", "TT"])
 @pytest.mark.parametrize("backend,dtype,N", [("INT8", np.float64, 14), ("INT8", np.complex64, 7), ("FP8", np.float32, 6), ("FP8", np.complex128, 12)])
 def test_scale_launch_folds_are_bit_identical(backend, dtype, N, ops, monkeypatch):
-    """Round 6: in accurate mode the zero-fill of the maxima / amax scratch rides on the first K-MAJOR extract (which then goes first) and the shift
-    finalize (scaling_accu_real.hpp:6-18) on the quantise launch -- 7 launches instead of 9.  Every operand orientation (both K-major, one, none: the
-    zero-fill keeps its own launch there), both backends incl. the FP6 lane-per-fragment writer: same shifts, planes, C_mid and C as the unfolded sequence
+    """Round 6: accurate mode in 6 launches instead of 9 -- row maxima of row-strided operands as partial arrays (both operands in one launch, no atomics),
+    both extracts in one launch that also zero-fills the maxima arrays, the shift finalize (scaling_accu_real.hpp:6-18) on the quantise launch.  Every operand
+    orientation (both K-major, one, none), both backends incl. the FP6 lane-per-fragment writer: same shifts, planes, C_mid and C as the unfolded sequence
     (GEMMUL8_SCALE_FOLD=0) and as the oracle."""
     import gemmul8_amd as g
     import gpu_util as gu

@@ -35,6 +35,8 @@ N = int(sys.argv[5]) if len(sys.argv) > 5 else 14
 operand = n * n * 8.0  # one FP64 operand
 known_reads = {  # bytes a launch reads exactly once (config 2: DGEMM n^3, N moduli, op N/N)
     "oz2::amax_strided_kernel<double>": operand,
+    "oz2::amax_pair_kernel<double>": operand,            # round 6 names (config 2, op N/N: A is the one row-strided operand)
+    "oz2::extract_pair_kernel<double>": 2 * operand,
     "oz2::extract_strided_kernel<double>": operand,
     "oz2::extract_kmajor_kernel<double>": operand,
     "oz2::quantise_pair_kernel<double>": 2 * operand,       # round 4: A and B in one launch
@@ -51,6 +53,8 @@ if len(sys.argv) > 6 and sys.argv[6] == "fp8":   # config 3: SGEMM n^3, N moduli
     op32 = n * n * 4.0
     known_reads = {
         "oz2::amax_strided_kernel<float>": op32,
+        "oz2::amax_pair_kernel<float>": op32,
+        "oz2::extract_pair_kernel<float>": 2 * op32,
         "oz2::extract_strided_kernel<float>": op32,
         "oz2::extract_kmajor_kernel<float>": op32,
         "oz2::quantise_f6_pair_kernel<float>": 2 * op32,
