@@ -621,7 +621,7 @@ int gemmul8_add_row_bias(void* stream_, int dtype, size_t m, size_t n, void* D, 
 // ---- strided batch as ONE set of launches (no counterpart in the reference; hipblas{S,D,C,Z}gemmStridedBatched in the hook).
 // The items' workspaces are consecutive blocks of gemmul8_batched_item_bytes; every kernel of the pipeline takes the item from
 // gridDim.z (the persistent GEMM kernels fold the items into their plane sequence), so that a batch of small matrices fills the
-// chip and costs ten launches instead of ten per item.  Results are bit-identical to per-item gemmul8_gemm calls.
+// chip and costs six launches (accurate mode) instead of six per item.  Results are bit-identical to per-item gemmul8_gemm calls.
 size_t gemmul8_batched_item_bytes(int is_complex, int backend, size_t m, size_t n, size_t k, unsigned N) {
     return padding256(gemmul8_work_size(is_complex, backend, m, n, k, N, 0, 0, nullptr, nullptr));
 }
