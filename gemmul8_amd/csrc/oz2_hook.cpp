@@ -468,10 +468,10 @@ struct FloorModel {
 };
 // generated by tools/fit_floor.py from profiles/sweeps/r06_floor_scan_*.csv (the round-6 kernels: accurate mode two launches shorter, short-k epilogue +3-5 %; round 4's fit: r04b_floor_scan_*.csv)
 static const FloorModel kFloor[4][2] = {  // [S, D, C, Z][accurate, fast]
-    {{{0.0528, 2.43e-09, 3.744e-10, 1.811e-09, 3.499e-10, 5.918e-13}, {0.01988, 5.614e-10, 1.318e-11}}, {{0.04183, 1.137e-09, 3.872e-10, 1.045e-09, 3.596e-10, 5.634e-13}, {0.01988, 5.614e-10, 1.318e-11}}},
-    {{{0.04782, 3.915e-09, 3.807e-10, 1.729e-09, 4.399e-10, 5.737e-13}, {0.009298, 7.301e-10, 2.73e-11}}, {{0.03784, 1.884e-09, 3.954e-10, 7.854e-10, 4.495e-10, 5.699e-13}, {0.009298, 7.301e-10, 2.73e-11}}},
-    {{{0.06839, 7.064e-09, 1.107e-09, 3.484e-09, 1.75e-09, 1.696e-12}, {0.01251, 4.119e-10, 5.43e-11}}, {{0.05451, 3.132e-09, 1.153e-09, 1.843e-09, 1.757e-09, 1.686e-12}, {0.01251, 4.119e-10, 5.43e-11}}},
-    {{{0.07595, 1.291e-08, 1.186e-09, 2.128e-09, 2.04e-09, 1.747e-12}, {0.009309, 2.677e-10, 1.067e-10}}, {{0.0617, 8.163e-09, 1.162e-09, 1.052e-09, 2.083e-09, 1.678e-12}, {0.009309, 2.677e-10, 1.067e-10}}},
+    {{{0.05373, 2.353e-09, 3.999e-10, 1.821e-09, 3.555e-10, 6.155e-13}, {0.02155, 4.627e-10, 1.407e-11}}, {{0.04309, 1.051e-09, 4.238e-10, 1.091e-09, 3.574e-10, 5.79e-13}, {0.02155, 4.627e-10, 1.407e-11}}},
+    {{{0.04743, 3.922e-09, 4.089e-10, 1.218e-09, 5.024e-10, 5.943e-13}, {0.01043, 8.077e-10, 2.819e-11}}, {{0.03986, 1.88e-09, 4.137e-10, 4.544e-10, 4.8e-10, 5.863e-13}, {0.01043, 8.077e-10, 2.819e-11}}},
+    {{{0.06931, 6.912e-09, 1.196e-09, 3.604e-09, 1.806e-09, 1.761e-12}, {0.01406, 2.65e-10, 5.735e-11}}, {{0.05653, 2.963e-09, 1.234e-09, 2.005e-09, 1.787e-09, 1.72e-12}, {0.01406, 2.65e-10, 5.735e-11}}},
+    {{{0.07734, 1.242e-08, 1.326e-09, 1.842e-09, 2.131e-09, 1.734e-12}, {0.01304, 2.591e-10, 1.098e-10}}, {{0.06313, 7.525e-09, 1.292e-09, 9.713e-10, 2.174e-09, 1.625e-12}, {0.01304, 2.591e-10, 1.098e-10}}},
 };
 static bool floor_model_declines(int dtype, double m, double n, double k, unsigned N, bool fast, int backend, double batch) {
     const FloorModel& fm = kFloor[dtype][fast ? 1 : 0];
