@@ -1310,13 +1310,13 @@ hipError_t launch_zero(hipStream_t stream, void* p, size_t bytes) {
 }
 
 // k splits of the row-maxima pass of a row-strided operand: enough workgroups to fill the chip (~2048) -- the per-thread chain of dependent strided loads,
-// not bandwidth, bounds that kernel when the grid is small -- at least 16 k values per workgroup, at most 16 splits (the extract reduces them per tile)
+// not bandwidth, bounds that kernel when the grid is small -- at least 16 k values per workgroup, at most 32 splits (the extract reduces them per tile)
 // and at most what the caller's scratch holds (max_parts).
 unsigned amax_parts_for(size_t rows, size_t k, size_t max_parts) {
     const size_t row_groups = (rows + 63) / 64;
     size_t ks = (2048 + row_groups - 1) / row_groups;
     ks = std::min(ks, (k + 15) / 16);
-    ks = std::min<size_t>(ks, 16);
+    ks = std::min<size_t>(ks, 32);
     ks = std::min(ks, max_parts);
     return (unsigned)std::max<size_t>(ks, 1);
 }
