@@ -61,6 +61,11 @@ namespace oz2 {
 #ifndef OZ2_KBAR_PEEL_FIRST
 #define OZ2_KBAR_PEEL_FIRST 0
 #endif
+#ifndef OZ2_MOD256
+#define OZ2_MOD256 0  // 1: K <= 256 launches carry their accumulators as float patterns (EPI_MOD256 / RED_MAGIC: two instead of three instructions per accumulator in the
+                      // residue epilogue).  Built and bit-identical in round 6, measured NEUTRAL (8192^2 x 128 / 256: -1 / -2 %, 16384^2 x 256: +1 %,
+                      // profiles/r06_short_k_epilogue_ab.txt): the instruction count is not what bounds that epilogue.  Not instantiated in the shipped library.
+#endif
 #ifndef OZ2_SLEEP_A
 #define OZ2_SLEEP_A 4  // s_sleep units (64 clocks) between the A producers' 8 groups of 2 LDS-DMA instructions
 #endif
@@ -115,6 +120,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
     static_assert(FUSE == 0, "the in-kernel CRT forms are laboratory code: tools/experiments/fused_crt");
 #endif
     static_assert(FUSE == 0 || EPI == EPI_MOD, "the CRT tail follows the real requantise epilogue");
+    static_assert(EPI != EPI_MOD256 || (KBAR && SMALLK && FUSE == 0), "the K <= 256 form is an instantiation of the short-K K-step-barrier kernel");
     static_assert(offsetof(CrtArgs, Cmid) == 0 && alignof(CrtArgs) == 8, "i8_crt_tail locates the block in the kernel-argument segment");
     (void)crt;
     const int planes_per_tile = FUSE ? args.planes : 1;
@@ -232,7 +238,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
         int sA = 0;  // slot of A(g); B(g) sits in the next slot (mod 5)
         // MFMA_REINIT: the accumulators live across the tile loop; the v_mov initialisation runs once, every later tile finds them rewritten by
         // the matrix pipe behind the previous epilogue (MfmaReinitHook)
-        constexpr bool MFMA_REINIT = OZ2_KBAR_MFMA_REINIT && SMALLK && EPI == EPI_MOD && FUSE == 0;  // SMALLK only: with a register C operand (start value -2^31) the form measured -0.6 ... -1.6 % at k = 1024 / 2048 (profiles/r06_short_k_epilogue_ab.txt)
+        constexpr bool MFMA_REINIT = OZ2_KBAR_MFMA_REINIT && SMALLK && (EPI == EPI_MOD || EPI == EPI_MOD256) && FUSE == 0;  // SMALLK only: with a register C operand (start value -2^31) the form measured -0.6 ... -1.6 % at k = 1024 / 2048 (profiles/r06_short_k_epilogue_ab.txt)
         v4i acc[8][4];
         if constexpr (MFMA_REINIT) {
 #pragma unroll
@@ -337,7 +343,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
 #define OZ2_KBAR_EPI_LANE_LIVE 0
 #endif
             int lane_e = lane;
-            if constexpr (!OZ2_KBAR_EPI_LANE_LIVE && EPI == EPI_MOD) {  // (the complex combine keeps the live lane id: recomputed there, 116 bytes of accumulator spills appear in its K loop)
+            if constexpr (!OZ2_KBAR_EPI_LANE_LIVE && (EPI == EPI_MOD || EPI == EPI_MOD256)) {  // (the complex combine keeps the live lane id: recomputed there, 116 bytes of accumulator spills appear in its K loop)
             // The lane id of the epilogue is RECOMPUTED here (two v_mbcnt behind an opaque asm, so that it is not hoisted): kept live across the K loop it was
             // spilled (12 bytes of scratch), and the reload's vmcnt(0) made every tile wait for the PREVIOUS tile's residue stores to be acknowledged --
             // free behind a long K loop, a stall of the order of the store latency at k <= 1024 where the K loop is 2-8 us (round 6).  The consumer waves
@@ -348,7 +354,7 @@ __global__ void __launch_bounds__(WS_THREADS) gemm_i8_kernel(const GemmArgs args
             }
             if constexpr (FUSE != 0) i8_epilogue<EPI, NoHook, -1>(acc, args, PlaneRef{0, pl}, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane_e);
             else if constexpr (EPI == EPI_MAX) i8_epilogue<EPI, NoHook, 0>(acc, args, plane_ref(args, tmap.plane), PlaneConsts{}, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane_e);
-            else if constexpr (MFMA_REINIT) i8_epilogue<EPI, MfmaReinitHook<SMALLK>, (int)SMALLK>(acc, args, pref, pcon, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane_e, MfmaReinitHook<SMALLK>{acc, args.acc0});
+            else if constexpr (MFMA_REINIT) i8_epilogue<EPI, MfmaReinitHook<EPI != EPI_MOD256>, (int)SMALLK>(acc, args, pref, pcon, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane_e, MfmaReinitHook<EPI != EPI_MOD256>{acc, args.acc0});
             else i8_epilogue<EPI, NoHook, (int)SMALLK>(acc, args, pref, pcon, tmap.tm * BM + (WM1 ? 128 : 0), tmap.tn * BN + wn * 64, lane_e);
 #endif
             }  // phase
@@ -566,6 +572,13 @@ template <int EPI> static hipError_t launch(hipStream_t stream, GemmArgs& a, int
         }
     }
 #endif
+    if constexpr (EPI == EPI_MOD && OZ2_MOD256) {
+        // K <= 256: accumulators carried as float patterns (RED_MAGIC, oz2_gemm_i8_epi.hpp): 8192^2 x 256, 14 planes: see profiles/r06_short_k_epilogue_ab.txt
+        if ((size_t)a.kp * (size_t)a.nseg <= 256) {
+            a.acc0 = 0x4B400000;
+            return launch_sched<EPI_MOD256, true, 0, true>(stream, a);
+        }
+    }
     if constexpr (EPI != EPI_MAX) {
         if (a.acc0 == 0) return launch_sched<EPI, true, 0, true>(stream, a);  // K <= 512
         if (a.kp * a.nseg <= OZ2_KBAR_MAX_KP) return launch_sched<EPI, true>(stream, a);

@@ -34,7 +34,7 @@ namespace oz2 {
 #error "timing probes (OZ2_HOOK_SKIP_*) compute something else: not allowed in the product build of libgemmul8.so"
 #endif
 
-enum { EPI_MOD = 0, EPI_MAX = 1, EPI_CPLX = 2 };
+enum { EPI_MOD = 0, EPI_MAX = 1, EPI_CPLX = 2, EPI_MOD256 = 3 };  // EPI_MOD256 (round 6): EPI_MOD of launches with K <= 256, accumulators carried as float patterns (RED_MAGIC)
 
 struct GemmArgs {
     const int8_t* A[3];    // K-segment s of plane 0: A[s] + plane*strideA : [rows(pad 256)][kp]
@@ -93,7 +93,7 @@ __device__ __forceinline__ PlaneConsts plane_consts(const GemmArgs& args, PlaneR
     const int t = args.t_begin + pl.tt;
     return {args.moduli[t], args.dotw[t], args.dotc[t]};
 }
-enum { RED_ODD = 1, RED_ODD_SMALL = 3 };
+enum { RED_ODD = 1, RED_ODD_SMALL = 3, RED_MAGIC = 4 };
 // RED selects how an accumulator is reduced to its residue's low byte -- one form per kernel instantiation (i8_epilogue): RED_ODD for any int32
 // accumulator (byte dot product on the biased accumulator + one fp32 quotient, below), RED_ODD_SMALL for launches with K <= 512.  p = 256 runs through
 // the same forms: every quotient leaves the low byte of the accumulator in place.  History: an FP64 quotient step (5 instructions; the two-step fp32
@@ -111,6 +111,10 @@ struct NoHook {
 // live through the complete epilogue of every variant but the last: no accumulator register could be reused, the residues, the X / Y values and the
 // store addresses of the complex combine went to scratch (64-144 bytes), and every reload in between is a vector-memory wait that serialises the
 // epilogue's loads (see the EPI_CPLX branch below).  The waitcnt pass does not see the store; hidden stores only make its vmcnt waits conservative.
+// The s_nop 1 behind the store is REQUIRED (round 6): a VALU write to the data registers of a store of more than 8 bytes needs two wait states on gfx940 / gfx950
+// (LLVM GCNHazardRecognizer, VMEM store-data hazard); the compiler cannot see a store inside an asm block, so it neither counts nor inserts them.  Found when a new
+// kernel instantiation re-used the data registers right behind the block: non-temporal stores (read a little later) wrote half-overwritten residues
+// (tests/test_kernel_resources.py::test_inline_asm_stores_carry_their_wait_states pins the two wait states).
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 #ifndef OZ2_HOOK_SKIP_STORES
 #define OZ2_HOOK_SKIP_STORES 0  // timing probe (lab_hooks.hpp, OZ2_PROBE & 64): the epilogue's arithmetic without its stores
@@ -125,10 +129,10 @@ template <bool NT> __device__ __forceinline__ void store16_cols(void* ptr, v4u d
 #endif
     unsigned long long saved;
     if constexpr (NT)
-        asm volatile("s_mov_b64 %0, exec\n\tv_cmp_gt_i32_e32 vcc, %1, %2\n\ts_and_b64 exec, exec, vcc\n\tglobal_store_dwordx4 %3, %4, off nt\n\ts_mov_b64 exec, %0"
+        asm volatile("s_mov_b64 %0, exec\n\tv_cmp_gt_i32_e32 vcc, %1, %2\n\ts_and_b64 exec, exec, vcc\n\tglobal_store_dwordx4 %3, %4, off nt\n\ts_nop 1\n\ts_mov_b64 exec, %0"
                      : "=&s"(saved) : "s"(n), "v"(col), "v"(ptr), "v"(d) : "vcc", "scc", "memory");
     else
-        asm volatile("s_mov_b64 %0, exec\n\tv_cmp_gt_i32_e32 vcc, %1, %2\n\ts_and_b64 exec, exec, vcc\n\tglobal_store_dwordx4 %3, %4, off\n\ts_mov_b64 exec, %0"
+        asm volatile("s_mov_b64 %0, exec\n\tv_cmp_gt_i32_e32 vcc, %1, %2\n\ts_and_b64 exec, exec, vcc\n\tglobal_store_dwordx4 %3, %4, off\n\ts_nop 1\n\ts_mov_b64 exec, %0"
                      : "=&s"(saved) : "s"(n), "v"(col), "v"(ptr), "v"(d) : "vcc", "scc", "memory");
 }
 template <int EPI, int RED, typename Hook = NoHook>
@@ -138,7 +142,8 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
     const int p = pc.p;
     const float invp = 1.0f / (float)p;
     [[maybe_unused]] const unsigned dotw = pc.dotw, dotc = pc.dotc;
-    static_assert(RED == RED_ODD || RED == RED_ODD_SMALL, "one of the two reduction forms");
+    static_assert(RED == RED_ODD || RED == RED_ODD_SMALL || RED == RED_MAGIC, "one of the three reduction forms");
+    constexpr bool MODLIKE = EPI == EPI_MOD || EPI == EPI_MOD256;
     // RED_ODD_SMALL, short K (kp * nseg <= 512: |x| <= 512 * 127^2 < 2^23; the accumulators start at 0, GemmArgs.acc0): the quotient comes
     // straight from the accumulator -- v_cvt_f32_i32, one fma against 1.5 * 2^23 (its low 24 bits are 2^22 + q for either sign
     // of q), v_mad_i32_i24: the canonical residue minus p 2^22, i.e. the canonical LOW BYTE, which is all the epilogue stores.
@@ -169,6 +174,19 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
         asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r0) : "v"(__float_as_int(qm[0])), "s"(-p), "v"(u0));
         asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r1) : "v"(__float_as_int(qm[1])), "s"(-p), "v"(u1));
     };
+    // RED_MAGIC, K <= 256 (round 6): the accumulators start at 0x4B400000 (GemmArgs.acc0), the bit pattern of the float 1.5 * 2^23; an int32 sum |x| <= 256 * 128^2 = 2^22
+    // added to it as an INTEGER leaves the pattern of the float 1.5 * 2^23 + x (ulp 1 on [2^23, 2^24], both ends representable).  So the conversion of RED_ODD_SMALL
+    // becomes a packed subtraction on two accumulators, its fma a packed fma with the very same operands (same quotient, bit for bit), and v_mad_i32_i24 finishes on
+    // the biased register: the bias has no bit below 2^22, the low byte -- all the epilogue keeps -- is that of x - q p.  Two instructions per accumulator instead of
+    // three (~20 % of the epilogue's vector-ALU work; CPU model: tests/test_residue_math.py::test_magic_bias_reduction).
+    [[maybe_unused]] auto red_magic_pair = [&](int x0, int x1, int& r0, int& r1) {
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f xm = {__int_as_float(x0), __int_as_float(x1)};
+        const v2f xf = xm - v2f{12582912.0f, 12582912.0f};
+        const v2f qm = __builtin_elementwise_fma(xf, v2f{invp, invp}, v2f{12582912.0f, 12582912.0f});
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r0) : "v"(__float_as_int(qm[0])), "s"(-p), "v"(x0));
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r1) : "v"(__float_as_int(qm[1])), "s"(-p), "v"(x1));
+    };
     [[maybe_unused]] auto red_small = [&](int x) { return mod_small_sym_odd(x, p, invp); };  // |x| < 2^16 (complex combine); p = 256: the low byte survives
     // After the 4 x 4 dword transpose below lane (q, c16) owns the 16 consecutive rows i0 + 64 tg + 16 q .. + 15 of column
     // j0 + 16 tj + c16: one 64-bit element offset per lane for the whole block, the (tg, tj) sub-blocks add 64 tg and 16 tj * ldo --
@@ -185,6 +203,9 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
             if constexpr (RED == RED_ODD) {
                 red_odd_pair(acc[tg * 4 + ti][tj][0], acc[tg * 4 + ti][tj][1], r[0], r[1]);
                 red_odd_pair(acc[tg * 4 + ti][tj][2], acc[tg * 4 + ti][tj][3], r[2], r[3]);
+            } else if constexpr (RED == RED_MAGIC) {
+                red_magic_pair(acc[tg * 4 + ti][tj][0], acc[tg * 4 + ti][tj][1], r[0], r[1]);
+                red_magic_pair(acc[tg * 4 + ti][tj][2], acc[tg * 4 + ti][tj][3], r[2], r[3]);
             } else {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) r[b] = red(acc[tg * 4 + ti][tj][b]);
@@ -202,7 +223,7 @@ __device__ __forceinline__ void i8_epilogue_mod(const v4i (&acc)[8][4], const Ge
         const auto w23 = __builtin_amdgcn_permlane16_swap(s0[1], s1[1], false, false);  //         rows 8-11, rows 12-15
         z[0] = w01[0], z[1] = w01[1], z[2] = w23[0], z[3] = w23[1];
     };
-    if constexpr (EPI == EPI_MOD) {
+    if constexpr (MODLIKE) {
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
             const int col = j0 + tj * 16 + c16;
@@ -295,7 +316,9 @@ __device__ __forceinline__ void i8_epilogue(const v4i (&acc)[8][4], const GemmAr
     const int c16 = lane & 15;
     const int q = lane >> 4;
 
-    if constexpr (EPI == EPI_MOD || EPI == EPI_CPLX) {
+    if constexpr (EPI == EPI_MOD256) {
+        i8_epilogue_mod<EPI, RED_MAGIC, Hook>(acc, args, pl, pc, i0, j0, lane, hook);
+    } else if constexpr (EPI == EPI_MOD || EPI == EPI_CPLX) {
         // ONE reduction form per kernel instantiation (SMALLK: the launch's accumulators start at 0, K <= 512).  p = 256 takes the odd-modulus forms too:
         // the only thing the epilogue keeps of a residue is its low byte, and for p = 256 every quotient leaves the low byte of the accumulator
         // in place (dotw = 1, dotc = 0).  Until round 4 the epilogue was a run-time chain of four forms (256 / small / odd / generic); the

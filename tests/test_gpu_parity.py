@@ -406,7 +406,8 @@ def test_complex_bound_one_or_two_launches(dtype, tile, launches, monkeypatch):
 @pytest.mark.parametrize("k", [256, 512, 768, 1024, 4096])
 def test_epilogue_reduction_on_extreme_accumulators(k):
     """The requantise epilogue on accumulators AT the bounds the residue planes allow (planes of +-127 with long runs of equal sign, so
-    |sum| reaches k * 127^2), fed straight to gemmul8_lowprec_gemm: K <= 512 takes the three-instruction form (exact below 2^23),
+    |sum| reaches k * 127^2), fed straight to gemmul8_lowprec_gemm: K <= 512 takes the three-instruction form (exact below 2^23; k = 256 also
+    runs a row of -128 x -128 = the 2^22 bound of the float-pattern form that -DOZ2_MOD256=1 builds use there),
     longer K the byte-dot form on biased accumulators (any int32).  Random operands never come near these values; the expected residues
     are plain integer arithmetic."""
     import ctypes as C
@@ -426,6 +427,8 @@ def test_epilogue_reduction_on_extreme_accumulators(k):
         x[:, 0, :] = 127                      # rows of one sign: the largest sums
         x[:, 1, :] = -127
         x[:, 2, ::2] = 127
+        if k == 256:
+            x[:, 3, :] = -128                 # 256 * 128^2 = 2^22: the bound of the float-pattern form (RED_MAGIC, -DOZ2_MOD256=1 builds)
         out = np.zeros((N, rows_pad, k), dtype=np.int8)
         out[:, :rows] = x
         return x, out
@@ -441,7 +444,7 @@ def test_epilogue_reduction_on_extreme_accumulators(k):
     moduli = [256, 255, 253, 251, 247, 241, 239, 233, 229, 227, 223, 217, 211, 199]
     for t, p in enumerate(moduli):
         acc = A[t].astype(np.int64) @ B[t].astype(np.int64).T          # (m, n)
-        assert np.abs(acc).max() == k * 127 * 127                      # the bound is reached
+        assert np.abs(acc).max() == (k * 128 * 128 if k == 256 else k * 127 * 127)   # the bound is reached
         r = np.mod(acc, p)
         r = np.where(r > (p - 1) // 2, r - p, r) if p != 256 else ((acc + 128) % 256 - 128)
         assert np.array_equal(got[t], r.T.astype(np.int8)), (k, p)

@@ -67,10 +67,10 @@ def _mfma_blocks(blocks):
 
 def test_int8_kernels_registers_and_scratch(i8):
     ks = {n: v for n, v in i8.items() if "gemm_i8_kernel" in n}
-    assert len(ks) == 7, sorted(ks)   # MOD / CPLX x {K-step barrier small-K, K-step barrier, ping-pong} + the bound GEMM
+    assert len(ks) == 7, sorted(ks)   # MOD / CPLX x {K-step barrier small-K, K-step barrier, ping-pong} + the bound GEMM (a -DOZ2_MOD256=1 build adds EPI_MOD256)
     for n, (vg, sc, blocks) in ks.items():
         assert vg <= 168, (n, vg)     # 12 waves per CU = 3 per SIMD
-        residue = "ILi0E" in n or "ILi2E" in n
+        residue = "ILi0E" in n or "ILi2E" in n or "ILi3E" in n
         # the residue kernels keep a handful of kernel-lifetime values in scratch (entry / tile start); the epilogues spill nothing
         assert sc <= (32 if residue else 256), (n, sc)
         loops = _mfma_blocks(blocks)
@@ -216,3 +216,17 @@ def test_fp6_quantise_lane_kernel_uses_the_hardware_pack_and_two_waves():
             assert sum(l.startswith("v_mov_b32") for l in b) <= 8, (n, "fragment operands are copied into place")
         hot = [b for b in blocks if sum(l.startswith("v_pk_fma_f32") or l.startswith("v_fma_f32") for l in b) >= 32 and not any("v_cmp_eq_f32" in l for l in b)]
         assert hot, (n, "no residue block without the tie compare: the even-modulus fix runs for every modulus")
+
+
+def test_inline_asm_stores_carry_their_wait_states(i8):
+    """store16_cols (oz2_gemm_i8_epi.hpp) issues its 16-byte residue stores from an asm block: invisible to the compiler's hazard recognizer, which on gfx950 must keep
+    two wait states between a store of more than 8 bytes and a VALU write to its data registers.  Round 6 found that hazard live (a kernel re-used the registers
+    right behind the block; non-temporal stores wrote half-overwritten data).  Every such store in every INT8 kernel must be followed by `s_nop 1` inside its block."""
+    n_stores = 0
+    for n, (vg, sc, blocks) in i8.items():
+        flat = [l for b in blocks for l in b]
+        for i, l in enumerate(flat):
+            if l.startswith("global_store_dwordx4") and i >= 3 and flat[i - 1].startswith("s_and_b64 exec"):   # the asm block's store (exec narrowed right before it)
+                n_stores += 1
+                assert flat[i + 1].split() == ["s_nop", "1"], (n, flat[i:i + 3])
+    assert n_stores >= 7 * 16, n_stores

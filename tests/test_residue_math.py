@@ -540,3 +540,26 @@ def test_fp6_panel_image_codec_round_trip():
         nb = (rows_img + 255) // 256
         img = gu.f6_plane_image(v, rows_img, kp, nb * 256 * (kp // 4 * 3))
         assert np.array_equal(gu.f6_plane_values(img, rows, rows_img, kp), v)
+
+
+@pytest.mark.parametrize("p", INT8_MODULI)
+def test_magic_bias_reduction(p):
+    """INT8 GEMM epilogue for K <= 256 (round 6, oz2_gemm_i8_epi.hpp RED_MAGIC): the accumulators start at 0x4B400000, the bit pattern of the float
+    1.5 * 2^23, and |x| <= 256 * 128^2 = 2^22: the INTEGER sum pattern 0x4B400000 + x IS the float 1.5 * 2^23 + x (ulp 1 on [2^23, 2^24], ends included), so
+    float(x) = as_float(acc) - 1.5 * 2^23 exactly -- the quotient is RED_ODD_SMALL's, bit for bit -- and v_mad_i32_i24 on the biased register returns the
+    canonical residue's LOW BYTE (the bias has no bit below 2^22).  EXHAUSTIVE over |x| <= 2^22."""
+    lim = 1 << 22
+    x = np.arange(-lim, lim + 1, dtype=np.int64)
+    acc = (np.int64(0x4B400000) + x).astype(np.uint32)
+    f = acc.view(np.float32)
+    assert np.array_equal(f.astype(np.float64), 12582912.0 + x)                          # the pattern is the float, at both ends too
+    xf = (f.astype(np.float64) - 12582912.0).astype(np.float32)                          # v_pk_add_f32: exact
+    assert np.array_equal(xf.astype(np.int64), x)
+    invp = np.float32(1.0) / np.float32(p)
+    qf = (xf.astype(np.float64) * np.float64(invp) + np.float64(12582912.0)).astype(np.float32)     # v_pk_fma_f32: one rounding at unit spacing
+    qf_small = (x.astype(np.float32).astype(np.float64) * np.float64(invp) + np.float64(12582912.0)).astype(np.float32)
+    assert np.array_equal(qf.view(np.uint32), qf_small.view(np.uint32))                  # RED_ODD_SMALL's quotient
+    low24 = qf.view(np.uint32).astype(np.int64) & 0xFFFFFF
+    got = (low24 * (-p) + acc.astype(np.int64)) & 0xFF                                   # v_mad_i32_i24 (low 24 bits of src0, 32-bit add), low byte
+    want = (sym_exact(x, p) & 0xFF) if p != 256 else (x & 0xFF)
+    assert np.array_equal(got, want)
