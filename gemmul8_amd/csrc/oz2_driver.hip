@@ -135,7 +135,7 @@ int gemmul8_set_fp8_bound_mode(int mode) {
 int gemmul8_abi_version(void) { return GEMMUL8_ABI_VERSION; }
 size_t gemmul8_layout_bytes(void) { return sizeof(gemmul8_layout); }
 
-const char* gemmul8_version(void) { return "gemmul8-mi355x 0.4 (gfx950; v_mfma_i32_16x16x64_i8 / v_mfma_scale_f32_16x16x128_f8f6f4, fused epilogues)"; }
+const char* gemmul8_version(void) { return "gemmul8-mi355x 0.5 (gfx950; v_mfma_i32_16x16x64_i8 / v_mfma_scale_f32_16x16x128_f8f6f4, fused epilogues)"; }
 
 size_t gemmul8_work_size(int is_complex, int backend, size_t m, size_t n, size_t k, unsigned N, int enA, int enB, size_t* wA,
                          size_t* wB) {
